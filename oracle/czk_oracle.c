@@ -1,0 +1,510 @@
+/* czk_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's hot path, limb-exact:
+ * Fp256/Fp384 Montgomery arithmetic, Fp2, short-Weierstrass Jacobian group law, Pippenger
+ * VariableBaseMSM with the reference window rule, the fffft-style in-order radix-2 FFT with the
+ * reference's root selection (LARGE_SUBGROUP_ROOT_OF_UNITY^3) and coset shift (22), and the Groth16
+ * witness-map / MSM sequence.  It is the checker for tests/, __graft_entry__.smoke() and the timed
+ * `cpu_baseline` leg of bench.py; the product library (collaborative-zksnark_amd/csrc) never links,
+ * loads or calls it.
+ *
+ * Pinning: the reference cannot be built here (Rust nightly + crates.io, no cargo in the image) and holds
+ * no golden NTT/MSM vectors, so this restatement is pinned against (a) the reference's constant KATs and
+ * (b) the independent Python big-int oracle oracle/pyref.py, via tests/test_oracle_*.py and the
+ * fixtures under tests/golden/.  Beyond those it is "parity unpinned" (see DESIGN.md).
+ *
+ * Paths in comments are relative to /root/reference.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+
+/* utils/src/lib.rs:65-73 -- ark_std::log2 = ceil(log2(x)), log2(0) = 0 */
+static unsigned orc_log2(size_t x) {
+    if (x == 0) return 0;
+    unsigned lz = (unsigned)__builtin_clzll((unsigned long long)x);
+    if ((x & (x - 1)) == 0) return 63 - lz;
+    return 64 - lz;
+}
+
+/* ------------------------------------------------------------------ Fr = Fp256<FrParameters> */
+/* curves/bls12_377/src/fields/fr.rs:30-75 */
+static const uint64_t fr_MODULUS[4] = {725501752471715841ULL, 6461107452199829505ULL, 6968279316240510977ULL,
+                                       1345280370688173398ULL};
+static const uint64_t fr_R[4] = {9015221291577245683ULL, 8239323489949974514ULL, 1646089257421115374ULL,
+                                 958099254763297437ULL};
+static const uint64_t fr_R2[4] = {2726216793283724667ULL, 14712177743343147295ULL, 12091039717619697043ULL,
+                                  81024008013859129ULL};
+#define fr_INV 725501752471715839ULL
+/* fr.rs:69-74 GENERATOR (Montgomery limbs; decodes to 22) */
+static const uint64_t fr_GENERATOR[4] = {2984901390528151251ULL, 10561528701063790279ULL, 5476750214495080041ULL,
+                                         898978044469942640ULL};
+/* fr.rs:21-28 LARGE_SUBGROUP_ROOT_OF_UNITY (Montgomery limbs), SMALL_SUBGROUP_BASE = 3, adicity 1 */
+static const uint64_t fr_LARGE_ROOT[4] = {0x9bfe9d90c790c167ULL, 0x7175a69e39013bffULL, 0x3fbbb698adabcf93ULL,
+                                          0xc59f8d8d6f0dc97ULL};
+#define FR_TWO_ADICITY 47
+
+#define FP_N 4
+#define FP(x) fr_##x
+#define FP_T fr_t
+#include "fp_tmpl.h"
+#undef FP_N
+#undef FP
+#undef FP_T
+
+/* ------------------------------------------------------------------ Fq = Fp384<FqParameters> */
+/* curves/bls12_377/src/fields/fq.rs:23-62 */
+static const uint64_t fq_MODULUS[6] = {0x8508c00000000001ULL, 0x170b5d4430000000ULL, 0x1ef3622fba094800ULL,
+                                       0x1a22d9f300f5138fULL, 0xc63b05c06ca1493bULL, 0x1ae3a4617c510eaULL};
+static const uint64_t fq_R[6] = {202099033278250856ULL, 5854854902718660529ULL, 11492539364873682930ULL,
+                                 8885205928937022213ULL, 5545221690922665192ULL, 39800542322357402ULL};
+static const uint64_t fq_R2[6] = {0xb786686c9400cd22ULL, 0x329fcaab00431b1ULL, 0x22a5f11162d6b46dULL,
+                                  0xbfdf7d03827dc3acULL, 0x837e92f041790bf9ULL, 0x6dfccb1e914b88ULL};
+#define fq_INV 9586122913090633727ULL
+
+#define FP_N 6
+#define FP(x) fq_##x
+#define FP_T fq_t
+#include "fp_tmpl.h"
+#undef FP_N
+#undef FP
+#undef FP_T
+
+/* ------------------------------------------------------------------ Fq2 = Fq[u]/(u^2 + 5) */
+/* algebra/ff/src/fields/models/quadratic_extension.rs; NONRESIDUE = -5 (curves/bls12_377/src/fields/fq2.rs:13) */
+typedef struct { fq_t c0, c1; } fq2_t;
+
+/* fq2.rs:29-34 -- mul_fp_by_nonresidue: -(2x) doubled, minus x  =  -5x */
+static void fq_mul_by_nonresidue(fq_t *r, const fq_t *x) {
+    fq_t t;
+    fq_dbl(&t, x);
+    fq_neg(&t, &t);
+    fq_dbl(&t, &t);
+    fq_sub(r, &t, x);
+}
+static void fq2_zero(fq2_t *a) { fq_zero(&a->c0); fq_zero(&a->c1); }
+static void fq2_one(fq2_t *a) { fq_one(&a->c0); fq_zero(&a->c1); }
+static int fq2_is_zero(const fq2_t *a) { return fq_is_zero(&a->c0) && fq_is_zero(&a->c1); }
+static int fq2_is_one(const fq2_t *a) { return fq_is_one(&a->c0) && fq_is_zero(&a->c1); }
+static int fq2_eq(const fq2_t *a, const fq2_t *b) { return fq_eq(&a->c0, &b->c0) && fq_eq(&a->c1, &b->c1); }
+/* quadratic_extension.rs:552-565 */
+static void fq2_add(fq2_t *r, const fq2_t *a, const fq2_t *b) { fq_add(&r->c0, &a->c0, &b->c0); fq_add(&r->c1, &a->c1, &b->c1); }
+static void fq2_sub(fq2_t *r, const fq2_t *a, const fq2_t *b) { fq_sub(&r->c0, &a->c0, &b->c0); fq_sub(&r->c1, &a->c1, &b->c1); }
+/* :227-231 */
+static void fq2_dbl(fq2_t *r, const fq2_t *a) { fq_dbl(&r->c0, &a->c0); fq_dbl(&r->c1, &a->c1); }
+static void fq2_neg(fq2_t *r, const fq2_t *a) { fq_neg(&r->c0, &a->c0); fq_neg(&r->c1, &a->c1); }
+/* :571-583 -- Karatsuba */
+static void fq2_mul(fq2_t *r, const fq2_t *a, const fq2_t *b) {
+    fq_t v0, v1, s, t, nr;
+    fq_mul(&v0, &a->c0, &b->c0);
+    fq_mul(&v1, &a->c1, &b->c1);
+    fq_add(&s, &a->c1, &a->c0);
+    fq_add(&t, &b->c0, &b->c1);
+    fq_mul(&s, &s, &t);
+    fq_sub(&s, &s, &v0);
+    fq_sub(&s, &s, &v1);
+    fq_mul_by_nonresidue(&nr, &v1);          /* add_and_mul_base_field_by_nonresidue(v0, v1) = v0 + beta*v1 */
+    fq_add(&r->c0, &v0, &nr);
+    r->c1 = s;
+}
+/* :257-305 -- square_in_place, generic (beta != -1) branch */
+static void fq2_sqr(fq2_t *r, const fq2_t *a) {
+    fq_t v0, v3, v2, nr, t;
+    fq_sub(&v0, &a->c0, &a->c1);
+    fq_mul_by_nonresidue(&nr, &a->c1);
+    fq_sub(&v3, &a->c0, &nr);                /* sub_and_mul_base_field_by_nonresidue: c0 - beta*c1 */
+    fq_mul(&v2, &a->c0, &a->c1);
+    fq_mul(&v0, &v0, &v3);
+    fq_dbl(&r->c1, &v2);
+    /* add_and_mul_base_field_by_nonresidue_plus_one(v0, v2) = (v0 + v2) + beta*v2  (quadratic_extension.rs:71-78) */
+    fq_add(&t, &v0, &v2);
+    fq_mul_by_nonresidue(&nr, &v2);
+    fq_add(&r->c0, &t, &nr);
+}
+/* :308-324 */
+static int fq2_inv(fq2_t *r, const fq2_t *a) {
+    if (fq2_is_zero(a)) return 0;
+    fq_t v1, v0, nr, t;
+    fq_sqr(&v1, &a->c1);
+    fq_sqr(&t, &a->c0);
+    fq_mul_by_nonresidue(&nr, &v1);
+    fq_sub(&v0, &t, &nr);
+    fq_inv(&v1, &v0);
+    fq_mul(&r->c0, &a->c0, &v1);
+    fq_mul(&t, &a->c1, &v1);
+    fq_neg(&r->c1, &t);
+    return 1;
+}
+
+/* ------------------------------------------------------------------ G1 / G2 */
+#define BF(x) fq_##x
+#define BF_T fq_t
+#define EC(x) g1_##x
+#include "ec_tmpl.h"
+#undef BF
+#undef BF_T
+#undef EC
+
+#define BF(x) fq2_##x
+#define BF_T fq2_t
+#define EC(x) g2_##x
+#include "ec_tmpl.h"
+#undef BF
+#undef BF_T
+#undef EC
+
+/* ------------------------------------------------------------------ Radix2EvaluationDomain<Fr> */
+typedef struct {
+    uint64_t size;
+    unsigned log_size;
+    fr_t size_inv, group_gen, group_gen_inv, generator, generator_inv;
+} orc_domain_t;
+
+/* algebra/ff/src/fields/mod.rs:337-386 -- get_root_of_unity, LARGE_SUBGROUP branch (n a power of two:
+ * q_adicity = 0 so omega = LARGE^3, then squared TWO_ADICITY - log2(n) times). */
+static int orc_root_of_unity(fr_t *omega, unsigned log_n) {
+    if (log_n > FR_TWO_ADICITY) return 0;
+    fr_t w;
+    memcpy(w.l, fr_LARGE_ROOT, sizeof w.l);
+    const uint64_t three[1] = {3};
+    fr_pow(&w, &w, three, 1);
+    for (unsigned i = log_n; i < FR_TWO_ADICITY; i++) fr_sqr(&w, &w);
+    *omega = w;
+    return 1;
+}
+
+/* algebra/poly/src/domain/radix2/mod.rs:51-82 -- Radix2EvaluationDomain::new */
+static int orc_domain_new(orc_domain_t *d, size_t num_coeffs) {
+    uint64_t size = 1;
+    unsigned lg = 0;
+    while (size < num_coeffs) { size <<= 1; lg++; }
+    if (lg > FR_TWO_ADICITY) return 0;
+    d->size = size;
+    d->log_size = lg;
+    if (!orc_root_of_unity(&d->group_gen, lg)) return 0;
+    fr_t sz;
+    fr_from_u64(&sz, size);
+    fr_inv(&d->size_inv, &sz);
+    fr_inv(&d->group_gen_inv, &d->group_gen);
+    memcpy(d->generator.l, fr_GENERATOR, sizeof d->generator.l);
+    fr_inv(&d->generator_inv, &d->generator);
+    return 1;
+}
+
+/* radix2/fft.rs:248-260 -- derange (bit-reversal permutation) */
+static void orc_derange(fr_t *x, size_t n, unsigned log_n) {
+    for (uint64_t idx = 1; idx + 1 < n; idx++) {
+        uint64_t r = 0, t = idx;
+        for (unsigned b = 0; b < log_n; b++) { r = (r << 1) | (t & 1); t >>= 1; }
+        if (idx < r) { fr_t tmp = x[idx]; x[idx] = x[r]; x[r] = tmp; }
+    }
+}
+/* domain/utils.rs:22-39 + radix2/fft.rs:75-78 -- roots_of_unity: size/2 successive powers */
+static fr_t *orc_roots(size_t half, const fr_t *root) {
+    fr_t *roots = (fr_t *)malloc((half ? half : 1) * sizeof(fr_t));
+    fr_t v;
+    fr_one(&v);
+    for (size_t i = 0; i < half; i++) { roots[i] = v; fr_mul(&v, &v, root); }
+    return roots;
+}
+/* radix2/fft.rs:140-203 -- io_helper (DIF, gap n/2 .. 1), serial build incl. root compaction :194-200 */
+static void orc_io_helper(fr_t *x, size_t n, const fr_t *root) {
+    fr_t *roots = orc_roots(n / 2, root);
+    size_t root_len = n / 2;
+    for (size_t gap = n / 2; gap > 0; gap /= 2) {
+        for (size_t base = 0; base < n; base += 2 * gap) {
+            for (size_t k = 0; k < gap; k++) {
+                fr_t *lo = &x[base + k], *hi = &x[base + gap + k], neg;
+                fr_sub(&neg, lo, hi);
+                fr_add(lo, lo, hi);
+                fr_mul(hi, &neg, &roots[k]);
+            }
+        }
+        for (size_t i = 1; i < root_len / 2; i++) roots[i] = roots[2 * i];
+        root_len /= 2;
+    }
+    free(roots);
+}
+/* radix2/fft.rs:205-235 -- oi_helper (DIT, gap 1 .. n/2) */
+static void orc_oi_helper(fr_t *x, size_t n, const fr_t *root) {
+    fr_t *roots = orc_roots(n / 2, root);
+    for (size_t gap = 1; gap < n; gap *= 2) {
+        size_t nchunks = n / (2 * gap);
+        for (size_t base = 0; base < n; base += 2 * gap) {
+            for (size_t k = 0; k < gap; k++) {
+                fr_t *lo = &x[base + k], *hi = &x[base + gap + k], neg;
+                fr_mul(hi, hi, &roots[nchunks * k]);
+                fr_sub(&neg, lo, hi);
+                fr_add(lo, lo, hi);
+                *hi = neg;
+            }
+        }
+    }
+    free(roots);
+}
+/* domain/mod.rs:99-106 -- distribute_powers_and_mul_by_const (serial): x[i] *= c * g^i */
+static void orc_distribute_powers(fr_t *x, size_t n, const fr_t *g, const fr_t *c) {
+    fr_t pw = *c;
+    for (size_t i = 0; i < n; i++) { fr_mul(&x[i], &x[i], &pw); fr_mul(&pw, &pw, g); }
+}
+
+enum { ORC_FFT = 0, ORC_IFFT = 1, ORC_COSET_FFT = 2, ORC_COSET_IFFT = 3 };
+
+/* {fft, ifft, coset_fft, coset_ifft}_in_place on a buffer of D = 2^log_d elements whose first in_len
+ * entries are the caller's vector (the tail is overwritten with zero = `resize(size, T::zero())`).
+ * radix2/mod.rs:99-117, domain/mod.rs:139-142, radix2/fft.rs:22-35. */
+int orc_ntt_fr(uint64_t *data, unsigned log_d, int kind, size_t in_len) {
+    orc_domain_t d;
+    size_t n = (size_t)1 << log_d;
+    if (!orc_domain_new(&d, n) || in_len > n) return 1;
+    fr_t *x = (fr_t *)data;
+    fr_t one;
+    fr_one(&one);
+    if (kind == ORC_COSET_FFT) orc_distribute_powers(x, in_len, &d.generator, &one);  /* on the un-resized input */
+    for (size_t i = in_len; i < n; i++) fr_zero(&x[i]);
+    if (kind == ORC_FFT || kind == ORC_COSET_FFT) {
+        orc_io_helper(x, n, &d.group_gen);
+        orc_derange(x, n, log_d);
+    } else {
+        orc_derange(x, n, log_d);
+        orc_oi_helper(x, n, &d.group_gen_inv);
+        if (kind == ORC_IFFT) {
+            for (size_t i = 0; i < n; i++) fr_mul(&x[i], &x[i], &d.size_inv);
+        } else {
+            orc_distribute_powers(x, n, &d.generator_inv, &d.size_inv);
+        }
+    }
+    return 0;
+}
+
+/* Domain constants, for cross-checking the product's host-side domain object. out = 6 x 4 limbs:
+ * size_inv, group_gen, group_gen_inv, generator, generator_inv, vanishing_on_coset_inv (g^D - 1)^-1 */
+int orc_domain_constants(unsigned log_d, uint64_t *out) {
+    orc_domain_t d;
+    if (!orc_domain_new(&d, (size_t)1 << log_d)) return 1;
+    fr_t v, one;
+    uint64_t e[1] = {(uint64_t)1 << log_d};
+    fr_pow(&v, &d.generator, e, 1);        /* evaluate_vanishing_polynomial(g) = g^D - 1 (radix2/mod.rs) */
+    fr_one(&one);
+    fr_sub(&v, &v, &one);
+    fr_inv(&v, &v);
+    memcpy(out + 0, d.size_inv.l, 32);
+    memcpy(out + 4, d.group_gen.l, 32);
+    memcpy(out + 8, d.group_gen_inv.l, 32);
+    memcpy(out + 12, d.generator.l, 32);
+    memcpy(out + 16, d.generator_inv.l, 32);
+    memcpy(out + 20, v.l, 32);
+    return 0;
+}
+
+/* Polynomial evaluation by Horner -- the check used by radix2/mod.rs:320-360 test_fft_correctness */
+void orc_fr_horner(const uint64_t *coeffs, size_t n, const uint64_t *x, uint64_t *out) {
+    fr_t acc, xx;
+    fr_zero(&acc);
+    memcpy(xx.l, x, 32);
+    for (size_t i = n; i-- > 0;) {
+        fr_mul(&acc, &acc, &xx);
+        fr_add(&acc, &acc, (const fr_t *)(coeffs + 4 * i));
+    }
+    memcpy(out, acc.l, 32);
+}
+
+/* ------------------------------------------------------------------ scalar-field element-wise exports */
+#define ORC_BINOP(NAME, T, W, FN)                                                          \
+    void NAME(const uint64_t *a, const uint64_t *b, uint64_t *out, size_t n) {             \
+        for (size_t i = 0; i < n; i++) {                                                   \
+            T r;                                                                           \
+            FN(&r, (const T *)(a + W * i), (const T *)(b + W * i));                        \
+            memcpy(out + W * i, &r, sizeof r);                                             \
+        }                                                                                  \
+    }
+#define ORC_UNOP(NAME, T, W, FN)                                                           \
+    void NAME(const uint64_t *a, uint64_t *out, size_t n) {                                \
+        for (size_t i = 0; i < n; i++) {                                                   \
+            T r;                                                                           \
+            FN(&r, (const T *)(a + W * i));                                                \
+            memcpy(out + W * i, &r, sizeof r);                                             \
+        }                                                                                  \
+    }
+ORC_BINOP(orc_fr_mul, fr_t, 4, fr_mul)
+ORC_BINOP(orc_fr_add, fr_t, 4, fr_add)
+ORC_BINOP(orc_fr_sub, fr_t, 4, fr_sub)
+ORC_UNOP(orc_fr_sqr, fr_t, 4, fr_sqr)
+ORC_UNOP(orc_fr_neg, fr_t, 4, fr_neg)
+ORC_UNOP(orc_fr_dbl, fr_t, 4, fr_dbl)
+ORC_UNOP(orc_fr_inv, fr_t, 4, fr_inv)
+ORC_BINOP(orc_fq_mul, fq_t, 6, fq_mul)
+ORC_BINOP(orc_fq_add, fq_t, 6, fq_add)
+ORC_BINOP(orc_fq_sub, fq_t, 6, fq_sub)
+ORC_UNOP(orc_fq_sqr, fq_t, 6, fq_sqr)
+ORC_UNOP(orc_fq_neg, fq_t, 6, fq_neg)
+ORC_UNOP(orc_fq_dbl, fq_t, 6, fq_dbl)
+ORC_UNOP(orc_fq_inv, fq_t, 6, fq_inv)
+ORC_BINOP(orc_fq2_mul, fq2_t, 12, fq2_mul)
+ORC_BINOP(orc_fq2_add, fq2_t, 12, fq2_add)
+ORC_BINOP(orc_fq2_sub, fq2_t, 12, fq2_sub)
+ORC_UNOP(orc_fq2_sqr, fq2_t, 12, fq2_sqr)
+ORC_UNOP(orc_fq2_inv, fq2_t, 12, fq2_inv)
+
+void orc_fr_into_repr(const uint64_t *a, uint64_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) fr_into_repr(out + 4 * i, (const fr_t *)(a + 4 * i));
+}
+int orc_fr_from_repr(const uint64_t *a, uint64_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) if (!fr_from_repr((fr_t *)(out + 4 * i), a + 4 * i)) return 1;
+    return 0;
+}
+void orc_fq_into_repr(const uint64_t *a, uint64_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) fq_into_repr(out + 6 * i, (const fq_t *)(a + 6 * i));
+}
+int orc_fq_from_repr(const uint64_t *a, uint64_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) if (!fq_from_repr((fq_t *)(out + 6 * i), a + 6 * i)) return 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ group exports
+ * Layouts (shared with include/czk.h): G1 affine = 12 u64 (x, y), G1 Jacobian = 18 u64 (x, y, z);
+ * G2 affine = 24 u64 (x.c0, x.c1, y.c0, y.c1), G2 Jacobian = 36 u64.  Montgomery limbs. */
+void orc_g1_msm(const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars, size_t n, uint64_t *out_jac) {
+    g1_jac_t r;
+    g1_msm_pippenger(&r, (const g1_aff_t *)bases, inf, scalars, n);
+    memcpy(out_jac, &r, sizeof r);
+}
+void orc_g2_msm(const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars, size_t n, uint64_t *out_jac) {
+    g2_jac_t r;
+    g2_msm_pippenger(&r, (const g2_aff_t *)bases, inf, scalars, n);
+    memcpy(out_jac, &r, sizeof r);
+}
+/* AffineCurve::multi_scalar_mul (algebra/ec/src/lib.rs:300-311): Montgomery scalars -> into_repr -> MSM */
+void orc_g1_multi_scalar_mul(const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars_mont, size_t n_bases,
+                             size_t n_scalars, uint64_t *out_jac) {
+    uint64_t *repr = (uint64_t *)malloc((n_scalars ? n_scalars : 1) * 32);
+    orc_fr_into_repr(scalars_mont, repr, n_scalars);
+    orc_g1_msm(bases, inf, repr, n_bases < n_scalars ? n_bases : n_scalars, out_jac);
+    free(repr);
+}
+void orc_g2_multi_scalar_mul(const uint64_t *bases, const uint8_t *inf, const uint64_t *scalars_mont, size_t n_bases,
+                             size_t n_scalars, uint64_t *out_jac) {
+    uint64_t *repr = (uint64_t *)malloc((n_scalars ? n_scalars : 1) * 32);
+    orc_fr_into_repr(scalars_mont, repr, n_scalars);
+    orc_g2_msm(bases, inf, repr, n_bases < n_scalars ? n_bases : n_scalars, out_jac);
+    free(repr);
+}
+int orc_g1_jac_to_affine(const uint64_t *jac, uint64_t *out_aff) {
+    g1_aff_t a;
+    int inf = g1_jac_to_affine(&a, (const g1_jac_t *)jac);
+    memcpy(out_aff, &a, sizeof a);
+    return inf;
+}
+int orc_g2_jac_to_affine(const uint64_t *jac, uint64_t *out_aff) {
+    g2_aff_t a;
+    int inf = g2_jac_to_affine(&a, (const g2_jac_t *)jac);
+    memcpy(out_aff, &a, sizeof a);
+    return inf;
+}
+void orc_g1_scalar_mul(const uint64_t *base_aff, int base_inf, const uint64_t *k_canonical, uint64_t *out_jac) {
+    g1_jac_t r;
+    g1_scalar_mul(&r, (const g1_aff_t *)base_aff, base_inf, k_canonical, 4);
+    memcpy(out_jac, &r, sizeof r);
+}
+void orc_g2_scalar_mul(const uint64_t *base_aff, int base_inf, const uint64_t *k_canonical, uint64_t *out_jac) {
+    g2_jac_t r;
+    g2_scalar_mul(&r, (const g2_aff_t *)base_aff, base_inf, k_canonical, 4);
+    memcpy(out_jac, &r, sizeof r);
+}
+void orc_g1_jac_add(const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    g1_jac_t r;
+    memcpy(&r, a, sizeof r);
+    g1_jac_add(&r, (const g1_jac_t *)b);
+    memcpy(out, &r, sizeof r);
+}
+void orc_g2_jac_add(const uint64_t *a, const uint64_t *b, uint64_t *out) {
+    g2_jac_t r;
+    memcpy(&r, a, sizeof r);
+    g2_jac_add(&r, (const g2_jac_t *)b);
+    memcpy(out, &r, sizeof r);
+}
+void orc_g1_jac_add_mixed(const uint64_t *a, const uint64_t *b_aff, int b_inf, uint64_t *out) {
+    g1_jac_t r;
+    memcpy(&r, a, sizeof r);
+    g1_jac_add_mixed(&r, (const g1_aff_t *)b_aff, b_inf);
+    memcpy(out, &r, sizeof r);
+}
+void orc_g2_jac_add_mixed(const uint64_t *a, const uint64_t *b_aff, int b_inf, uint64_t *out) {
+    g2_jac_t r;
+    memcpy(&r, a, sizeof r);
+    g2_jac_add_mixed(&r, (const g2_aff_t *)b_aff, b_inf);
+    memcpy(out, &r, sizeof r);
+}
+void orc_g1_jac_double(const uint64_t *a, uint64_t *out) {
+    g1_jac_t r;
+    memcpy(&r, a, sizeof r);
+    g1_jac_double(&r);
+    memcpy(out, &r, sizeof r);
+}
+void orc_g2_jac_double(const uint64_t *a, uint64_t *out) {
+    g2_jac_t r;
+    memcpy(&r, a, sizeof r);
+    g2_jac_double(&r);
+    memcpy(out, &r, sizeof r);
+}
+/* y^2 == x^3 + b in Montgomery form (short_weierstrass_jacobian.rs is_on_curve) */
+int orc_g1_on_curve(const uint64_t *aff) {
+    const g1_aff_t *p = (const g1_aff_t *)aff;
+    fq_t l, r, b;
+    fq_sqr(&l, &p->y);
+    fq_sqr(&r, &p->x);
+    fq_mul(&r, &r, &p->x);
+    fq_one(&b);                                   /* COEFF_B = 1 (curves/g1.rs:23) */
+    fq_add(&r, &r, &b);
+    return fq_eq(&l, &r);
+}
+int orc_g2_on_curve(const uint64_t *aff, const uint64_t *coeff_b) {
+    const g2_aff_t *p = (const g2_aff_t *)aff;
+    fq2_t l, r;
+    fq2_sqr(&l, &p->y);
+    fq2_sqr(&r, &p->x);
+    fq2_mul(&r, &r, &p->x);
+    fq2_add(&r, &r, (const fq2_t *)coeff_b);
+    return fq2_eq(&l, &r);
+}
+
+/* ------------------------------------------------------------------ Groth16 per-party local compute
+ * mpc-snarks/src/groth/r1cs_to_qap.rs:47-113 (witness_map) on ONE Fr lane.  `a`, `b`, `c` are D-element
+ * buffers already holding the evaluated constraint rows (a[0..N) = <A_i, z>, a[N..N+n_inst) = z[0..n_inst),
+ * zeros above; :67-83, :95-100).  The share-by-share product `F::batch_product_in_place(ab, b)` (:92) is a
+ * communication step for shares; the caller supplies it through `beaver`:
+ *   beaver == 0 : plain field product (single-prover flavour, proof.rs:75-110)
+ *   beaver == 1 : the local half of Beaver multiplication with the dummy triple source
+ *                 (mpc-algebra/src/share/field.rs:97-127, wire/field.rs:41-60) is NOT done here; callers that
+ *                 model shares call orc_witness_map_pre / _post around their own open step.
+ * Output h = ab (D elements). */
+static void orc_witness_map_pre_lane(fr_t *a, fr_t *b, unsigned log_d) {
+    orc_ntt_fr((uint64_t *)a, log_d, ORC_IFFT, (size_t)1 << log_d);
+    orc_ntt_fr((uint64_t *)b, log_d, ORC_IFFT, (size_t)1 << log_d);
+    orc_ntt_fr((uint64_t *)a, log_d, ORC_COSET_FFT, (size_t)1 << log_d);
+    orc_ntt_fr((uint64_t *)b, log_d, ORC_COSET_FFT, (size_t)1 << log_d);
+}
+static void orc_witness_map_post_lane(fr_t *ab, fr_t *c, unsigned log_d) {
+    size_t n = (size_t)1 << log_d;
+    uint64_t consts[24];
+    orc_domain_constants(log_d, consts);
+    fr_t zinv;
+    memcpy(zinv.l, consts + 20, 32);
+    orc_ntt_fr((uint64_t *)c, log_d, ORC_IFFT, n);
+    orc_ntt_fr((uint64_t *)c, log_d, ORC_COSET_FFT, n);
+    for (size_t i = 0; i < n; i++) fr_sub(&ab[i], &ab[i], &c[i]);                 /* :105-107 */
+    for (size_t i = 0; i < n; i++) fr_mul(&ab[i], &ab[i], &zinv);                 /* :109, domain/mod.rs:184-191 */
+    orc_ntt_fr((uint64_t *)ab, log_d, ORC_COSET_IFFT, n);                          /* :110 */
+}
+void orc_witness_map_pre(uint64_t *a, uint64_t *b, unsigned log_d) { orc_witness_map_pre_lane((fr_t *)a, (fr_t *)b, log_d); }
+void orc_witness_map_post(uint64_t *ab, uint64_t *c, unsigned log_d) { orc_witness_map_post_lane((fr_t *)ab, (fr_t *)c, log_d); }
+/* single-prover witness map: a, b, c in; h written over a */
+void orc_witness_map_plain(uint64_t *a, uint64_t *b, uint64_t *c, unsigned log_d) {
+    size_t n = (size_t)1 << log_d;
+    fr_t *fa = (fr_t *)a, *fb = (fr_t *)b;
+    orc_witness_map_pre_lane(fa, fb, log_d);
+    for (size_t i = 0; i < n; i++) fr_mul(&fa[i], &fa[i], &fb[i]);
+    orc_witness_map_post_lane(fa, (fr_t *)c, log_d);
+}

@@ -1,0 +1,179 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference's short-Weierstrass Jacobian group law and
+ * of its Pippenger VariableBaseMSM.  Included twice by czk_oracle.c:
+ *   G1: BF(x)=fq_##x,  BF_T=fq_t,  EC(x)=g1_##x
+ *   G2: BF(x)=fq2_##x, BF_T=fq2_t, EC(x)=g2_##x
+ * Paths relative to /root/reference.  a = 0 for both BLS12-377 groups (curves/g1.rs:38-40, g2.rs).
+ */
+
+typedef struct { BF_T x, y; } EC(aff_t);      /* the `infinity` flag travels as a separate byte */
+typedef struct { BF_T x, y, z; } EC(jac_t);
+
+/* short_weierstrass_jacobian.rs:444-457 -- zero() = (1, 1, 0); is_zero <=> z == 0 */
+static void EC(jac_zero)(EC(jac_t) *p) { BF(one)(&p->x); BF(one)(&p->y); BF(zero)(&p->z); }
+static int EC(jac_is_zero)(const EC(jac_t) *p) { return BF(is_zero)(&p->z); }
+
+/* short_weierstrass_jacobian.rs:502-535 -- double_in_place, COEFF_A == 0 branch */
+static void EC(jac_double)(EC(jac_t) *p) {
+    if (EC(jac_is_zero)(p)) return;
+    BF_T a, b, c, d, e, f, t;
+    BF(sqr)(&a, &p->x);
+    BF(sqr)(&b, &p->y);
+    BF(sqr)(&c, &b);
+    BF(add)(&t, &p->x, &b);
+    BF(sqr)(&t, &t);
+    BF(sub)(&t, &t, &a);
+    BF(sub)(&t, &t, &c);
+    BF(dbl)(&d, &t);
+    BF(dbl)(&t, &a);          /* a.double_in_place() */
+    BF(add)(&e, &a, &t);      /* e = a(old) + 2a */
+    BF(sqr)(&f, &e);
+    BF(mul)(&p->z, &p->z, &p->y);
+    BF(dbl)(&p->z, &p->z);
+    BF(sub)(&p->x, &f, &d);
+    BF(sub)(&p->x, &p->x, &d);
+    BF(sub)(&t, &d, &p->x);
+    BF(mul)(&t, &t, &e);
+    BF(dbl)(&c, &c); BF(dbl)(&c, &c); BF(dbl)(&c, &c);
+    BF(sub)(&p->y, &t, &c);
+}
+
+/* short_weierstrass_jacobian.rs:570-638 -- add_assign_mixed (madd-2007-bl with explicit edge cases) */
+static void EC(jac_add_mixed)(EC(jac_t) *p, const EC(aff_t) *q, int q_inf) {
+    if (q_inf) return;
+    if (EC(jac_is_zero)(p)) { p->x = q->x; p->y = q->y; BF(one)(&p->z); return; }
+    BF_T z1z1, u2, s2;
+    BF(sqr)(&z1z1, &p->z);
+    BF(mul)(&u2, &q->x, &z1z1);
+    BF(mul)(&s2, &q->y, &p->z);
+    BF(mul)(&s2, &s2, &z1z1);
+    if (BF(eq)(&p->x, &u2) && BF(eq)(&p->y, &s2)) { EC(jac_double)(p); return; }
+    BF_T h, hh, i, j, r, v;
+    BF(sub)(&h, &u2, &p->x);
+    BF(sqr)(&hh, &h);
+    BF(dbl)(&i, &hh); BF(dbl)(&i, &i);
+    BF(mul)(&j, &h, &i);
+    BF(sub)(&r, &s2, &p->y); BF(dbl)(&r, &r);
+    BF(mul)(&v, &p->x, &i);
+    BF(sqr)(&p->x, &r);
+    BF(sub)(&p->x, &p->x, &j);
+    BF(sub)(&p->x, &p->x, &v);
+    BF(sub)(&p->x, &p->x, &v);
+    BF(mul)(&j, &j, &p->y); BF(dbl)(&j, &j);
+    BF(sub)(&p->y, &v, &p->x);
+    BF(mul)(&p->y, &p->y, &r);
+    BF(sub)(&p->y, &p->y, &j);
+    BF(add)(&p->z, &p->z, &h);
+    BF(sqr)(&p->z, &p->z);
+    BF(sub)(&p->z, &p->z, &z1z1);
+    BF(sub)(&p->z, &p->z, &hh);
+}
+
+/* short_weierstrass_jacobian.rs:666-728 -- add_assign (add-2007-bl with explicit edge cases) */
+static void EC(jac_add)(EC(jac_t) *p, const EC(jac_t) *q) {
+    if (EC(jac_is_zero)(p)) { *p = *q; return; }
+    if (EC(jac_is_zero)(q)) return;
+    BF_T z1z1, z2z2, u1, u2, s1, s2;
+    BF(sqr)(&z1z1, &p->z);
+    BF(sqr)(&z2z2, &q->z);
+    BF(mul)(&u1, &p->x, &z2z2);
+    BF(mul)(&u2, &q->x, &z1z1);
+    BF(mul)(&s1, &p->y, &q->z); BF(mul)(&s1, &s1, &z2z2);
+    BF(mul)(&s2, &q->y, &p->z); BF(mul)(&s2, &s2, &z1z1);
+    if (BF(eq)(&u1, &u2) && BF(eq)(&s1, &s2)) { EC(jac_double)(p); return; }
+    BF_T h, i, j, r, v, t;
+    BF(sub)(&h, &u2, &u1);
+    BF(dbl)(&i, &h); BF(sqr)(&i, &i);
+    BF(mul)(&j, &h, &i);
+    BF(sub)(&r, &s2, &s1); BF(dbl)(&r, &r);
+    BF(mul)(&v, &u1, &i);
+    BF(sqr)(&p->x, &r);
+    BF(sub)(&p->x, &p->x, &j);
+    BF(dbl)(&t, &v);
+    BF(sub)(&p->x, &p->x, &t);
+    BF(sub)(&t, &v, &p->x);
+    BF(mul)(&t, &r, &t);
+    BF(mul)(&s1, &s1, &j); BF(dbl)(&s1, &s1);
+    BF(sub)(&p->y, &t, &s1);
+    BF(add)(&t, &p->z, &q->z);
+    BF(sqr)(&t, &t);
+    BF(sub)(&t, &t, &z1z1);
+    BF(sub)(&t, &t, &z2z2);
+    BF(mul)(&p->z, &t, &h);
+}
+
+/* short_weierstrass_jacobian.rs:768-789 -- From<Projective> for Affine; returns the infinity flag */
+static int EC(jac_to_affine)(EC(aff_t) *out, const EC(jac_t) *p) {
+    if (EC(jac_is_zero)(p)) { BF(zero)(&out->x); BF(one)(&out->y); return 1; }   /* (0, 1, true) :149-151 */
+    if (BF(is_one)(&p->z)) { out->x = p->x; out->y = p->y; return 0; }
+    BF_T zi, zi2, zi3;
+    BF(inv)(&zi, &p->z);
+    BF(sqr)(&zi2, &zi);
+    BF(mul)(&out->x, &p->x, &zi2);
+    BF(mul)(&zi3, &zi2, &zi);
+    BF(mul)(&out->y, &p->y, &zi3);
+    return 0;
+}
+
+/* ProjectiveCurve::mul -- plain MSB-first double-and-add over a canonical little-endian scalar */
+static void EC(scalar_mul)(EC(jac_t) *out, const EC(aff_t) *base, int base_inf, const uint64_t *k, int k_limbs) {
+    EC(jac_t) acc;
+    EC(jac_zero)(&acc);
+    for (int i = k_limbs * 64 - 1; i >= 0; i--) {
+        EC(jac_double)(&acc);
+        if ((k[i / 64] >> (i % 64)) & 1) EC(jac_add_mixed)(&acc, base, base_inf);
+    }
+    *out = acc;
+}
+
+/* algebra/ec/src/msm/variable_base.rs:12-106 -- VariableBaseMSM::multi_scalar_mul, serial build.
+ * scalars: n x 4 canonical limbs; bases: n affine points + infinity bytes.  Same window rule, same
+ * unit-scalar shortcut, same bucket running sum, same high-to-low window fold. */
+static void EC(msm_pippenger)(EC(jac_t) *out, const EC(aff_t) *bases, const uint8_t *inf,
+                              const uint64_t *scalars, size_t size) {
+    size_t c = size < 32 ? 3 : (size_t)(orc_log2(size) * 69 / 100) + 2;   /* :21-25, msm/mod.rs:10-13 */
+    const size_t num_bits = 253;                                           /* FrParameters::MODULUS_BITS */
+    const uint64_t fr_one[4] = {1, 0, 0, 0};                               /* one().into_repr() */
+    size_t n_windows = (num_bits + c - 1) / c;
+    size_t n_buckets = ((size_t)1 << c) - 1;
+    EC(jac_t) *window_sums = (EC(jac_t) *)malloc(n_windows * sizeof(EC(jac_t)));
+    EC(jac_t) *buckets = (EC(jac_t) *)malloc(n_buckets * sizeof(EC(jac_t)));
+    for (size_t w = 0; w < n_windows; w++) {
+        size_t w_start = w * c;
+        EC(jac_t) res;
+        EC(jac_zero)(&res);
+        for (size_t b = 0; b < n_buckets; b++) EC(jac_zero)(&buckets[b]);
+        for (size_t i = 0; i < size; i++) {
+            const uint64_t *s = scalars + 4 * i;
+            if ((s[0] | s[1] | s[2] | s[3]) == 0) continue;                /* filter(!s.is_zero()) :19 */
+            if (memcmp(s, fr_one, sizeof fr_one) == 0) {
+                if (w_start == 0) EC(jac_add_mixed)(&res, &bases[i], inf[i]);
+                continue;
+            }
+            /* scalar.divn(w_start); scalar.as_ref()[0] % (1 << c)   (c <= 64 - always true here) */
+            size_t limb = w_start / 64, off = w_start % 64;
+            uint64_t lo = limb < 4 ? s[limb] >> off : 0;
+            if (off && limb + 1 < 4) lo |= s[limb + 1] << (64 - off);
+            uint64_t digit = lo & (((uint64_t)1 << c) - 1);
+            if (digit) EC(jac_add_mixed)(&buckets[digit - 1], &bases[i], inf[i]);
+        }
+        EC(jac_t) running;
+        EC(jac_zero)(&running);
+        for (size_t b = n_buckets; b-- > 0;) {
+            EC(jac_add)(&running, &buckets[b]);
+            EC(jac_add)(&res, &running);
+        }
+        window_sums[w] = res;
+    }
+    EC(jac_t) total;
+    EC(jac_zero)(&total);
+    for (size_t w = n_windows - 1; w >= 1; w--) {
+        EC(jac_add)(&total, &window_sums[w]);
+        for (size_t k = 0; k < c; k++) EC(jac_double)(&total);
+    }
+    /* lowest + fold: `lowest + &...` is add_assign on a copy of lowest with the fold as `other` */
+    EC(jac_t) lowest = window_sums[0];
+    EC(jac_add)(&lowest, &total);
+    *out = lowest;
+    free(buckets);
+    free(window_sums);
+}

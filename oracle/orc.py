@@ -1,0 +1,248 @@
+"""ctypes binding of oracle/libczk_oracle.so (TEST INFRASTRUCTURE ONLY -- the CPU checker).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Arrays are numpy uint64, little-endian limbs, Montgomery form unless a name says `repr`/`canonical`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libczk_oracle.so")
+
+FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("czk_oracle.c", "fp_tmpl.h", "ec_tmpl.h")]
+    stale = force or not os.path.exists(_LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
+    if stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return a
+
+
+# ----------------------------------------------------------------------------- int <-> limbs
+def ints_to_limbs(vals, n_limbs):
+    out = np.zeros((len(vals), n_limbs), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        for j in range(n_limbs):
+            out[i, j] = (v >> (64 * j)) & mask
+    return out
+
+
+def limbs_to_ints(arr):
+    arr = np.asarray(arr, dtype=np.uint64)
+    arr = arr.reshape(-1, arr.shape[-1])
+    return [sum(int(arr[i, j]) << (64 * j) for j in range(arr.shape[1])) for i in range(arr.shape[0])]
+
+
+# ----------------------------------------------------------------------------- field ops
+def _binop(name, width):
+    def f(a, b):
+        a, b = _u64(a), _u64(b)
+        out = np.empty_like(a)
+        getattr(lib(), name)(_p(a), _p(b), _p(out), C.c_size_t(a.size // width))
+        return out
+    return f
+
+
+def _unop(name, width):
+    def f(a):
+        a = _u64(a)
+        out = np.empty_like(a)
+        getattr(lib(), name)(_p(a), _p(out), C.c_size_t(a.size // width))
+        return out
+    return f
+
+
+fr_mul, fr_add, fr_sub = _binop("orc_fr_mul", 4), _binop("orc_fr_add", 4), _binop("orc_fr_sub", 4)
+fr_sqr, fr_neg, fr_dbl, fr_inv = (_unop("orc_fr_sqr", 4), _unop("orc_fr_neg", 4), _unop("orc_fr_dbl", 4),
+                                  _unop("orc_fr_inv", 4))
+fq_mul, fq_add, fq_sub = _binop("orc_fq_mul", 6), _binop("orc_fq_add", 6), _binop("orc_fq_sub", 6)
+fq_sqr, fq_neg, fq_dbl, fq_inv = (_unop("orc_fq_sqr", 6), _unop("orc_fq_neg", 6), _unop("orc_fq_dbl", 6),
+                                  _unop("orc_fq_inv", 6))
+fq2_mul, fq2_add, fq2_sub = _binop("orc_fq2_mul", 12), _binop("orc_fq2_add", 12), _binop("orc_fq2_sub", 12)
+fq2_sqr, fq2_inv = _unop("orc_fq2_sqr", 12), _unop("orc_fq2_inv", 12)
+fr_into_repr = _unop("orc_fr_into_repr", 4)
+fq_into_repr = _unop("orc_fq_into_repr", 6)
+
+
+def fr_from_repr(a):
+    a = _u64(a)
+    out = np.empty_like(a)
+    rc = lib().orc_fr_from_repr(_p(a), _p(out), C.c_size_t(a.size // 4))
+    if rc:
+        raise ValueError("from_repr: value >= modulus")
+    return out
+
+
+def fq_from_repr(a):
+    a = _u64(a)
+    out = np.empty_like(a)
+    rc = lib().orc_fq_from_repr(_p(a), _p(out), C.c_size_t(a.size // 6))
+    if rc:
+        raise ValueError("from_repr: value >= modulus")
+    return out
+
+
+# ----------------------------------------------------------------------------- NTT
+def ntt_fr(data, log_d, kind, in_len=None):
+    """In-order {fft, ifft, coset_fft, coset_ifft} of one Fr lane; returns a new (D, 4) array."""
+    d = 1 << log_d
+    data = _u64(data).reshape(-1, 4)
+    if in_len is None:
+        in_len = data.shape[0]
+    buf = np.zeros((d, 4), dtype=np.uint64)
+    buf[:in_len] = data[:in_len]
+    rc = lib().orc_ntt_fr(_p(buf), C.c_uint(log_d), C.c_int(kind), C.c_size_t(in_len))
+    if rc:
+        raise ValueError("orc_ntt_fr failed")
+    return buf
+
+
+def domain_constants(log_d):
+    out = np.zeros((6, 4), dtype=np.uint64)
+    rc = lib().orc_domain_constants(C.c_uint(log_d), _p(out))
+    if rc:
+        raise ValueError("domain too large")
+    return dict(zip(["size_inv", "group_gen", "group_gen_inv", "generator", "generator_inv", "vanishing_inv"], out))
+
+
+def fr_horner(coeffs, x):
+    coeffs = _u64(coeffs).reshape(-1, 4)
+    x = _u64(x)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().orc_fr_horner(_p(coeffs), C.c_size_t(coeffs.shape[0]), _p(x), _p(out))
+    return out
+
+
+# ----------------------------------------------------------------------------- groups
+def _grp(g):
+    aff_w = 12 if g == 1 else 24
+    jac_w = 18 if g == 1 else 36
+    return aff_w, jac_w
+
+
+def msm(g, bases, inf, scalars_canonical):
+    """VariableBaseMSM::multi_scalar_mul: canonical scalars (n,4); returns Jacobian limbs."""
+    aff_w, jac_w = _grp(g)
+    bases = _u64(bases).reshape(-1, aff_w)
+    scalars = _u64(scalars_canonical).reshape(-1, 4)
+    n = min(bases.shape[0], scalars.shape[0])
+    inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    out = np.zeros(jac_w, dtype=np.uint64)
+    getattr(lib(), f"orc_g{g}_msm")(_p(bases), _p(inf), _p(scalars), C.c_size_t(n), _p(out))
+    return out
+
+
+def multi_scalar_mul(g, bases, inf, scalars_mont):
+    """AffineCurve::multi_scalar_mul: Montgomery scalars; lengths may differ (min is used)."""
+    aff_w, jac_w = _grp(g)
+    bases = _u64(bases).reshape(-1, aff_w)
+    scalars = _u64(scalars_mont).reshape(-1, 4)
+    inf = np.ascontiguousarray(inf, dtype=np.uint8)
+    out = np.zeros(jac_w, dtype=np.uint64)
+    getattr(lib(), f"orc_g{g}_multi_scalar_mul")(_p(bases), _p(inf), _p(scalars), C.c_size_t(bases.shape[0]),
+                                                 C.c_size_t(scalars.shape[0]), _p(out))
+    return out
+
+
+def jac_to_affine(g, jac):
+    aff_w, _ = _grp(g)
+    jac = _u64(jac)
+    out = np.zeros(aff_w, dtype=np.uint64)
+    fn = getattr(lib(), f"orc_g{g}_jac_to_affine")
+    fn.restype = C.c_int
+    is_inf = fn(_p(jac), _p(out))
+    return out, bool(is_inf)
+
+
+def scalar_mul(g, base_aff, base_inf, k_canonical):
+    _, jac_w = _grp(g)
+    out = np.zeros(jac_w, dtype=np.uint64)
+    base_aff, k = _u64(base_aff), _u64(k_canonical)
+    getattr(lib(), f"orc_g{g}_scalar_mul")(_p(base_aff), C.c_int(int(base_inf)), _p(k), _p(out))
+    return out
+
+
+def jac_add(g, a, b):
+    _, jac_w = _grp(g)
+    out = np.zeros(jac_w, dtype=np.uint64)
+    a, b = _u64(a), _u64(b)
+    getattr(lib(), f"orc_g{g}_jac_add")(_p(a), _p(b), _p(out))
+    return out
+
+
+def jac_add_mixed(g, a, b_aff, b_inf=False):
+    _, jac_w = _grp(g)
+    out = np.zeros(jac_w, dtype=np.uint64)
+    a, b_aff = _u64(a), _u64(b_aff)
+    getattr(lib(), f"orc_g{g}_jac_add_mixed")(_p(a), _p(b_aff), C.c_int(int(b_inf)), _p(out))
+    return out
+
+
+def jac_double(g, a):
+    _, jac_w = _grp(g)
+    out = np.zeros(jac_w, dtype=np.uint64)
+    a = _u64(a)
+    getattr(lib(), f"orc_g{g}_jac_double")(_p(a), _p(out))
+    return out
+
+
+def g1_on_curve(aff):
+    aff = _u64(aff)
+    fn = lib().orc_g1_on_curve
+    fn.restype = C.c_int
+    return bool(fn(_p(aff)))
+
+
+def g2_on_curve(aff, coeff_b):
+    aff, coeff_b = _u64(aff), _u64(coeff_b)
+    fn = lib().orc_g2_on_curve
+    fn.restype = C.c_int
+    return bool(fn(_p(aff), _p(coeff_b)))
+
+
+# ----------------------------------------------------------------------------- witness map
+def witness_map_plain(a, b, c, log_d):
+    """Single-prover R1CStoQAP::witness_map on one Fr lane; returns h (D,4)."""
+    a, b, c = (np.array(_u64(x).reshape(-1, 4)) for x in (a, b, c))
+    lib().orc_witness_map_plain(_p(a), _p(b), _p(c), C.c_uint(log_d))
+    return a
+
+
+def witness_map_pre(a, b, log_d):
+    a, b = (np.array(_u64(x).reshape(-1, 4)) for x in (a, b))
+    lib().orc_witness_map_pre(_p(a), _p(b), C.c_uint(log_d))
+    return a, b
+
+
+def witness_map_post(ab, c, log_d):
+    ab, c = (np.array(_u64(x).reshape(-1, 4)) for x in (ab, c))
+    lib().orc_witness_map_post(_p(ab), _p(c), C.c_uint(log_d))
+    return ab
