@@ -1,0 +1,239 @@
+"""ctypes binding of libczk_hip.so (include/czk.h).  Host arrays are numpy uint64; device arrays are raw
+pointers (ints) -- e.g. `tensor.data_ptr()` of a torch int64/uint64 CUDA tensor."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libczk_hip.so")
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "czk.h")
+
+CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT = 0, 1, 2, 3
+CZK_MEM_HOST, CZK_MEM_DEVICE = 0, 1
+CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY = 0, 1
+CZK_G1, CZK_G2 = 1, 2
+CZK_OP_ADD, CZK_OP_SUB, CZK_OP_MUL = 0, 1, 2
+_STATUS = {1: "CZK_ERR_SIZE", 2: "CZK_ERR_HIP", 3: "CZK_ERR_ARG", 4: "CZK_ERR_NOMEM"}
+
+
+class CzkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{_STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    """Loads libczk_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise FileNotFoundError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(there is no CPU fallback for the product path)")
+        _lib = C.CDLL(_LIB)
+        _lib.czk_last_error.restype = C.c_char_p
+        _lib.czk_version.restype = C.c_char_p
+        _lib.czk_bases_len.restype = C.c_size_t
+    return _lib
+
+
+def header_symbols() -> list[str]:
+    """Every function include/czk.h declares."""
+    txt = open(_HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(czk_[a-z0-9_]+)\s*\(", txt)))
+
+
+def exported_symbols() -> list[str]:
+    l = lib()
+    return [s for s in header_symbols() if hasattr(l, s)]
+
+
+def _ptr(x):
+    """numpy array -> void*, int -> void*, None -> NULL"""
+    if x is None:
+        return C.c_void_p(0)
+    if isinstance(x, np.ndarray):
+        assert x.flags["C_CONTIGUOUS"]
+        return x.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(x))
+
+
+class Context:
+    """czk_ctx: one GPU + one HIP stream = one MPC party."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p(0)
+        rc = lib().czk_ctx_create(C.byref(self._h), C.c_int(device), C.c_void_p(stream or 0))
+        if rc:
+            raise CzkError(rc, "czk_ctx_create failed (no visible GPU?)")
+
+    def close(self):
+        if self._h:
+            lib().czk_ctx_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise CzkError(rc, (lib().czk_last_error(self._h) or b"").decode())
+
+    def sync(self):
+        self._ck(lib().czk_ctx_sync(self._h))
+
+    # ---- NTT ------------------------------------------------------------------------------------
+    def ntt_fr(self, data, log_d: int, kind: int, lanes: int = 1, in_len: int | None = None, mem: int = CZK_MEM_HOST):
+        """EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place on `lanes` Fr lanes (in place)."""
+        d = 1 << log_d
+        if in_len is None:
+            in_len = d
+        if isinstance(data, np.ndarray):
+            assert data.dtype == np.uint64 and data.size == lanes * d * 4, "buffer must hold lanes x D x 4 u64"
+        self._ck(lib().czk_ntt_fr(self._h, _ptr(data), C.c_uint(log_d), C.c_size_t(lanes), C.c_int(kind), C.c_size_t(in_len),
+                                  C.c_int(mem)))
+        return data
+
+    def domain_constants(self, log_d: int):
+        out = np.zeros((6, 4), dtype=np.uint64)
+        self._ck(lib().czk_domain_constants(self._h, C.c_uint(log_d), _ptr(out)))
+        names = ["size_inv", "group_gen", "group_gen_inv", "generator", "generator_inv", "vanishing_inv"]
+        return dict(zip(names, out))
+
+    # ---- pointwise ------------------------------------------------------------------------------
+    def fr_vec_op(self, op, a, b, out=None, n=None, mem=CZK_MEM_HOST):
+        if mem == CZK_MEM_HOST:
+            a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
+            n = a.size // 4
+            out = np.empty_like(a) if out is None else out
+        self._ck(lib().czk_fr_vec_op(self._h, C.c_int(op), _ptr(a), _ptr(b), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        return out
+
+    def fr_vec_scale(self, a, k, out=None, n=None, mem=CZK_MEM_HOST):
+        if mem == CZK_MEM_HOST:
+            a, k = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(k, np.uint64)
+            n = a.size // 4
+            out = np.empty_like(a) if out is None else out
+        self._ck(lib().czk_fr_vec_scale(self._h, _ptr(a), _ptr(k), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        return out
+
+    def fr_beaver_combine(self, x, y, z, sx, oy, add_open, out=None, n=None, mem=CZK_MEM_HOST):
+        if mem == CZK_MEM_HOST:
+            x, y, z, sx, oy = (np.ascontiguousarray(v, np.uint64) for v in (x, y, z, sx, oy))
+            n = x.size // 4
+            out = np.empty_like(x) if out is None else out
+        self._ck(lib().czk_fr_beaver_combine(self._h, _ptr(x), _ptr(y), _ptr(z), _ptr(sx), _ptr(oy), C.c_int(int(add_open)),
+                                             _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        return out
+
+    def fr_into_repr(self, a, out=None, n=None, mem=CZK_MEM_HOST):
+        if mem == CZK_MEM_HOST:
+            a = np.ascontiguousarray(a, np.uint64)
+            n = a.size // 4
+            out = np.empty_like(a) if out is None else out
+        self._ck(lib().czk_fr_into_repr(self._h, _ptr(a), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        return out
+
+    def fr_from_repr(self, a, out=None, n=None, mem=CZK_MEM_HOST):
+        if mem == CZK_MEM_HOST:
+            a = np.ascontiguousarray(a, np.uint64)
+            n = a.size // 4
+            out = np.empty_like(a) if out is None else out
+        self._ck(lib().czk_fr_from_repr(self._h, _ptr(a), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        return out
+
+    # ---- MSM ------------------------------------------------------------------------------------
+    def register_bases(self, group: int, bases, inf=None, n: int | None = None, mem: int = CZK_MEM_HOST) -> "Bases":
+        aw = 12 if group == CZK_G1 else 24
+        if mem == CZK_MEM_HOST:
+            bases = np.ascontiguousarray(bases, np.uint64)
+            n = bases.size // aw
+            if inf is not None:
+                inf = np.ascontiguousarray(inf, np.uint8)
+        h = C.c_void_p(0)
+        self._ck(lib().czk_bases_register(self._h, C.c_int(group), _ptr(bases), _ptr(inf), C.c_size_t(n), C.c_int(mem), C.byref(h)))
+        return Bases(self, h, group, n)
+
+    def msm(self, bases: "Bases", scalars, n_scalars: int | None = None, lanes: int = 1, scalar_form: int = CZK_SCALAR_CANONICAL,
+            mem: int = CZK_MEM_HOST):
+        """VariableBaseMSM::multi_scalar_mul over `lanes` scalar vectors; returns (lanes, 18|36) Jacobian limbs."""
+        jw = 18 if bases.group == CZK_G1 else 36
+        if mem == CZK_MEM_HOST:
+            scalars = np.ascontiguousarray(scalars, np.uint64)
+            if n_scalars is None:
+                n_scalars = scalars.size // (4 * lanes)
+        out = np.zeros((lanes, jw), dtype=np.uint64)
+        self._ck(lib().czk_msm(self._h, bases._h, _ptr(scalars), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
+                               C.c_int(mem), _ptr(out)))
+        return out
+
+    def msm_oneshot(self, group, bases, inf, scalars, lanes=1, scalar_form=CZK_SCALAR_CANONICAL):
+        aw, jw = (12, 18) if group == CZK_G1 else (24, 36)
+        bases = np.ascontiguousarray(bases, np.uint64)
+        scalars = np.ascontiguousarray(scalars, np.uint64)
+        n = bases.size // aw
+        inf = None if inf is None else np.ascontiguousarray(inf, np.uint8)
+        out = np.zeros((lanes, jw), dtype=np.uint64)
+        fn = lib().czk_msm_g1 if group == CZK_G1 else lib().czk_msm_g2
+        self._ck(fn(self._h, _ptr(bases), _ptr(inf), _ptr(scalars), C.c_size_t(n), C.c_size_t(lanes), C.c_int(scalar_form), _ptr(out)))
+        return out
+
+    def jac_to_affine(self, group, jac):
+        aw, jw = (12, 18) if group == CZK_G1 else (24, 36)
+        jac = np.ascontiguousarray(jac, np.uint64).reshape(-1, jw)
+        n = jac.shape[0]
+        aff = np.zeros((n, aw), dtype=np.uint64)
+        inf = np.zeros(n, dtype=np.uint8)
+        self._ck(lib().czk_jac_to_affine(self._h, C.c_int(group), _ptr(jac), C.c_size_t(n), _ptr(aff), _ptr(inf)))
+        return aff, inf
+
+    def fixed_base_points(self, group, k, out=None, n=None, mem=CZK_MEM_HOST):
+        aw = 12 if group == CZK_G1 else 24
+        if mem == CZK_MEM_HOST:
+            k = np.ascontiguousarray(k, np.uint64)
+            n = k.size // 4
+            out = np.zeros((n, aw), dtype=np.uint64)
+        self._ck(lib().czk_fixed_base_points(self._h, C.c_int(group), _ptr(k), C.c_size_t(n), _ptr(out), C.c_int(mem)))
+        return out
+
+    # ---- Groth16 witness map (device buffers) ------------------------------------------------------
+    def witness_map_pre(self, a_ptr, b_ptr, log_d, lanes):
+        self._ck(lib().czk_witness_map_pre(self._h, _ptr(a_ptr), _ptr(b_ptr), C.c_uint(log_d), C.c_size_t(lanes)))
+
+    def witness_map_post(self, ab_ptr, c_ptr, log_d, lanes):
+        self._ck(lib().czk_witness_map_post(self._h, _ptr(ab_ptr), _ptr(c_ptr), C.c_uint(log_d), C.c_size_t(lanes)))
+
+
+class Bases:
+    """czk_bases: a public base array pinned (with its window multiples) in HBM."""
+
+    def __init__(self, ctx: Context, handle, group: int, n: int):
+        self.ctx, self._h, self.group, self.n = ctx, handle, group, n
+
+    def __len__(self):
+        return int(lib().czk_bases_len(self._h))
+
+    def release(self):
+        if self._h:
+            lib().czk_bases_release(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass

@@ -1,0 +1,129 @@
+// core.hip -- context lifecycle, error reporting, workspace management and the O(1) host-side group
+// helpers of libczk_hip.so.
+#include "czk_internal.h"
+
+namespace czk {
+
+int set_err(czk_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes) {
+    if (b.bytes >= bytes) return CZK_OK;
+    if (b.p) {
+        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CZK_HIP(ctx, hipFree(b.p));
+        b.p = nullptr;
+        b.bytes = 0;
+    }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return set_err(ctx, CZK_ERR_NOMEM, std::string("hipMalloc workspace: ") + hipGetErrorString(e));
+    }
+    b.bytes = bytes;
+    return CZK_OK;
+}
+
+template <class F>
+static void limbs_to_field(const u64* p, F& out);
+template <>
+void limbs_to_field<Fq>(const u64* p, Fq& out) {
+    for (int i = 0; i < 6; i++) {
+        out.l[2 * i] = (u32)p[i];
+        out.l[2 * i + 1] = (u32)(p[i] >> 32);
+    }
+}
+template <>
+void limbs_to_field<Fq2>(const u64* p, Fq2& out) {
+    limbs_to_field<Fq>(p, out.c0);
+    limbs_to_field<Fq>(p + 6, out.c1);
+}
+static void field_to_limbs(const Fq& a, u64* p) {
+    for (int i = 0; i < 6; i++) p[i] = (u64)a.l[2 * i] | ((u64)a.l[2 * i + 1] << 32);
+}
+static void field_to_limbs(const Fq2& a, u64* p) {
+    field_to_limbs(a.c0, p);
+    field_to_limbs(a.c1, p + 6);
+}
+
+template <class F>
+static void host_jac_to_affine(const u64* jac, size_t n, u64* out_aff, uint8_t* out_inf) {
+    constexpr int W = FieldIO<F>::W64;
+    for (size_t i = 0; i < n; i++) {
+        Jac<F> p;
+        limbs_to_field<F>(jac + 3 * W * i, p.x);
+        limbs_to_field<F>(jac + 3 * W * i + W, p.y);
+        limbs_to_field<F>(jac + 3 * W * i + 2 * W, p.z);
+        Affine<F> a;
+        bool inf = jac_to_affine(p, a);
+        field_to_limbs(a.x, out_aff + 2 * W * i);
+        field_to_limbs(a.y, out_aff + 2 * W * i + W);
+        if (out_inf) out_inf[i] = inf ? 1 : 0;
+    }
+}
+
+}  // namespace czk
+
+using namespace czk;
+
+extern "C" const char* czk_version(void) { return "czk-mi355x 0.1 (gfx950)"; }
+
+extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
+    if (!out) return CZK_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return CZK_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return CZK_ERR_HIP;
+    czk_ctx* c = new czk_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return CZK_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    *out = c;
+    return CZK_OK;
+}
+
+extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->domains) {
+        DomainTables& d = kv.second;
+        if (d.tw_fwd) (void)hipFree(d.tw_fwd);
+        if (d.tw_inv) (void)hipFree(d.tw_inv);
+        if (d.coset_fwd) (void)hipFree(d.coset_fwd);
+        if (d.coset_inv) (void)hipFree(d.coset_inv);
+    }
+    if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
+    if (ctx->stage.p) (void)hipFree(ctx->stage.p);
+    if (ctx->msm_ws.p) (void)hipFree(ctx->msm_ws.p);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int czk_ctx_sync(czk_ctx* ctx) {
+    if (!ctx) return CZK_ERR_ARG;
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CZK_OK;
+}
+
+extern "C" const char* czk_last_error(const czk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int czk_jac_to_affine(czk_ctx* ctx, int group, const uint64_t* jac, size_t n, uint64_t* out_aff, uint8_t* out_inf) {
+    if (!ctx) return CZK_ERR_ARG;
+    if (n && (!jac || !out_aff)) return set_err(ctx, CZK_ERR_ARG, "null jac_to_affine argument");
+    if (group == CZK_G1) host_jac_to_affine<Fq>(jac, n, out_aff, out_inf);
+    else if (group == CZK_G2) host_jac_to_affine<Fq2>(jac, n, out_aff, out_inf);
+    else return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    return CZK_OK;
+}

@@ -1,0 +1,142 @@
+// curve.h -- short-Weierstrass Jacobian group law for BLS12-377 G1 (over Fq) and G2 (over Fq2), a = 0.
+//
+// Same formulas and the same explicit edge cases as the reference
+// (algebra/ec/src/models/short_weierstrass_jacobian.rs): doubling :502-535 (a == 0 branch), mixed
+// addition :570-638 (madd-2007-bl), full addition :666-728 (add-2007-bl), infinity = (1, 1, 0) :444-457.
+// Group elements are compared in affine form only (Jacobian triples are not canonical), so the MSM is
+// free to order its additions differently from the reference's serial loop.
+#pragma once
+#include "field.h"
+
+namespace czk {
+
+template <class F>
+struct Affine {
+    F x, y;
+};
+
+template <class F>
+struct Jac {
+    F x, y, z;
+    static CZK_HD Jac zero() { return Jac{F::one(), F::one(), F::zero()}; }
+    CZK_HD bool is_zero() const { return z.is_zero(); }
+};
+
+template <class F>
+CZK_HD Jac<F> jac_double(const Jac<F>& p) {
+    if (p.is_zero()) return p;
+    F a = f_sqr(p.x);
+    F b = f_sqr(p.y);
+    F c = f_sqr(b);
+    F d = f_dbl(f_sub(f_sub(f_sqr(f_add(p.x, b)), a), c));
+    F e = f_add(a, f_dbl(a));
+    F f = f_sqr(e);
+    Jac<F> r;
+    r.z = f_dbl(f_mul(p.z, p.y));
+    r.x = f_sub(f_sub(f, d), d);
+    F c8 = f_dbl(f_dbl(f_dbl(c)));
+    r.y = f_sub(f_mul(f_sub(d, r.x), e), c8);
+    return r;
+}
+
+// The equal-points branch of the additions is essentially never taken in an MSM (it needs two equal bases in
+// one bucket); keep it out of line so the hot loop's code and register footprint stay small.
+template <class F>
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline))
+#else
+inline
+#endif
+Jac<F> jac_double_rare(const Jac<F>& p) {
+    return jac_double(p);
+}
+
+// p + q, q affine (q_inf = q is the point at infinity)
+template <class F>
+CZK_HD Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q, bool q_inf) {
+    if (q_inf) return p;
+    if (p.is_zero()) return Jac<F>{q.x, q.y, F::one()};
+    F z1z1 = f_sqr(p.z);
+    F u2 = f_mul(q.x, z1z1);
+    F s2 = f_mul(f_mul(q.y, p.z), z1z1);
+    if (p.x == u2 && p.y == s2) return jac_double_rare(p);
+    F h = f_sub(u2, p.x);
+    F hh = f_sqr(h);
+    F i = f_dbl(f_dbl(hh));
+    F j = f_mul(h, i);
+    F r = f_dbl(f_sub(s2, p.y));
+    F v = f_mul(p.x, i);
+    Jac<F> o;
+    o.x = f_sub(f_sub(f_sub(f_sqr(r), j), v), v);
+    F yj = f_dbl(f_mul(j, p.y));
+    o.y = f_sub(f_mul(f_sub(v, o.x), r), yj);
+    o.z = f_sub(f_sub(f_sqr(f_add(p.z, h)), z1z1), hh);
+    return o;
+}
+
+template <class F>
+CZK_HD Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
+    if (p.is_zero()) return q;
+    if (q.is_zero()) return p;
+    F z1z1 = f_sqr(p.z);
+    F z2z2 = f_sqr(q.z);
+    F u1 = f_mul(p.x, z2z2);
+    F u2 = f_mul(q.x, z1z1);
+    F s1 = f_mul(f_mul(p.y, q.z), z2z2);
+    F s2 = f_mul(f_mul(q.y, p.z), z1z1);
+    if (u1 == u2 && s1 == s2) return jac_double_rare(p);
+    F h = f_sub(u2, u1);
+    F i = f_sqr(f_dbl(h));
+    F j = f_mul(h, i);
+    F r = f_dbl(f_sub(s2, s1));
+    F v = f_mul(u1, i);
+    Jac<F> o;
+    o.x = f_sub(f_sub(f_sqr(r), j), f_dbl(v));
+    o.y = f_sub(f_mul(r, f_sub(v, o.x)), f_dbl(f_mul(s1, j)));
+    o.z = f_mul(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2), h);
+    return o;
+}
+
+// From<Projective> for Affine (short_weierstrass_jacobian.rs:768-789); returns the infinity flag.
+template <class F>
+CZK_HD bool jac_to_affine(const Jac<F>& p, Affine<F>& out) {
+    if (p.is_zero()) {
+        out.x = F::zero();
+        out.y = F::one();
+        return true;
+    }
+    F zi = f_inv(p.z);
+    F zi2 = f_sqr(zi);
+    out.x = f_mul(p.x, zi2);
+    out.y = f_mul(p.y, f_mul(zi2, zi));
+    return false;
+}
+
+template <class F>
+CZK_HD Affine<F> aff_load(const u64* p) {
+    return Affine<F>{FieldIO<F>::load(p), FieldIO<F>::load(p + FieldIO<F>::W64)};
+}
+template <class F>
+CZK_HD void aff_store(u64* p, const Affine<F>& a) {
+    FieldIO<F>::store(p, a.x);
+    FieldIO<F>::store(p + FieldIO<F>::W64, a.y);
+}
+template <class F>
+CZK_HD Jac<F> jac_load(const u64* p) {
+    constexpr int W = FieldIO<F>::W64;
+    return Jac<F>{FieldIO<F>::load(p), FieldIO<F>::load(p + W), FieldIO<F>::load(p + 2 * W)};
+}
+template <class F>
+CZK_HD void jac_store(u64* p, const Jac<F>& a) {
+    constexpr int W = FieldIO<F>::W64;
+    FieldIO<F>::store(p, a.x);
+    FieldIO<F>::store(p + W, a.y);
+    FieldIO<F>::store(p + 2 * W, a.z);
+}
+
+typedef Affine<Fq> G1Affine;
+typedef Jac<Fq> G1Jac;
+typedef Affine<Fq2> G2Affine;
+typedef Jac<Fq2> G2Jac;
+
+}  // namespace czk

@@ -1,0 +1,95 @@
+// czk_internal.h -- context object and helpers shared by the .hip translation units of libczk_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/czk.h"
+#include "curve.h"
+
+namespace czk {
+
+// Per-domain device tables for the radix-2 NTT of size D = 2^log_d (see ntt.hip).
+struct DomainTables {
+    unsigned log_d = 0;
+    u64* tw_fwd = nullptr;     // D-1 entries: stage s (bit s) occupies [2^s - 1, 2^(s+1) - 1): w_s^j, w_s = w^(2^(n-1-s))
+    u64* tw_inv = nullptr;     // same for w^-1
+    u64* coset_fwd = nullptr;  // D entries: g^i, g = 22
+    u64* coset_inv = nullptr;  // D entries: size_inv * g^-i
+    Fr size_inv, group_gen, group_gen_inv, generator, generator_inv, vanishing_inv;
+};
+
+template <class F>
+struct GT;
+template <>
+struct GT<Fq> {
+    static constexpr int AW = 12, JW = 18, FW = 6;   // u64 words: affine, Jacobian, field element
+};
+template <>
+struct GT<Fq2> {
+    static constexpr int AW = 24, JW = 36, FW = 12;
+};
+
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+}  // namespace czk
+
+struct czk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::map<unsigned, czk::DomainTables> domains;
+    czk::DeviceBuf ntt_scratch;   // one lane-batch for the out-of-place NTT passes
+    czk::DeviceBuf stage;         // staging for CZK_MEM_HOST arguments
+    czk::DeviceBuf msm_ws;        // MSM workspace
+    int num_cu = 256;
+};
+
+struct czk_bases {
+    czk_ctx* ctx = nullptr;
+    int group = 1;
+    size_t n = 0;
+    unsigned c = 0;            // signed-digit window width chosen at registration
+    unsigned W = 0;            // number of windows = ceil(254 / c)
+    uint64_t* pts = nullptr;   // device, W x n x (12|24) u64: window w holds 2^(c*w) * P_i, affine Montgomery
+    uint8_t* inf = nullptr;    // device, W x n infinity flags (never null)
+};
+
+namespace czk {
+
+int set_err(czk_ctx* ctx, int code, const std::string& msg);
+int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes);
+int get_domain(czk_ctx* ctx, unsigned log_d, DomainTables** out);
+
+#define CZK_HIP(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e__ = (call);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return czk::set_err((ctx), CZK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+#define CZK_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != CZK_OK) return rc__; \
+    } while (0)
+
+// implemented in ntt.hip
+int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len);
+// implemented in msm.hip
+int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
+               int scalar_form, u64* out_jac_host);
+int fixed_base_points_device(czk_ctx* ctx, int group, const u64* k_dev, size_t n, u64* out_dev);
+// implemented in msm_acc_g1.hip / msm_acc_g2.hip (hot kernels, built with the multiply inlined)
+void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+                          size_t sorted_stride, u64* buckets, unsigned lanes);
+void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+                          size_t sorted_stride, u64* buckets, unsigned lanes);
+
+}  // namespace czk

@@ -1,0 +1,525 @@
+// msm.hip -- variable-base multi-scalar multiplication over BLS12-377 G1 / G2 for gfx950.
+//
+// Replaces VariableBaseMSM::multi_scalar_mul (algebra/ec/src/msm/variable_base.rs:12-106) and
+// AffineCurve::multi_scalar_mul (algebra/ec/src/lib.rs:300-311) as reached from the MPC wrappers
+// (mpc-algebra/src/wire/pairing.rs:746-809, share/spdz.rs:440-446).  The result is the same group element
+// sum_i s_i * P_i; Jacobian representatives differ from the reference's (they are not canonical), so parity is
+// checked in affine form, as the reference's own MSM test does (algebra/test-templates/src/msm.rs:16-33).
+//
+// MI355X-first design -- NOT the reference's serial "for each window: fill 2^c-1 buckets, running-sum them,
+// then Horner over windows with c doublings":
+//   * HBM capacity is traded for arithmetic.  The bases are public and reused across proofs
+//     (groth16/src/data_structures.rs:132-149), so registration stores 2^(c*w) * P_i for every window w
+//     (W x the table; ~9 GB for a 2^20-constraint Groth16 key, out of 288 GB).  Every (scalar, window)
+//     digit then lands in ONE shared bucket set: a single bucket reduction per MSM and no window-combine
+//     doubling chain (256 dependent doublings in the reference) at all.
+//   * signed digits: 2^(c-1) buckets of weight 1..2^(c-1); a negative digit adds -P (y -> p - y).
+//   * digits are counting-sorted by bucket (histogram -> scan -> scatter), then one thread owns one bucket
+//     and folds its points with the mixed addition (madd-2007-bl, same formulas / edge cases as
+//     short_weierstrass_jacobian.rs:570-638) -- no atomics or locks on group elements.
+//   * bucket reduction sum_b (b+1) * B_b: multi-level chunked running sums (the reference's :82-86 running
+//     sum, applied per chunk, with the chunk offsets folded in at the next level).
+//   * `lanes` scalar vectors that share the bases (SPDZ sh / mac lanes) ride on gridDim.y.
+// All arithmetic is 32-bit-limb integer VALU (field.h); nothing here is MFMA-shaped.
+#include "czk_internal.h"
+
+namespace czk {
+
+// curves/bls12_377/src/curves/g1.rs:46-51, g2.rs:64-86 generators, Montgomery form, 32-bit limbs
+__device__ __forceinline__ Affine<Fq> generator(Fq*) {
+    const u32 gx[12] = {0x772451f4u, 0x260f33b9u, 0x169d5658u, 0xc54dd773u, 0x69a510ddu, 0x5c1551c4u,
+                        0x425e1698u, 0x761662e4u, 0x6f065272u, 0xc97d78ccu, 0xb361fd4du, 0x00a41206u};
+    const u32 gy[12] = {0xb8cb81f3u, 0x8193961fu, 0x5f44adb8u, 0x00638d4cu, 0xd4daf54au, 0xfafaf3dau,
+                        0xd655cd18u, 0xc27849e2u, 0x01d52814u, 0x2ec3ddb4u, 0x26303c71u, 0x007da933u};
+    Affine<Fq> g;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        g.x.l[i] = gx[i];
+        g.y.l[i] = gy[i];
+    }
+    return g;
+}
+__device__ __forceinline__ Affine<Fq2> generator(Fq2*) {
+    const u32 x0[12] = {0xf268725bu, 0x68904082u, 0x4f45328bu, 0x668f2ea7u, 0x802be84fu, 0xebca7a65u,
+                        0xc1ada3e6u, 0x1e1850f4u, 0x588ef1e9u, 0x830dc22du, 0x767c0982u, 0x01862a81u};
+    const u32 x1[12] = {0xc91c7f39u, 0x5f02a915u, 0x388da2a7u, 0xf8c553bau, 0xbd198850u, 0xd51a416du,
+                        0x8ae3073au, 0xe943c6f3u, 0x259a4981u, 0xffe24aa8u, 0x1e73dfddu, 0x01185339u};
+    const u32 y0[12] = {0x7881430fu, 0xd5b19b89u, 0xa5b371edu, 0x05be9118u, 0x86c131eeu, 0x6063f91fu,
+                        0xe8f4ec19u, 0x3244a61bu, 0x9f9a3a12u, 0xa02e425bu, 0x4f3360d2u, 0x018af8c0u};
+    const u32 y1[12] = {0x1a5b96f5u, 0x57601ac7u, 0x14f2440eu, 0xe99acc17u, 0x10118ea9u, 0x2339612fu,
+                        0x3b1cd722u, 0x8321e68au, 0x0cc74917u, 0x2b543b05u, 0xb396c112u, 0x00590182u};
+    Affine<Fq2> g;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        g.x.c0.l[i] = x0[i];
+        g.x.c1.l[i] = x1[i];
+        g.y.c0.l[i] = y0[i];
+        g.y.c1.l[i] = y1[i];
+    }
+    return g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// setup kernels: fixed-base points, window multiples, batched Jacobian -> affine
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(128) void k_fixed_base(const u64* k, size_t n, u64* out_jac) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Affine<F> g = generator((F*)nullptr);
+    Jac<F> acc = Jac<F>::zero();
+    for (int limb = 3; limb >= 0; limb--) {
+        u64 w = k[4 * i + limb];
+        for (int b = 63; b >= 0; b--) {
+            acc = jac_double(acc);
+            if ((w >> b) & 1) acc = jac_add_mixed(acc, g, false);
+        }
+    }
+    jac_store<F>(out_jac + (size_t)GT<F>::JW * i, acc);
+}
+
+// out = 2^c * in   (in affine + infinity flag, out Jacobian)
+template <class F>
+__global__ __launch_bounds__(128) void k_dbl_c(const u64* aff, const uint8_t* inf, size_t n, unsigned c, u64* out_jac) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Jac<F> p;
+    if (inf[i]) {
+        p = Jac<F>::zero();
+    } else {
+        Affine<F> a = aff_load<F>(aff + (size_t)GT<F>::AW * i);
+        p = Jac<F>{a.x, a.y, F::one()};
+        for (unsigned k = 0; k < c; k++) p = jac_double(p);
+    }
+    jac_store<F>(out_jac + (size_t)GT<F>::JW * i, p);
+}
+
+// Montgomery's trick over CH consecutive points per thread (one field inversion per CH points).
+// scratch: n field elements.
+template <class F>
+__global__ __launch_bounds__(128) void k_batch_to_affine(const u64* jac, size_t n, unsigned CH, u64* scratch, u64* out_aff,
+                                                        uint8_t* out_inf) {
+    constexpr int JW = GT<F>::JW, AW = GT<F>::AW, FW = GT<F>::FW;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t start = t * CH;
+    if (start >= n) return;
+    size_t end = start + CH < n ? start + CH : n;
+    F acc = F::one();
+    for (size_t i = start; i < end; i++) {
+        F z = FieldIO<F>::load(jac + JW * i + 2 * FW);
+        FieldIO<F>::store(scratch + FW * i, acc);
+        if (!z.is_zero()) acc = f_mul(acc, z);
+    }
+    F inv = f_inv(acc);
+    for (size_t i = end; i-- > start;) {
+        F z = FieldIO<F>::load(jac + JW * i + 2 * FW);
+        Affine<F> a;
+        if (z.is_zero()) {
+            a.x = F::zero();
+            a.y = F::one();
+            out_inf[i] = 1;
+        } else {
+            F zinv = f_mul(inv, FieldIO<F>::load(scratch + FW * i));
+            inv = f_mul(inv, z);
+            F zi2 = f_sqr(zinv);
+            a.x = f_mul(FieldIO<F>::load(jac + JW * i), zi2);
+            a.y = f_mul(FieldIO<F>::load(jac + JW * i + FW), f_mul(zi2, zinv));
+            out_inf[i] = 0;
+        }
+        aff_store<F>(out_aff + (size_t)AW * i, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// digit extraction + counting sort
+// ------------------------------------------------------------------------------------------------
+// digits[(lane*W + w)*size + i] = 0 (skip) or |d| | sign<<31, d in [-2^(c-1), 2^(c-1)].
+__global__ void k_digits(const u64* scalars, size_t n_scalars, size_t size, int montgomery, unsigned c, unsigned W,
+                         const uint8_t* inf, size_t n_bases, u32* digits, u32* counts, size_t B) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    const unsigned lane = blockIdx.y;
+    Fr s = fp_load<FrParams>(scalars + 4 * ((size_t)lane * n_scalars + i));
+    if (montgomery) s = fp_into_repr(s);   // ec/src/lib.rs:305-307
+    u32 carry = 0;
+    const u32 half = 1u << (c - 1);
+    for (unsigned w = 0; w < W; w++) {
+        unsigned bit = w * c;
+        u32 v = 0;
+        if (bit < 256) {
+            unsigned limb = bit >> 5, off = bit & 31;
+            u64 two = (u64)s.l[limb] | ((limb + 1 < 8) ? ((u64)s.l[limb + 1] << 32) : 0);
+            v = (u32)(two >> off) & ((1u << c) - 1u);
+        }
+        v += carry;
+        u32 code;
+        if (v > half) {
+            code = ((1u << c) - v) | 0x80000000u;
+            carry = 1;
+        } else {
+            code = v;
+            carry = 0;
+        }
+        if (inf[(size_t)w * n_bases + i]) code = 0;   // add_assign_mixed skips infinity (short_weierstrass_jacobian.rs:571-573)
+        if ((code & 0x7fffffffu) == 0) code = 0;
+        digits[((size_t)lane * W + w) * size + i] = code;
+        if (code) atomicAdd(&counts[(size_t)lane * B + (code & 0x7fffffffu) - 1], 1u);
+    }
+}
+
+// exclusive scan of counts[lane][0..B) -> offsets; zeroes counts (reused as scatter cursors). One block per lane.
+__global__ __launch_bounds__(1024) void k_offsets(u32* counts, u32* offsets, size_t B) {
+    __shared__ u32 part[1024];
+    const unsigned tid = threadIdx.x;
+    u32* cnt = counts + (size_t)blockIdx.x * B;
+    u32* off = offsets + (size_t)blockIdx.x * B;
+    size_t per = (B + 1023) / 1024;
+    size_t start = tid * per, end = start + per < B ? start + per : B;
+    u32 sum = 0;
+    for (size_t i = start; i < end; i++) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        u32 v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (size_t i = start; i < end; i++) {
+        u32 cval = cnt[i];
+        off[i] = run;
+        run += cval;
+        cnt[i] = 0;
+    }
+}
+
+// sorted[lane][offsets[b] + k] = (w * n_bases + i) | sign<<31
+__global__ void k_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* offsets, u32* cursors, size_t B,
+                          u32* sorted) {
+    size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)W * size) return;
+    const unsigned lane = blockIdx.y;
+    u32 code = digits[(size_t)lane * W * size + e];
+    if (!code) return;
+    size_t w = e / size, i = e - w * size;
+    size_t b = (code & 0x7fffffffu) - 1;
+    u32 pos = offsets[(size_t)lane * B + b] + atomicAdd(&cursors[(size_t)lane * B + b], 1u);
+    sorted[(size_t)lane * W * size + pos] = (u32)(w * n_bases + i) | (code & 0x80000000u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bucket reduction: total = sum_j j * P_j + sum_j E_j over a segment; one level shrinks it by L.
+//   P_out[m] = sum_{t in chunk m} P[t]
+//   E_out[m] = sum_{t in chunk m} E[t] + 2^scale_dbl * sum_{t in chunk m} (t - start_m) * P[t]
+// with 2^scale_dbl = L^level, so that  L^(level+1) * sum_m m P_out[m] + sum_m E_out[m]  is unchanged.
+// ------------------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(128) void k_reduce_level(const u64* P_in, const u64* E_in, size_t n_in, unsigned L, unsigned scale_dbl,
+                                                     u64* P_out, u64* E_out, size_t n_out) {
+    constexpr int JW = GT<F>::JW;
+    size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_out) return;
+    const size_t seg = blockIdx.y;
+    const u64* P = P_in + (size_t)JW * seg * n_in;
+    size_t start = m * L, end = start + L < n_in ? start + L : n_in;
+    Jac<F> running = Jac<F>::zero(), A = Jac<F>::zero();
+    for (size_t t = end; t-- > start;) {
+        running = jac_add(running, jac_load<F>(P + JW * t));
+        if (t > start) A = jac_add(A, running);
+    }
+    for (unsigned k = 0; k < scale_dbl; k++) A = jac_double(A);
+    if (E_in) {
+        const u64* E = E_in + (size_t)JW * seg * n_in;
+        for (size_t t = start; t < end; t++) A = jac_add(A, jac_load<F>(E + JW * t));
+    }
+    jac_store<F>(P_out + (size_t)JW * (seg * n_out + m), running);
+    jac_store<F>(E_out + (size_t)JW * (seg * n_out + m), A);
+}
+
+// out[seg] = P[seg] + E[seg]   (weights are b+1: sum_b (b+1) B_b = sum_b b B_b + sum_b B_b)
+template <class F>
+__global__ void k_finish(const u64* P, const u64* E, size_t segs, u64* out) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= segs) return;
+    Jac<F> r = jac_load<F>(P + (size_t)GT<F>::JW * s);
+    if (E) r = jac_add(r, jac_load<F>(E + (size_t)GT<F>::JW * s));
+    jac_store<F>(out + (size_t)GT<F>::JW * s, r);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host drivers
+// ------------------------------------------------------------------------------------------------
+struct Bump {
+    char* base;
+    size_t off = 0;
+    template <class T>
+    T* take(size_t count) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = (T*)(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+static unsigned num_windows(unsigned c) { return (254 + c - 1) / c; }
+
+// window width for n bases: minimise W(c) * n mixed adds + ~3 * 2^(c-1) reduction adds
+static unsigned choose_c(size_t n) {
+    unsigned best = 2;
+    double best_cost = 1e300;
+    for (unsigned c = 2; c <= 22; c++) {
+        double cost = (double)num_windows(c) * (double)(n ? n : 1) + 3.0 * (double)((size_t)1 << (c - 1));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
+template <class F>
+static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const uint8_t* inf_dev) {
+    constexpr int AW = GT<F>::AW, JW = GT<F>::JW, FW = GT<F>::FW;
+    const size_t n = b->n;
+    const unsigned W = b->W;
+    CZK_HIP(ctx, hipMalloc(&b->pts, (size_t)W * (n ? n : 1) * AW * 8));
+    CZK_HIP(ctx, hipMalloc(&b->inf, (size_t)W * (n ? n : 1)));
+    if (!n) return CZK_OK;
+    CZK_HIP(ctx, hipMemcpyAsync(b->pts, pts_dev, n * AW * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (inf_dev) CZK_HIP(ctx, hipMemcpyAsync(b->inf, inf_dev, n, hipMemcpyDeviceToDevice, ctx->stream));
+    else CZK_HIP(ctx, hipMemsetAsync(b->inf, 0, n, ctx->stream));
+    if (W > 1) {
+        u64 *jac = nullptr, *scr = nullptr;
+        CZK_HIP(ctx, hipMalloc(&jac, n * JW * 8));
+        CZK_HIP(ctx, hipMalloc(&scr, n * FW * 8));
+        const unsigned CH = 32;
+        unsigned g1 = (unsigned)((n + 127) / 128), g2 = (unsigned)(((n + CH - 1) / CH + 127) / 128);
+        for (unsigned w = 1; w < W; w++) {
+            hipLaunchKernelGGL(k_dbl_c<F>, dim3(g1), dim3(128), 0, ctx->stream, b->pts + (size_t)(w - 1) * n * AW, b->inf + (size_t)(w - 1) * n,
+                               n, b->c, jac);
+            hipLaunchKernelGGL(k_batch_to_affine<F>, dim3(g2), dim3(128), 0, ctx->stream, jac, n, CH, scr, b->pts + (size_t)w * n * AW,
+                               b->inf + (size_t)w * n);
+        }
+        CZK_HIP(ctx, hipGetLastError());
+        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        CZK_HIP(ctx, hipFree(jac));
+        CZK_HIP(ctx, hipFree(scr));
+    }
+    return CZK_OK;
+}
+
+template <class F>
+static int msm_impl(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host) {
+    constexpr int JW = GT<F>::JW;
+    const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
+    const unsigned c = b->c, W = b->W;
+    const size_t B = (size_t)1 << (c - 1);
+    const unsigned L = 8, logL = 3;
+    if ((size_t)W * b->n >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
+
+    // workspace
+    size_t lvl0 = (B + L - 1) / L;
+    size_t need = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 2 + B * JW * 8 + 4 * lvl0 * JW * 8 + JW * 8) + (1 << 16);
+    CZK_TRY(ensure_buf(ctx, ctx->msm_ws, need));
+    Bump bump{(char*)ctx->msm_ws.p};
+    u32* digits = bump.take<u32>(lanes * W * size);
+    u32* sorted = bump.take<u32>(lanes * W * size);
+    u32* counts = bump.take<u32>(lanes * B);
+    u32* offsets = bump.take<u32>(lanes * B);
+    u64* buckets = bump.take<u64>(lanes * B * JW);
+    u64* lv[4];
+    for (int i = 0; i < 4; i++) lv[i] = bump.take<u64>(lanes * lvl0 * JW);
+    u64* result = bump.take<u64>(lanes * JW);
+
+    CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ctx->stream));
+    if (size) {
+        hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, scalars, n_scalars, size,
+                           form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, counts, B);
+    }
+    hipLaunchKernelGGL(k_offsets, dim3((unsigned)lanes), dim3(1024), 0, ctx->stream, counts, offsets, B);
+    if (size) {
+        hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, digits, size,
+                           W, b->n, offsets, counts, B, sorted);
+    }
+    if (GT<F>::AW == 12) launch_accumulate_g1(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
+    else launch_accumulate_g2(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
+    CZK_HIP(ctx, hipGetLastError());
+
+    // multi-level reduction
+    const u64 *P = buckets, *E = nullptr;
+    size_t n_in = B;
+    unsigned level = 0;
+    int flip = 0;
+    while (n_in > 1) {
+        size_t n_out = (n_in + L - 1) / L;
+        u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
+        hipLaunchKernelGGL(k_reduce_level<F>, dim3((unsigned)((n_out + 127) / 128), (unsigned)lanes), dim3(128), 0, ctx->stream, P, E, n_in, L,
+                           level * logL, Po, Eo, n_out);
+        P = Po;
+        E = Eo;
+        n_in = n_out;
+        level++;
+        flip ^= 1;
+    }
+    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, ctx->stream, P, E, lanes, result);
+    CZK_HIP(ctx, hipGetLastError());
+    CZK_HIP(ctx, hipMemcpyAsync(out_host, result, lanes * JW * 8, hipMemcpyDeviceToHost, ctx->stream));
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CZK_OK;
+}
+
+int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes, int scalar_form,
+               u64* out_jac_host) {
+    if (bases->group == CZK_G1) return msm_impl<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host);
+    return msm_impl<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host);
+}
+
+template <class F>
+static int fixed_base_impl(czk_ctx* ctx, const u64* k_dev, size_t n, u64* out_dev) {
+    constexpr int JW = GT<F>::JW, FW = GT<F>::FW;
+    if (!n) return CZK_OK;
+    u64 *jac = nullptr, *scr = nullptr;
+    uint8_t* inf = nullptr;
+    CZK_HIP(ctx, hipMalloc(&jac, n * JW * 8));
+    CZK_HIP(ctx, hipMalloc(&scr, n * FW * 8));
+    CZK_HIP(ctx, hipMalloc(&inf, n));
+    const unsigned CH = 32;
+    hipLaunchKernelGGL(k_fixed_base<F>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, k_dev, n, jac);
+    hipLaunchKernelGGL(k_batch_to_affine<F>, dim3((unsigned)(((n + CH - 1) / CH + 127) / 128)), dim3(128), 0, ctx->stream, jac, n, CH, scr,
+                       out_dev, inf);
+    CZK_HIP(ctx, hipGetLastError());
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CZK_HIP(ctx, hipFree(jac));
+    CZK_HIP(ctx, hipFree(scr));
+    CZK_HIP(ctx, hipFree(inf));
+    return CZK_OK;
+}
+
+int fixed_base_points_device(czk_ctx* ctx, int group, const u64* k_dev, size_t n, u64* out_dev) {
+    return group == CZK_G1 ? fixed_base_impl<Fq>(ctx, k_dev, n, out_dev) : fixed_base_impl<Fq2>(ctx, k_dev, n, out_dev);
+}
+
+}  // namespace czk
+
+using namespace czk;
+
+// ------------------------------------------------------------------------------------------------
+// C ABI (MSM part)
+// ------------------------------------------------------------------------------------------------
+extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases, const uint8_t* inf, size_t n, int mem, czk_bases** out) {
+    if (!ctx || !out) return CZK_ERR_ARG;
+    *out = nullptr;
+    if (group != CZK_G1 && group != CZK_G2) return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    if (n && !bases) return set_err(ctx, CZK_ERR_ARG, "null bases");
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t aw = group == CZK_G1 ? 12 : 24;
+    czk_bases* b = new czk_bases();
+    b->ctx = ctx;
+    b->group = group;
+    b->n = n;
+    b->c = choose_c(n);
+    b->W = num_windows(b->c);
+    const u64* pts_dev = bases;
+    const uint8_t* inf_dev = inf;
+    void *tmp_p = nullptr, *tmp_i = nullptr;
+    int rc = CZK_OK;
+    if (mem == CZK_MEM_HOST && n) {
+        if (hipMalloc(&tmp_p, n * aw * 8) != hipSuccess) rc = set_err(ctx, CZK_ERR_NOMEM, "hipMalloc bases staging");
+        if (rc == CZK_OK && hipMemcpyAsync(tmp_p, bases, n * aw * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+            rc = set_err(ctx, CZK_ERR_HIP, "H2D bases");
+        pts_dev = (const u64*)tmp_p;
+        if (rc == CZK_OK && inf) {
+            if (hipMalloc(&tmp_i, n) != hipSuccess) rc = set_err(ctx, CZK_ERR_NOMEM, "hipMalloc inf staging");
+            if (rc == CZK_OK && hipMemcpyAsync(tmp_i, inf, n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = set_err(ctx, CZK_ERR_HIP, "H2D inf");
+            inf_dev = (const uint8_t*)tmp_i;
+        }
+    }
+    if (rc == CZK_OK) rc = group == CZK_G1 ? register_impl<Fq>(ctx, b, pts_dev, inf_dev) : register_impl<Fq2>(ctx, b, pts_dev, inf_dev);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (tmp_p) (void)hipFree(tmp_p);
+    if (tmp_i) (void)hipFree(tmp_i);
+    if (rc != CZK_OK) {
+        czk_bases_release(b);
+        return rc;
+    }
+    *out = b;
+    return CZK_OK;
+}
+
+extern "C" void czk_bases_release(czk_bases* b) {
+    if (!b) return;
+    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    if (b->pts) (void)hipFree(b->pts);
+    if (b->inf) (void)hipFree(b->inf);
+    delete b;
+}
+
+extern "C" size_t czk_bases_len(const czk_bases* b) { return b ? b->n : 0; }
+
+extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,
+                       uint64_t* out_jac) {
+    if (!ctx || !bases || !out_jac) return ctx ? set_err(ctx, CZK_ERR_ARG, "null msm argument") : CZK_ERR_ARG;
+    if (n_scalars && !scalars) return set_err(ctx, CZK_ERR_ARG, "null scalars");
+    if (scalar_form != CZK_SCALAR_CANONICAL && scalar_form != CZK_SCALAR_MONTGOMERY) return set_err(ctx, CZK_ERR_ARG, "bad scalar_form");
+    if (!lanes) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    const u64* sdev = scalars;
+    void* tmp = nullptr;
+    if (mem == CZK_MEM_HOST && n_scalars) {
+        CZK_HIP(ctx, hipMalloc(&tmp, lanes * n_scalars * 32));
+        hipError_t e = hipMemcpyAsync(tmp, scalars, lanes * n_scalars * 32, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(tmp);
+            return set_err(ctx, CZK_ERR_HIP, "H2D scalars");
+        }
+        sdev = (const u64*)tmp;
+    }
+    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac);
+    if (tmp) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(tmp);
+    }
+    return rc;
+}
+
+static int msm_oneshot(czk_ctx* ctx, int group, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t lanes,
+                       int scalar_form, uint64_t* out_jac) {
+    czk_bases* b = nullptr;
+    CZK_TRY(czk_bases_register(ctx, group, bases_xy, inf, n, CZK_MEM_HOST, &b));
+    int rc = czk_msm(ctx, b, scalars, n, lanes, scalar_form, CZK_MEM_HOST, out_jac);
+    czk_bases_release(b);
+    return rc;
+}
+extern "C" int czk_msm_g1(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t lanes,
+                          int scalar_form, uint64_t* out_jac) {
+    if (!ctx) return CZK_ERR_ARG;
+    return msm_oneshot(ctx, CZK_G1, bases_xy, inf, scalars, n, lanes, scalar_form, out_jac);
+}
+extern "C" int czk_msm_g2(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t lanes,
+                          int scalar_form, uint64_t* out_jac) {
+    if (!ctx) return CZK_ERR_ARG;
+    return msm_oneshot(ctx, CZK_G2, bases_xy, inf, scalars, n, lanes, scalar_form, out_jac);
+}
+
+extern "C" int czk_fixed_base_points(czk_ctx* ctx, int group, const uint64_t* k, size_t n, uint64_t* out, int mem) {
+    if (!ctx || (n && (!k || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null fixed_base argument") : CZK_ERR_ARG;
+    if (group != CZK_G1 && group != CZK_G2) return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    if (!n) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t aw = group == CZK_G1 ? 12 : 24;
+    if (mem == CZK_MEM_DEVICE) return fixed_base_points_device(ctx, group, k, n, out);
+    void *kd = nullptr, *od = nullptr;
+    CZK_HIP(ctx, hipMalloc(&kd, n * 32));
+    CZK_HIP(ctx, hipMalloc(&od, n * aw * 8));
+    CZK_HIP(ctx, hipMemcpyAsync(kd, k, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    int rc = fixed_base_points_device(ctx, group, (const u64*)kd, n, (u64*)od);
+    if (rc == CZK_OK) {
+        CZK_HIP(ctx, hipMemcpyAsync(out, od, n * aw * 8, hipMemcpyDeviceToHost, ctx->stream));
+        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    (void)hipFree(kd);
+    (void)hipFree(od);
+    return rc;
+}

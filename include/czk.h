@@ -1,0 +1,146 @@
+/* czk.h -- C ABI of libczk_hip.so: the MI355X (gfx950) implementation of the per-party local compute
+ * of collaborative-zksnark's MPC provers (radix-2 NTT over BLS12-377 Fr on share lanes; variable-base MSM
+ * over BLS12-377 G1/G2).  Plain pointers and sizes only -- no torch / HIP types in any signature.
+ *
+ * The reference (alex-ozdemir/collaborative-zksnark) has no FFI; its seams are Rust trait impls.  Each
+ * entry point below names the reference interface it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the Rust `extern "C"` shim a maintainer would add at each seam.
+ *
+ * Data formats (identical to the reference's in-memory values):
+ *   Fr  : 4 x u64 little-endian limbs, Montgomery form R = 2^256   (algebra/ff/src/fields/macros.rs:103-108,
+ *         curves/bls12_377/src/fields/fr.rs:48-53); "canonical" = `into_repr()` BigInteger256.
+ *   Fq  : 6 x u64, Montgomery form R = 2^384                         (curves/bls12_377/src/fields/fq.rs:43-50)
+ *   Fq2 : c0, c1 (12 x u64)                                           (fields/models/quadratic_extension.rs:136-142)
+ *   G1 affine  : x, y          = 12 u64  + a separate u8 infinity flag per point
+ *   G1 Jacobian: x, y, z       = 18 u64  (infinity <=> z == 0)        (short_weierstrass_jacobian.rs:338-344)
+ *   G2 affine  : x.c0 x.c1 y.c0 y.c1 = 24 u64 + u8 flag;  G2 Jacobian = 36 u64
+ * Rust's struct layout is unspecified (no #[repr(C)]), so the shim repacks into these arrays.
+ *
+ * Memory: every buffer argument is either host memory (CZK_MEM_HOST: the library stages it through
+ * HBM) or device memory on the context's GPU (CZK_MEM_DEVICE: used in place, no copies).
+ * Threading: one czk_ctx = one GPU + one HIP stream = one MPC party; calls on a ctx are serialized by
+ * the caller (the reference prover is single-threaded; mpc-net/src/multi.rs:15-23).
+ * Errors: every call returns a czk_status; the reference's `None`/`assert!`/`unwrap()` sites map to
+ * CZK_ERR_SIZE / CZK_ERR_ARG and the shim `expect()`s them, preserving panic behaviour.
+ */
+#ifndef CZK_H
+#define CZK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct czk_ctx czk_ctx;
+typedef struct czk_bases czk_bases;
+
+typedef enum {
+    CZK_OK = 0,
+    CZK_ERR_SIZE = 1,  /* domain too large (log2 D > TWO_ADICITY = 47: radix2/mod.rs:61-63) or len > D (:100) */
+    CZK_ERR_HIP = 2,   /* HIP runtime failure (message via czk_last_error) */
+    CZK_ERR_ARG = 3,   /* null / inconsistent argument */
+    CZK_ERR_NOMEM = 4
+} czk_status;
+
+typedef enum { CZK_MEM_HOST = 0, CZK_MEM_DEVICE = 1 } czk_mem;
+
+/* EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (algebra/poly/src/domain/mod.rs:79,90,139,155) */
+typedef enum { CZK_FFT = 0, CZK_IFFT = 1, CZK_COSET_FFT = 2, CZK_COSET_IFFT = 3 } czk_ntt_kind;
+
+/* scalar encodings accepted by the MSM */
+typedef enum {
+    CZK_SCALAR_CANONICAL = 0, /* BigInteger256, as VariableBaseMSM::multi_scalar_mul takes (msm/variable_base.rs:12-15) */
+    CZK_SCALAR_MONTGOMERY = 1 /* Fr, as AffineCurve::multi_scalar_mul takes; into_repr runs on the GPU (ec/src/lib.rs:300-311) */
+} czk_scalar_form;
+
+typedef enum { CZK_G1 = 1, CZK_G2 = 2 } czk_group;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+/* `hip_stream`: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL for a private one. */
+int czk_ctx_create(czk_ctx** out, int device, void* hip_stream);
+void czk_ctx_destroy(czk_ctx* ctx);
+int czk_ctx_sync(czk_ctx* ctx);
+const char* czk_last_error(const czk_ctx* ctx);
+const char* czk_version(void);
+
+/* ---- NTT ---------------------------------------------------------------------------------------- */
+/* Replaces Radix2EvaluationDomain<Fr>::{fft,ifft,coset_ifft}_in_place (algebra/poly/src/domain/radix2/mod.rs:99-117)
+ * and the trait-default coset_fft_in_place (domain/mod.rs:139-142) for T = Fr lanes (an MpcField<Fr, SpdzFieldShare>
+ * vector is two lanes: sh and mac; mpc-algebra/src/share/spdz.rs:186-202).
+ * data: lanes x D x 4 u64, D = 2^log_d, lane-major, transformed in place, natural order in and out.
+ * in_len <= D: entries [in_len, D) of every lane are taken as zero (`resize(size, T::zero())`) whatever they hold.
+ * Root of unity = get_root_of_unity(D) = LARGE_SUBGROUP_ROOT_OF_UNITY^3 squared down (ff/src/fields/mod.rs:360-367);
+ * coset shift = Fr::multiplicative_generator() = 22. */
+int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int kind, size_t in_len, int mem);
+
+/* Domain constants as the reference's Radix2EvaluationDomain::new computes them (radix2/mod.rs:51-82), Montgomery
+ * limbs: out[0..4) size_inv, [4..8) group_gen, [8..12) group_gen_inv, [12..16) generator (22), [16..20) generator_inv,
+ * [20..24) (generator^D - 1)^-1 used by divide_by_vanishing_poly_on_coset_in_place (domain/mod.rs:184-191). */
+int czk_domain_constants(czk_ctx* ctx, unsigned log_d, uint64_t* out24);
+
+/* ---- element-wise Fr vector ops (the share-local pointwise steps of witness_map) ------------------ */
+/* out[i] = a[i] op b[i], n elements of 4 u64; out may alias a or b.  r1cs_to_qap.rs:92 (plain product), :105-107 (sub). */
+typedef enum { CZK_OP_ADD = 0, CZK_OP_SUB = 1, CZK_OP_MUL = 2 } czk_binop;
+int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int mem);
+/* out[i] = a[i] * k  (k: one Montgomery Fr; domain/mod.rs:184-191) */
+int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n, int mem);
+/* Local half of Beaver multiplication (mpc-algebra/src/share/field.rs:97-127), per lane:
+ *   out[i] = z[i] - y[i]*sx[i] - x[i]*oy[i] + (add_open ? sx[i]*oy[i] : 0)
+ * x, y, z: this party's triple shares; sx, oy: the opened values; add_open = this party applies `shift`
+ * (king for the sh lane, mac_share != 0 for the mac lane; share/spdz.rs:31-37,204-208). */
+int czk_fr_beaver_combine(czk_ctx* ctx, const uint64_t* x, const uint64_t* y, const uint64_t* z, const uint64_t* sx,
+                          const uint64_t* oy, int add_open, uint64_t* out, size_t n, int mem);
+/* Fr::into_repr / from_repr over a vector (fields/arithmetic.rs:59-81, macros.rs:443-454) -- also the wire format. */
+int czk_fr_into_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
+int czk_fr_from_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
+
+/* ---- MSM ---------------------------------------------------------------------------------------- */
+/* Pin a public base array (a proving-key query) on the GPU once; it is reused across proofs
+ * (groth16/src/data_structures.rs:132-149).  bases: n x (12|24) u64 affine Montgomery; inf: n bytes (may be NULL =
+ * no infinity points). */
+int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases, const uint8_t* inf, size_t n, int mem,
+                       czk_bases** out);
+void czk_bases_release(czk_bases* b);
+size_t czk_bases_len(const czk_bases* b);
+
+/* Replaces VariableBaseMSM::multi_scalar_mul (algebra/ec/src/msm/variable_base.rs:12-106) / AffineCurve::
+ * multi_scalar_mul (ec/src/lib.rs:300-311) as reached from MpcG{1,2}Affine::multi_scalar_mul
+ * (mpc-algebra/src/wire/pairing.rs:746-809) -> GroupShare::multi_scale_pub_group (share/spdz.rs:440-446).
+ * scalars: lanes x n_scalars x 4 u64 (lane-major); `lanes` scalar vectors share the bases (SPDZ: sh and mac).
+ * size = min(czk_bases_len, n_scalars) pairs are used (variable_base.rs:16; h has D scalars vs D-1 bases).
+ * out_jac: lanes x (18|36) u64 Jacobian, Montgomery, HOST memory.  Jacobian triples are not canonical: compare in
+ * affine (czk_jac_to_affine), as the reference's own MSM test does (algebra/test-templates/src/msm.rs:16-33). */
+int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
+            int scalar_form, int mem, uint64_t* out_jac);
+
+/* One-shot forms with the reference's argument order (bases not kept on the GPU). */
+int czk_msm_g1(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
+               size_t lanes, int scalar_form, uint64_t* out_jac);
+int czk_msm_g2(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
+               size_t lanes, int scalar_form, uint64_t* out_jac);
+
+/* From<GroupProjective> for GroupAffine (short_weierstrass_jacobian.rs:768-789): n host Jacobian points ->
+ * n host affine points + infinity flags.  This is what AffineMsm::msm's `.into()` does (share/msm.rs:31-37). */
+int czk_jac_to_affine(czk_ctx* ctx, int group, const uint64_t* jac, size_t n, uint64_t* out_aff, uint8_t* out_inf);
+
+/* Synthetic public bases P_i = [k_i] * generator for i < n, k_i = canonical scalars (n x 4 u64), written as
+ * affine Montgomery points to `out` (device or host).  Stands in for a trusted-setup run when benchmarking
+ * (SURVEY.md section 8d); also how tests obtain on-curve points with known discrete logs. */
+int czk_fixed_base_points(czk_ctx* ctx, int group, const uint64_t* k, size_t n, uint64_t* out, int mem);
+
+/* ---- Groth16 per-party local compute (callers of the two kernels) -------------------------------- */
+/* R1CStoQAP::witness_map minus its communication step (mpc-snarks/src/groth/r1cs_to_qap.rs:47-113), on `lanes`
+ * Fr lanes of D = 2^log_d elements, all buffers lanes x D x 4 u64 in DEVICE memory:
+ *   czk_witness_map_pre : a <- coset_fft(ifft(a)), b <- coset_fft(ifft(b))                       (:85-89)
+ *   [caller: ab = batch_product(a, b) -- Beaver opens for shares, czk_fr_vec_op(MUL) for a single prover] (:92)
+ *   czk_witness_map_post: c <- coset_fft(ifft(c)); ab <- coset_ifft((ab - c) * Z(g)^-1)          (:102-110)
+ * h = ab on return. */
+int czk_witness_map_pre(czk_ctx* ctx, uint64_t* a, uint64_t* b, unsigned log_d, size_t lanes);
+int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, unsigned log_d, size_t lanes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CZK_H */

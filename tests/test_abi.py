@@ -1,0 +1,39 @@
+"""CPU-only checks of the drop-in boundary: libczk_hip.so loads without a GPU and exports every symbol that
+include/czk.h declares; calls that need a GPU fail loudly (no CPU fallback)."""
+import ctypes as C
+
+import pytest
+
+
+def test_library_exports_every_declared_symbol():
+    import czk_amd
+    hs, es = czk_amd.header_symbols(), czk_amd.exported_symbols()
+    assert len(hs) >= 20
+    assert hs == es, sorted(set(hs) - set(es))
+    assert b"gfx950" in czk_amd.lib().czk_version()
+
+
+def test_product_never_touches_the_oracle():
+    # the product package must not import, link or reference anything under oracle/
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "collaborative-zksnark_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                assert "czk_oracle" not in txt and "import orc" not in txt and "pyref" not in txt, fn
+    import subprocess
+    out = subprocess.run(["ldd", os.path.join(pkg, "libczk_hip.so")], capture_output=True, text=True).stdout
+    assert "czk_oracle" not in out
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import czk_amd
+    with pytest.raises(czk_amd.CzkError):
+        czk_amd.Context(0)
+    # null-context calls are rejected, not crashed
+    assert czk_amd.lib().czk_ntt_fr(None, None, C.c_uint(3), C.c_size_t(1), 0, C.c_size_t(8), 0) == 3

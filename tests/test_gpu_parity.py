@@ -1,0 +1,268 @@
+"""Parity tests proper: the HIP path (through the C ABI, libczk_hip.so) against the CPU checker (oracle/) on the
+same seeded inputs -- bit-exact limbs for field/NTT results, affine equality for group results.  Run on a real
+MI355X with `-m gpu`."""
+import numpy as np
+import pytest
+
+from util import ints_to_limbs, limbs_to_ints, rand_fr_canonical, R_MOD
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import czk_amd
+    c = czk_amd.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def czk():
+    import czk_amd
+    return czk_amd
+
+
+def test_field_vector_ops_bit_exact(ctx, czk, orc):
+    n = 5000
+    a = rand_fr_canonical(11, n)
+    b = rand_fr_canonical(12, n)
+    edge = ints_to_limbs([0, 1, R_MOD - 1, R_MOD - 2, 2, 1 << 252], 4)
+    a[:6], b[:6] = edge, edge[::-1]
+    from czk_amd.binding import CZK_OP_ADD, CZK_OP_MUL, CZK_OP_SUB
+    assert np.array_equal(ctx.fr_vec_op(CZK_OP_MUL, a, b), orc.fr_mul(a, b))
+    assert np.array_equal(ctx.fr_vec_op(CZK_OP_ADD, a, b), orc.fr_add(a, b))
+    assert np.array_equal(ctx.fr_vec_op(CZK_OP_SUB, a, b), orc.fr_sub(a, b))
+    assert np.array_equal(ctx.fr_into_repr(a), orc.fr_into_repr(a))
+    assert np.array_equal(ctx.fr_from_repr(a), orc.fr_from_repr(a))
+    k = a[7].copy()
+    assert np.array_equal(ctx.fr_vec_scale(a, k), orc.fr_mul(a, np.tile(k, (n, 1))))
+    # local half of Beaver multiplication (share/field.rs:116-126): z - y*sx - x*oy (+ sx*oy for the king)
+    x, y, z = rand_fr_canonical(13, n), rand_fr_canonical(14, n), rand_fr_canonical(15, n)
+    sx, oy = a, b
+    base = orc.fr_sub(orc.fr_sub(z, orc.fr_mul(y, sx)), orc.fr_mul(x, oy))
+    assert np.array_equal(ctx.fr_beaver_combine(x, y, z, sx, oy, False), base)
+    assert np.array_equal(ctx.fr_beaver_combine(x, y, z, sx, oy, True), orc.fr_add(base, orc.fr_mul(sx, oy)))
+    # empty input
+    assert ctx.fr_vec_op(CZK_OP_MUL, a[:0], b[:0]).size == 0
+
+
+def test_domain_constants_match_reference_rule(ctx, orc):
+    for log_d in (0, 1, 5, 16, 21, 23, 47):
+        got, want = ctx.domain_constants(log_d), orc.domain_constants(log_d)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), (log_d, k)
+    import czk_amd
+    with pytest.raises(czk_amd.CzkError) as e:     # D::new -> None above 2^47 (radix2/mod.rs:61-63)
+        ctx.domain_constants(48)
+    assert e.value.code == 1
+
+
+@pytest.mark.parametrize("log_d", [0, 1, 2, 3, 4, 6, 7, 8, 10, 13, 14, 15, 16])
+def test_ntt_all_kinds_bit_exact(ctx, czk, orc, log_d):
+    d = 1 << log_d
+    for in_len in sorted({d, max(1, d - 3), (d + 1) // 2}):
+        lanes = 2
+        x = orc.fr_from_repr(rand_fr_canonical(100 + log_d, lanes * in_len)).reshape(lanes, in_len, 4)
+        for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+            buf = np.full((lanes, d, 4), 0xDEADBEEFDEADBEEF, dtype=np.uint64)   # garbage tail must be ignored
+            buf[:, :in_len] = x
+            ctx.ntt_fr(buf, log_d, kind, lanes=lanes, in_len=in_len)
+            for ln in range(lanes):
+                want = orc.ntt_fr(x[ln], log_d, kind, in_len)
+                assert np.array_equal(buf[ln], want), (log_d, in_len, kind, ln)
+
+
+def test_ntt_size_errors(ctx, czk):
+    buf = np.zeros((8, 4), dtype=np.uint64)
+    with pytest.raises(czk.CzkError) as e:      # assert!(coeffs.len() <= self.size()) radix2/mod.rs:100
+        ctx.ntt_fr(buf, 3, czk.CZK_FFT, in_len=9)
+    assert e.value.code == 1
+    with pytest.raises(czk.CzkError) as e:
+        ctx.ntt_fr(buf, 48, czk.CZK_FFT, in_len=1)
+    assert e.value.code == 1
+
+
+def _fr_pow(orc, base, e):
+    acc = orc.fr_from_repr(ints_to_limbs([1], 4))[0]
+    base = base.copy()
+    while e:
+        if e & 1:
+            acc = orc.fr_mul(acc, base)
+        base = orc.fr_mul(base, base)
+        e >>= 1
+    return acc
+
+
+def test_ntt_device_memory_and_full_size_properties(ctx, czk, orc):
+    """BASELINE size D = 2^21, device-resident, 2 lanes: round trips restore the input exactly; forward
+    transforms agree with Horner evaluation at w^i / 22 w^i (radix2/mod.rs:320-360) at sampled points."""
+    import torch
+    log_d, lanes = 21, 2
+    d = 1 << log_d
+    x = orc.fr_from_repr(rand_fr_canonical(777, lanes * d)).reshape(lanes, d, 4)
+    t = torch.from_numpy(x.view(np.int64)).cuda()
+    k = orc.domain_constants(log_d)
+    w, g = k["group_gen"], k["generator"]
+    for fwd, inv in ((czk.CZK_FFT, czk.CZK_IFFT), (czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT)):
+        ctx.ntt_fr(t.data_ptr(), log_d, fwd, lanes=lanes, mem=czk.CZK_MEM_DEVICE)
+        ctx.sync()
+        ev = t.cpu().numpy().view(np.uint64)
+        for i in (0, 1, 2, 12345, d // 2, d - 1):
+            pt = _fr_pow(orc, w, i)
+            if fwd == czk.CZK_COSET_FFT:
+                pt = orc.fr_mul(pt, g)
+            for ln in range(lanes):
+                assert np.array_equal(ev[ln, i], orc.fr_horner(x[ln], pt)), (fwd, i, ln)
+        ctx.ntt_fr(t.data_ptr(), log_d, inv, lanes=lanes, mem=czk.CZK_MEM_DEVICE)
+        ctx.sync()
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), x)
+    # linearity on the device buffer: NTT(a + b) == NTT(a) + NTT(b)
+    s = orc.fr_add(x[0], x[1])
+    ts = torch.from_numpy(s.view(np.int64)).cuda()
+    ctx.ntt_fr(ts.data_ptr(), log_d, czk.CZK_FFT, lanes=1, mem=czk.CZK_MEM_DEVICE)
+    ctx.ntt_fr(t.data_ptr(), log_d, czk.CZK_FFT, lanes=2, mem=czk.CZK_MEM_DEVICE)
+    ctx.sync()
+    tt = t.cpu().numpy().view(np.uint64)
+    assert np.array_equal(ts.cpu().numpy().view(np.uint64), orc.fr_add(tt[0], tt[1]))
+
+
+def _bases(ctx, g, n, seed):
+    k = rand_fr_canonical(seed, n)
+    return k, ctx.fixed_base_points(g, k)
+
+
+def _same_point(ctx, orc, g, have_jac, want_jac):
+    want_aff, want_inf = orc.jac_to_affine(g, want_jac)
+    have_aff, have_inf = ctx.jac_to_affine(g, have_jac)
+    chk_aff, chk_inf = orc.jac_to_affine(g, have_jac)     # product's own to-affine agrees with the checker's
+    assert chk_inf == bool(have_inf[0]) and (chk_inf or np.array_equal(chk_aff, have_aff[0]))
+    return bool(have_inf[0]) == want_inf and (want_inf or np.array_equal(have_aff[0], want_aff))
+
+
+@pytest.mark.parametrize("g", [1, 2])
+def test_fixed_base_points_match_scalar_mul(ctx, czk, orc, g):
+    n = 40
+    k = rand_fr_canonical(21 + g, n)
+    k[0] = ints_to_limbs([1], 4)[0]
+    k[1] = ints_to_limbs([2], 4)[0]
+    k[2] = ints_to_limbs([R_MOD - 1], 4)[0]
+    pts = ctx.fixed_base_points(g, k)
+    gen = pts[0]                                  # k = 1 -> the generator itself
+    for i in range(n):
+        want, inf = orc.jac_to_affine(g, orc.scalar_mul(g, gen, False, k[i]))
+        assert not inf and np.array_equal(pts[i], want), (g, i)
+    if g == 1:
+        assert all(orc.g1_on_curve(p) for p in pts)
+
+
+@pytest.mark.parametrize("g,n", [(1, 1), (1, 2), (1, 10), (1, 31), (1, 33), (1, 300), (1, 4096), (2, 1), (2, 10), (2, 33), (2, 700)])
+def test_msm_matches_reference_pippenger(ctx, czk, orc, g, n):
+    """Pippenger parity in affine (test-templates/src/msm.rs:16-33), with the reference's special cases: zero
+    scalars (variable_base.rs:19), unit scalars (:44-48), infinity bases, equal and opposite bases."""
+    _, bases = _bases(ctx, g, n, 300 + n)
+    inf = np.zeros(n, dtype=np.uint8)
+    sc = rand_fr_canonical(400 + n, 2 * n).reshape(2, n, 4)
+    if n >= 10:
+        bases[3] = bases[2]                                            # equal points
+        aw = bases.shape[1] // 2
+        neg = bases[4].copy()
+        if g == 1:
+            neg[aw:] = orc.fq_neg(bases[4][aw:])
+        else:
+            neg[aw:] = np.concatenate([orc.fq_neg(bases[4][aw:aw + 6]), orc.fq_neg(bases[4][aw + 6:])])
+        bases[5] = neg                                                 # opposite points
+        inf[7] = 1
+        sc[:, 0] = 0
+        sc[:, 1] = ints_to_limbs([1], 4)[0]
+        sc[:, 2] = sc[:, 3] = ints_to_limbs([5], 4)[0]
+        sc[:, 4] = sc[:, 5] = ints_to_limbs([R_MOD - 3], 4)[0]
+    b = ctx.register_bases(g, bases, inf)
+    assert len(b) == n
+    got = ctx.msm(b, sc, lanes=2)
+    for ln in range(2):
+        assert _same_point(ctx, orc, g, got[ln], orc.msm(g, bases, inf, sc[ln])), (g, n, ln)
+    # AffineCurve::multi_scalar_mul: Montgomery scalars, one more scalar than bases (h vs h_query, lib.rs:304)
+    scm = orc.fr_from_repr(np.vstack([sc[0], ints_to_limbs([77], 4)]))
+    got_m = ctx.msm(b, scm, lanes=1, scalar_form=czk.CZK_SCALAR_MONTGOMERY)
+    assert _same_point(ctx, orc, g, got_m[0], orc.multi_scalar_mul(g, bases, inf, scm))
+    # fewer scalars than bases: size = min(len) (variable_base.rs:16)
+    if n > 2:
+        got_s = ctx.msm(b, sc[0, : n - 1], lanes=1)
+        assert _same_point(ctx, orc, g, got_s[0], orc.msm(g, bases[: n - 1], inf[: n - 1], sc[0, : n - 1]))
+    b.release()
+    # one-shot entry point with the reference's argument order
+    one = ctx.msm_oneshot(g, bases, inf, sc[0])
+    assert _same_point(ctx, orc, g, one[0], orc.msm(g, bases, inf, sc[0]))
+
+
+def test_msm_empty_and_all_zero(ctx, czk, orc):
+    _, bases = _bases(ctx, 1, 8, 5)
+    b = ctx.register_bases(1, bases, None)
+    out = ctx.msm(b, np.zeros((8, 4), dtype=np.uint64))
+    assert ctx.jac_to_affine(1, out[0])[1][0] == 1          # all-zero scalars -> infinity
+    out = ctx.msm(b, np.zeros((0, 4), dtype=np.uint64), n_scalars=0)
+    assert ctx.jac_to_affine(1, out[0])[1][0] == 1          # empty -> zero()
+    b.release()
+    b0 = ctx.register_bases(1, np.zeros((0, 12), dtype=np.uint64), None)
+    out = ctx.msm(b0, rand_fr_canonical(1, 4))
+    assert ctx.jac_to_affine(1, out[0])[1][0] == 1
+    b0.release()
+
+
+@pytest.mark.parametrize("g,log_n", [(1, 20), (2, 17)])
+def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, log_n):
+    """Size-independent check at BASELINE scale: bases P_i = [k_i] G, so MSM(P, s) must equal
+    [sum k_i s_i mod r] G; plus linearity between the two lanes."""
+    import torch
+    n = (1 << log_n) + 1
+    k = rand_fr_canonical(0xBA5E5, n)
+    aw = 12 if g == 1 else 24
+    kd = torch.from_numpy(k.view(np.int64)).cuda()
+    pts = torch.empty((n, aw), dtype=torch.int64, device="cuda")
+    ctx.fixed_base_points(g, kd.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+    b = ctx.register_bases(g, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
+    s = rand_fr_canonical(0xC0FFEE, 2 * n).reshape(2, n, 4)
+    sd = torch.from_numpy(s.view(np.int64)).cuda()
+    out = ctx.msm(b, sd.data_ptr(), n_scalars=n, lanes=2, mem=czk.CZK_MEM_DEVICE)
+    ki, gen = limbs_to_ints(k), ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
+    for ln in range(2):
+        si = limbs_to_ints(s[ln])
+        e = sum(a * c for a, c in zip(ki, si)) % R_MOD
+        assert _same_point(ctx, orc, g, out[ln], orc.scalar_mul(g, gen, False, ints_to_limbs([e], 4)[0])), (g, ln)
+    # linearity: MSM(s0) + MSM(s1) == MSM(s0 + s1)
+    ssum = orc.fr_into_repr(orc.fr_add(orc.fr_from_repr(s[0]), orc.fr_from_repr(s[1])))
+    out_sum = ctx.msm(b, ssum, lanes=1)
+    assert _same_point(ctx, orc, g, out_sum[0], orc.jac_add(g, out[0], out[1]))
+    b.release()
+
+
+def test_witness_map_matches_reference_sequence(ctx, czk, orc):
+    """R1CStoQAP::witness_map (r1cs_to_qap.rs:47-113) for a single prover on device buffers, squaring circuit
+    of N = 1000 constraints (proof.rs:304-344): a_i = b_i = w_i, c_i = w_{i+1}, a[N] = 1, a[N+1] = out."""
+    import torch
+    from czk_amd.binding import CZK_OP_MUL
+    n_c, log_d = 1000, 10
+    d = 1 << log_d
+    one = orc.fr_from_repr(ints_to_limbs([1], 4))
+    w = [orc.fr_from_repr(rand_fr_canonical(9, 1))]
+    for _ in range(n_c):
+        w.append(orc.fr_sqr(w[-1]))
+    w = np.vstack(w)                       # w_0 .. w_N (w_N = public output)
+    a = np.zeros((d, 4), dtype=np.uint64)
+    a[:n_c] = w[:n_c]
+    a[n_c], a[n_c + 1] = one[0], w[n_c]    # instance assignment copy (r1cs_to_qap.rs:79-83)
+    bq = np.zeros((d, 4), dtype=np.uint64)
+    bq[:n_c] = w[:n_c]
+    c = np.zeros((d, 4), dtype=np.uint64)
+    c[:n_c] = w[1:n_c + 1]
+    want = orc.witness_map_plain(a, bq, c, log_d)
+    ta, tb, tc = (torch.from_numpy(v.view(np.int64).copy()).cuda() for v in (a, bq, c))
+    ctx.witness_map_pre(ta.data_ptr(), tb.data_ptr(), log_d, 1)
+    ctx.fr_vec_op(CZK_OP_MUL, ta.data_ptr(), tb.data_ptr(), out=ta.data_ptr(), n=d, mem=czk.CZK_MEM_DEVICE)
+    ctx.witness_map_post(ta.data_ptr(), tc.data_ptr(), log_d, 1)
+    ctx.sync()
+    h = ta.cpu().numpy().view(np.uint64)
+    assert np.array_equal(h, want)
+    # the quotient is exact: deg h <= D - 2, so the top coefficient is zero
+    assert not h[d - 1].any()
