@@ -40,6 +40,13 @@ def lib():
         if not os.path.exists(_LIB):
             raise FileNotFoundError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(there is no CPU fallback for the product path)")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes cannot share a process, so let
+        # torch's copy load first (same SONAME -> libczk_hip.so binds to it).  torch is plumbing here: device
+        # memory, streams, torch.distributed.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(_LIB)
         _lib.czk_last_error.restype = C.c_char_p
         _lib.czk_version.restype = C.c_char_p
@@ -103,7 +110,7 @@ class Context:
         if in_len is None:
             in_len = d
         if isinstance(data, np.ndarray):
-            assert data.dtype == np.uint64 and data.size == lanes * d * 4, "buffer must hold lanes x D x 4 u64"
+            assert data.dtype == np.uint64 and (log_d > 40 or data.size == lanes * d * 4), "buffer must hold lanes x D x 4 u64"
         self._ck(lib().czk_ntt_fr(self._h, _ptr(data), C.c_uint(log_d), C.c_size_t(lanes), C.c_int(kind), C.c_size_t(in_len),
                                   C.c_int(mem)))
         return data

@@ -40,14 +40,10 @@ CZK_HD Jac<F> jac_double(const Jac<F>& p) {
 }
 
 // The equal-points branch of the additions is essentially never taken in an MSM (it needs two equal bases in
-// one bucket); keep it out of line so the hot loop's code and register footprint stay small.
+// one bucket).  It stays inlined: an out-of-line call here (large by-value aggregates through scratch) hung the
+// G2 accumulation kernel on gfx950 / ROCm 7.2, and the cold code costs nothing when it is not executed.
 template <class F>
-#if defined(__HIPCC__)
-__host__ __device__ __attribute__((noinline))
-#else
-inline
-#endif
-Jac<F> jac_double_rare(const Jac<F>& p) {
+CZK_HD Jac<F> jac_double_rare(const Jac<F>& p) {
     return jac_double(p);
 }
 

@@ -10,7 +10,7 @@ namespace czk {
 // multiples 2^(c*w) * P_i in affine Montgomery form.  acc += (+/-) P with madd-2007-bl
 // (short_weierstrass_jacobian.rs:570-638, edge cases included).
 template <class F>
-__global__ __launch_bounds__(128) void k_accumulate(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts,
                                                    size_t B, size_t sorted_stride, u64* buckets) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;

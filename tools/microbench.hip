@@ -79,13 +79,21 @@ __global__ void k_mul_fr(u64* data, int iters) {
     for (int i = 0; i < iters; i++) { a = fp_mul(a, b); b = fp_mul(b, a); }
     fp_store<FrParams>(data + 4 * t, fp_add(a, b));
 }
-__global__ __launch_bounds__(128) void k_madd(u64* data, int iters) {
+template <int WPE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_madd(u64* data, int iters) {
     size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
     Affine<Fq> p = aff_load<Fq>(data + 12 * t);
     Jac<Fq> acc{p.x, p.y, Fq::one()};
     acc = jac_double(acc);
     for (int i = 0; i < iters; i++) acc = jac_add_mixed(acc, p, false);
     jac_store<Fq>(data + 18 * t, acc);
+}
+template <int WPE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mul2(u64* data, int iters) {
+    size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    Fq2 a = FieldIO<Fq2>::load(data + 12 * t), b = a;
+    for (int i = 0; i < iters; i++) { a = f_mul(a, b); b = f_mul(b, a); }
+    FieldIO<Fq2>::store(data + 12 * t, f_add(a, b));
 }
 
 int main() {
@@ -115,6 +123,11 @@ int main() {
     timeit("Fr mul (256thr x8/CU)", [&](int it) { hipLaunchKernelGGL(k_mul_fr, dim3(blocks), dim3(threads), 0, 0, data, it); }, 2, n);
     timeit("Fq mul (256thr x8/CU)", [&](int it) { hipLaunchKernelGGL(k_mul<Fq>, dim3(blocks), dim3(threads), 0, 0, data, it); }, 2, n);
     timeit("Fq2 mul (=3 Fq mul)", [&](int it) { hipLaunchKernelGGL(k_mul<Fq2>, dim3(blocks), dim3(threads), 0, 0, data, it); }, 6, n);
-    timeit("G1 madd (=11 Fq mul)", [&](int it) { hipLaunchKernelGGL(k_madd, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
+    timeit("Fq2 mul wpe2", [&](int it) { hipLaunchKernelGGL(k_mul2<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 6, n);
+    timeit("Fq2 mul wpe3", [&](int it) { hipLaunchKernelGGL(k_mul2<3>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 6, n);
+    timeit("G1 madd wpe1", [&](int it) { hipLaunchKernelGGL(k_madd<1>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
+    timeit("G1 madd wpe2", [&](int it) { hipLaunchKernelGGL(k_madd<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
+    timeit("G1 madd wpe3", [&](int it) { hipLaunchKernelGGL(k_madd<3>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
+    timeit("G1 madd wpe4", [&](int it) { hipLaunchKernelGGL(k_madd<4>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
     return 0;
 }
