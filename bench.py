@@ -1,0 +1,338 @@
+#!/usr/bin/env python3
+"""bench.py -- collaborative Groth16 proofs/sec (BLS12-377, 2^20 constraints, SPDZ, 2 parties) on MI355X.
+
+One "step" = the complete per-party local compute of ONE proof for BOTH parties of a 2-party SPDZ prover on one
+GPU (BASELINE.json configs[1]): the R1CS->QAP witness map (7 share-vector NTT ops per party = 28 Fr NTT lanes of
+D = 2^21, the Beaver local half and the pointwise steps) plus the 5 MSMs h / l / a / b_g1 / b_g2 for every share
+lane (4 lanes: 2 parties x {sh, mac}), inputs already resident in HBM, outputs = the 20 MSM results on the host.
+With N GPUs every rank proves its own independent proof (weak scaling, no data-path collective: parties and
+proofs are independent units); value = N * steps / max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (G1 bucket accumulation), timed live with
+HIP events on the stream it runs on; `cpu_baseline` times the CPU checker (oracle/, the C restatement of the
+reference algorithms, single thread like the reference's build) on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+R_MOD = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def to_mont_limbs(vals):
+    """python ints (canonical) -> (n,4) uint64 Montgomery limbs (a * 2^256 mod r)."""
+    R = (1 << 256) % R_MOD
+    buf = b"".join(((v * R) % R_MOD).to_bytes(32, "little") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+class Groth16Local:
+    """Device-resident state + the per-step pipeline (mpc-snarks/src/groth/{r1cs_to_qap.rs:47-113, prover.rs:66-178})."""
+
+    def __init__(self, czk, ctx, log_n: int, parties: int, seed: int = 0xC0FFEE):
+        from util import rand_fr_canonical
+        self.czk, self.ctx = czk, ctx
+        self.N = 1 << log_n
+        self.P = parties
+        self.lanes = 2 * parties                      # SPDZ: sh + mac per party (share/spdz.rs:50-53)
+        self.log_d = (self.N + 2 - 1).bit_length()    # D = next_pow2(N + num_instance) (r1cs_to_qap.rs:63-65)
+        self.D = 1 << self.log_d
+        N, D, L = self.N, self.D, self.lanes
+        dev = torch.device("cuda")
+
+        # ---- synthetic proving key: P_i = [k_i] G  (seed 0xBA5E5) -------------------
+        def mk_bases(group, n, sd, inf_first=False):
+            k = torch.from_numpy(rand_fr_canonical(0xBA5E5 + sd, n).view(np.int64)).to(dev)
+            aw = 12 if group == czk.CZK_G1 else 24
+            pts = torch.empty((n, aw), dtype=torch.int64, device=dev)
+            ctx.fixed_base_points(group, k.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+            inf = torch.zeros(n, dtype=torch.uint8, device=dev)
+            if inf_first:
+                inf[0] = 1   # b_query[1] (the public output has no B entry) is infinity in the real key
+            b = ctx.register_bases(group, pts.data_ptr(), inf.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+            del pts, k
+            return b
+        t0 = time.time()
+        self.h_query = mk_bases(czk.CZK_G1, D - 1, 1)             # groth16/src/generator.rs:156-163
+        self.l_query = mk_bases(czk.CZK_G1, N, 2)
+        self.a_query = mk_bases(czk.CZK_G1, N + 1, 3)             # a_query[1..]
+        self.b_g1_query = mk_bases(czk.CZK_G1, N + 1, 4, True)
+        self.b_g2_query = mk_bases(czk.CZK_G2, N + 1, 5, True)
+        self.setup_key_s = time.time() - t0
+
+        # ---- squaring circuit witness (proof.rs:304-344) and its additive shares ---------------------------
+        w = [rand_fr_canonical(seed, 1)[0]]
+        w0 = sum(int(w[0][j]) << (64 * j) for j in range(4))
+        chain = [w0]
+        for _ in range(N):
+            chain.append(chain[-1] * chain[-1] % R_MOD)
+        wm = to_mont_limbs(chain)                                  # w_0 .. w_N (w_N = public output)
+        one = to_mont_limbs([1])[0]
+        # additive sharing on the GPU: parties 0..P-2 uniform, last = value - sum (share/spdz.rs:150-162)
+        wd = torch.from_numpy(wm.view(np.int64)).to(dev)
+        sh = []
+        rest = wd.clone()
+        for p in range(parties - 1):
+            r = torch.from_numpy(rand_fr_canonical(seed + 17 * (p + 1), N + 1).view(np.int64)).to(dev)
+            rm = torch.empty_like(r)
+            ctx.fr_from_repr(r.data_ptr(), out=rm.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+            ctx.fr_vec_op(1, rest.data_ptr(), rm.data_ptr(), out=rest.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+            sh.append(rm)
+        sh.append(rest)
+        ctx.sync()
+        one_t = torch.from_numpy(one.view(np.int64)).to(dev)
+
+        def lanes_buf():
+            return torch.zeros((L, D, 4), dtype=torch.int64, device=dev)
+        # a_i = b_i = w_i, c_i = w_{i+1} for i < N; a[N] = 1 (king only: Public lifted per SURVEY a18), a[N+1] = out
+        self.a0, self.b0, self.c0 = lanes_buf(), lanes_buf(), lanes_buf()
+        self.wit = torch.zeros((L, N, 4), dtype=torch.int64, device=dev)          # l-MSM scalars: witness
+        self.asg = torch.zeros((L, N + 1, 4), dtype=torch.int64, device=dev)      # a/b-MSM scalars: [out, witness]
+        for p in range(parties):
+            for m in range(2):                                     # mac lane = sh * mac(), mac() = 1 (spdz.rs:41-47)
+                ln = 2 * p + m
+                self.a0[ln, :N] = sh[p][:N]
+                self.b0[ln, :N] = sh[p][:N]
+                self.c0[ln, :N] = sh[p][1:N + 1]
+                if p == 0:
+                    self.a0[ln, N] = one_t
+                self.a0[ln, N + 1] = sh[p][N]
+                self.wit[ln] = sh[p][:N]
+                self.asg[ln, 0] = sh[p][N]
+                self.asg[ln, 1:] = sh[p][:N]
+        # dummy Beaver triples (wire/field.rs:41-60): king holds (1,1,1), everyone else (0,0,0)
+        self.tx, self.ty, self.tz = lanes_buf(), lanes_buf(), lanes_buf()
+        for t in (self.tx, self.ty, self.tz):
+            t[0, :] = one_t
+            t[1, :] = one_t
+        self.a, self.b, self.c = lanes_buf(), lanes_buf(), lanes_buf()
+        self.sx, self.oy = (torch.zeros((D, 4), dtype=torch.int64, device=dev) for _ in range(2))
+        self.chk = torch.zeros((2, D, 4), dtype=torch.int64, device=dev)
+        self.ab = lanes_buf()
+        self.results = {}
+
+    # one open of a 4-lane share vector: value = sum of sh lanes; MAC check vector = mac_share*value - sum(mac lanes)
+    def _open(self, shares, out, chk):
+        czk, ctx, D = self.czk, self.ctx, self.D
+        ADD, SUB = 0, 1
+        M = czk.CZK_MEM_DEVICE
+        ctx.fr_vec_op(ADD, shares[0].data_ptr(), shares[2].data_ptr(), out=out.data_ptr(), n=D, mem=M)
+        for p in range(2, self.P):
+            ctx.fr_vec_op(ADD, out.data_ptr(), shares[2 * p].data_ptr(), out=out.data_ptr(), n=D, mem=M)
+        ctx.fr_vec_op(SUB, out.data_ptr(), shares[1].data_ptr(), out=chk.data_ptr(), n=D, mem=M)
+        for p in range(1, self.P):
+            ctx.fr_vec_op(SUB, chk.data_ptr(), shares[2 * p + 1].data_ptr(), out=chk.data_ptr(), n=D, mem=M)
+
+    def step(self):
+        czk, ctx = self.czk, self.ctx
+        D, N, L, ld = self.D, self.N, self.lanes, self.log_d
+        M = czk.CZK_MEM_DEVICE
+        ADD = 0
+        self.a.copy_(self.a0); self.b.copy_(self.b0); self.c.copy_(self.c0)   # fresh inputs (in-place transforms)
+        # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
+        ctx.witness_map_pre(self.a.data_ptr(), self.b.data_ptr(), ld, L)       # ifft, ifft, coset_fft, coset_fft
+        # batch_product_in_place -> S::batch_mul (share/field.rs:97-127): (s + x), (o + y), two opens, combine
+        ctx.fr_vec_op(ADD, self.a.data_ptr(), self.tx.data_ptr(), out=self.a.data_ptr(), n=L * D, mem=M)
+        ctx.fr_vec_op(ADD, self.b.data_ptr(), self.ty.data_ptr(), out=self.b.data_ptr(), n=L * D, mem=M)
+        self._open(self.a, self.sx, self.chk[0])
+        self._open(self.b, self.oy, self.chk[1])
+        for ln in range(L):
+            ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
+                                  self.oy.data_ptr(), ln < 2, out=self.ab[ln].data_ptr(), n=D, mem=M)
+        ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L)     # h = ab
+        # --- create_proof MSMs (prover.rs:104-156), every share lane -----------------------------------------
+        MONT = czk.CZK_SCALAR_MONTGOMERY
+        r = self.results
+        r["h"] = ctx.msm(self.h_query, self.ab.data_ptr(), n_scalars=D, lanes=L, scalar_form=MONT, mem=M)
+        r["l"] = ctx.msm(self.l_query, self.wit.data_ptr(), n_scalars=N, lanes=L, scalar_form=MONT, mem=M)
+        r["a"] = ctx.msm(self.a_query, self.asg.data_ptr(), n_scalars=N + 1, lanes=L, scalar_form=MONT, mem=M)
+        r["b_g1"] = ctx.msm(self.b_g1_query, self.asg.data_ptr(), n_scalars=N + 1, lanes=L, scalar_form=MONT, mem=M)
+        r["b_g2"] = ctx.msm(self.b_g2_query, self.asg.data_ptr(), n_scalars=N + 1, lanes=L, scalar_form=MONT, mem=M)
+
+    def g1_accumulate_algorithmic_bytes(self):
+        """an MSM of n points moves n*(96 B base) once + n*32 B of scalars per lane."""
+        tot = 0
+        for n in (self.D - 1, self.N, self.N + 1, self.N + 1):
+            tot += n * 96 + self.lanes * n * 32
+        return tot, 4   # bytes per step, launches per step
+
+
+def cpu_baseline(log_n_sample: int, log_n_full: int, parties: int):
+    """Times the CPU checker (oracle/libczk_oracle.so: limb-exact C restatement of the reference algorithms,
+    same Pippenger window rule, same io/oi FFT, single thread like the reference's build) on ONE proof's local
+    compute for all share lanes at N = 2^log_n_sample, then scales linearly in N (the reference's own data is
+    linear in N: SURVEY.md section 6)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+    from util import rand_fr_canonical
+    N = 1 << log_n_sample
+    log_d = (N + 1).bit_length()
+    D = 1 << log_d
+    lanes = 2 * parties
+    # bases: cheap on-curve points for timing: multiples of the generator by small increments via the checker
+    from pyref import G1_GEN, G2_GEN, fq_to_mont
+    g1 = orc.ints_to_limbs([fq_to_mont(G1_GEN[0]), fq_to_mont(G1_GEN[1])], 6).reshape(-1)
+    g2 = orc.ints_to_limbs([fq_to_mont(G2_GEN[0][0]), fq_to_mont(G2_GEN[0][1]), fq_to_mont(G2_GEN[1][0]),
+                            fq_to_mont(G2_GEN[1][1])], 6).reshape(-1)
+
+    def chain(g, gen, n):   # P_{i+1} = 2 P_i + G: distinct subgroup points, O(n) group ops
+        pts = np.zeros((n, gen.size), dtype=np.uint64)
+        jac = np.concatenate([gen, orc.fq_from_repr(orc.ints_to_limbs([1], 6)).reshape(-1) if g == 1 else
+                              np.concatenate([orc.fq_from_repr(orc.ints_to_limbs([1], 6)).reshape(-1), np.zeros(6, np.uint64)])])
+        for i in range(n):
+            aff, _ = orc.jac_to_affine(g, jac)
+            pts[i] = aff
+            jac = orc.jac_add_mixed(g, orc.jac_double(g, jac), gen)
+        return pts
+    nb = D
+    b1 = chain(1, g1, nb)
+    b2 = chain(2, g2, N + 1)
+    inf = np.zeros(nb, dtype=np.uint8)
+    x = orc.fr_from_repr(rand_fr_canonical(5, D))
+    t0 = time.perf_counter()
+    for _ in range(lanes):
+        a, b = orc.witness_map_pre(x, x, log_d)
+        ab = orc.fr_mul(a, b)                      # stands in for the Beaver local half (same op count order)
+        h = orc.witness_map_post(ab, x, log_d)
+        orc.multi_scalar_mul(1, b1[:D - 1], inf, h)
+        orc.multi_scalar_mul(1, b1[:N], inf, x[:N])
+        orc.multi_scalar_mul(1, b1[:N + 1], inf, x[:N + 1])
+        orc.multi_scalar_mul(1, b1[:N + 1], inf, x[:N + 1])
+        orc.multi_scalar_mul(2, b2[:N + 1], inf, x[:N + 1])
+    dt = time.perf_counter() - t0
+    scale = _ref_work(log_n_full) / _ref_work(log_n_sample)
+    return {"value": 1.0 / (dt * scale), "unit": "proofs/s", "cores": 1, "kind": "port",
+            "sample": f"oracle C restatement, 1 thread: full local compute of one proof ({lanes} share lanes: witness map + 5 MSMs each) "
+                      f"at 2^{log_n_sample} constraints took {dt:.2f} s; scaled x{scale:.1f} to 2^{log_n_full} by the reference algorithm's "
+                      f"field-multiplication count (Pippenger windows shrink with N, so this is below the linear x{1 << (log_n_full - log_n_sample)})"}
+
+
+def _ref_work(log_n: int) -> float:
+    """Fq-multiplication-equivalents of the REFERENCE algorithm for one share lane at N = 2^log_n constraints:
+    Pippenger with c = ceil(log2 n)*69/100 + 2 (variable_base.rs:21-25): ceil(253/c) windows x (n mixed adds (11 M) +
+    2*(2^c - 1) full adds (16 M)); G2 costs 3x; 7 NTTs of D log2(D)/2 Fr multiplications (one Fr mul ~ 0.45 Fq mul)."""
+    N = 1 << log_n
+    D = 1 << (N + 1).bit_length()
+
+    def msm(n, g2=False):
+        lg = (n - 1).bit_length() if n & (n - 1) else n.bit_length() - 1
+        c = 3 if n < 32 else lg * 69 // 100 + 2
+        w = -(-253 // c)
+        return w * (n * 11 + 2 * ((1 << c) - 1) * 16) * (3 if g2 else 1)
+    ntt = 7 * D * (D.bit_length() - 1) / 2 * 0.45
+    return msm(D - 1) + msm(N) + 2 * msm(N + 1) + msm(N + 1, True) + ntt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--log-n", type=int, default=20, help="log2(constraints); BASELINE config = 20")
+    ap.add_argument("--parties", type=int, default=2)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=13)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import czk_amd as czk
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = czk.Context(local_rank, stream)
+    prover = Groth16Local(czk, ctx, args.log_n, args.parties)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        prover.step()
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        prover.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # MAC-check vectors of the two opens must be all zero (share/spdz.rs:176-183)
+    assert not bool(prover.chk.any().item()), "SPDZ MAC check failed"
+
+    acc_ms, acc_n = ctx.profile_read("msm_accumulate_g1")
+    breakdown = {k: ctx.profile_read(k)[0] / max(1, args.steps) for k in
+                 ("ntt_pass", "msm_sort", "msm_accumulate_g1", "msm_accumulate_g2", "msm_reduce")}
+    alg_bytes, launches = prover.g1_accumulate_algorithmic_bytes()
+    achieved = (alg_bytes * args.steps) / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("msm_accumulate_g1_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "collaborative Groth16 proofs/sec (BLS12-377, 2^20 constraints, SPDZ N=2)",
+        "value": world * args.steps / dt,
+        "unit": "proofs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"Groth16 SPDZ {args.parties} parties, BLS12-377, 2^{args.log_n} constraints (squaring circuit), both parties' "
+                               f"share-local NTT+MSM on one GPU: {7 * 2 * args.parties} Fr NTT lanes of 2^{prover.log_d} + 5 MSMs x "
+                               f"{2 * args.parties} share lanes",
+                   "constraints": 1 << args.log_n, "domain": prover.D, "parties": args.parties, "share_lanes": prover.lanes,
+                   "parallelism": f"{world} independent proofs (one per GPU), no data-path collective"},
+        "roofline": {"bound": "hbm", "kernel": "k_accumulate<Fq> (G1 bucket accumulation)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
+                     "algorithmic_bytes_per_launch": alg_bytes / launches,
+                     "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md"},
+        "breakdown_ms_per_step": breakdown,
+        "setup_key_s": prover.setup_key_s,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, args.log_n, args.parties)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -217,6 +217,18 @@ class Context:
         self._ck(lib().czk_fixed_base_points(self._h, C.c_int(group), _ptr(k), C.c_size_t(n), _ptr(out), C.c_int(mem)))
         return out
 
+    # ---- measurement hooks ------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._ck(lib().czk_profile_enable(self._h, C.c_int(1 if on else 0)))
+
+    def profile_reset(self):
+        self._ck(lib().czk_profile_reset(self._h))
+
+    def profile_read(self, kernel: str):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        self._ck(lib().czk_profile_read(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     # ---- Groth16 witness map (device buffers) ------------------------------------------------------
     def witness_map_pre(self, a_ptr, b_ptr, log_d, lanes):
         self._ck(lib().czk_witness_map_pre(self._h, _ptr(a_ptr), _ptr(b_ptr), C.c_uint(log_d), C.c_size_t(lanes)))

@@ -26,6 +26,42 @@ int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes) {
     return CZK_OK;
 }
 
+static hipEvent_t take_event(czk_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+ProfScope::ProfScope(czk_ctx* c, const char* n) : ctx(c), name(n) {
+    if (!ctx->profiling) return;
+    e0 = take_event(ctx);
+    e1 = take_event(ctx);
+    (void)hipEventRecord(e0, ctx->stream);
+}
+ProfScope::~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->prof[name].pending.emplace_back(e0, e1);
+}
+static void prof_resolve(czk_ctx* ctx) {
+    for (auto& kv : ctx->prof) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                kv.second.ms += ms;
+                kv.second.launches++;
+            }
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
 template <class F>
 static void limbs_to_field(const u64* p, F& out);
 template <>
@@ -107,6 +143,8 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
     if (ctx->stage.p) (void)hipFree(ctx->stage.p);
     if (ctx->msm_ws.p) (void)hipFree(ctx->msm_ws.p);
+    prof_resolve(ctx);
+    for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -114,6 +152,28 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
 extern "C" int czk_ctx_sync(czk_ctx* ctx) {
     if (!ctx) return CZK_ERR_ARG;
     CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CZK_OK;
+}
+
+extern "C" int czk_profile_enable(czk_ctx* ctx, int on) {
+    if (!ctx) return CZK_ERR_ARG;
+    ctx->profiling = on != 0;
+    return CZK_OK;
+}
+extern "C" int czk_profile_reset(czk_ctx* ctx) {
+    if (!ctx) return CZK_ERR_ARG;
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    ctx->prof.clear();
+    return CZK_OK;
+}
+extern "C" int czk_profile_read(czk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches) {
+    if (!ctx || !kernel) return CZK_ERR_ARG;
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    prof_resolve(ctx);
+    auto it = ctx->prof.find(kernel);
+    if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
     return CZK_OK;
 }
 

@@ -39,7 +39,18 @@ struct DeviceBuf {
 
 }  // namespace czk
 
+namespace czk {
+struct ProfEntry {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0;
+    uint64_t launches = 0;
+};
+}  // namespace czk
+
 struct czk_ctx {
+    bool profiling = false;
+    std::map<std::string, czk::ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -66,6 +77,15 @@ namespace czk {
 int set_err(czk_ctx* ctx, int code, const std::string& msg);
 int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes);
 int get_domain(czk_ctx* ctx, unsigned log_d, DomainTables** out);
+
+// RAII bracket: records an event pair around the launches issued in its scope (no-op unless profiling)
+struct ProfScope {
+    czk_ctx* ctx;
+    const char* name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(czk_ctx* c, const char* n);
+    ~ProfScope();
+};
 
 #define CZK_HIP(ctx, call)                                                                              \
     do {                                                                                                \

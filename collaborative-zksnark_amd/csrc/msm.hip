@@ -332,6 +332,8 @@ static int msm_impl(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t
     for (int i = 0; i < 4; i++) lv[i] = bump.take<u64>(lanes * lvl0 * JW);
     u64* result = bump.take<u64>(lanes * JW);
 
+    {
+    ProfScope ps(ctx, "msm_sort");
     CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ctx->stream));
     if (size) {
         hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, scalars, n_scalars, size,
@@ -342,9 +344,14 @@ static int msm_impl(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t
         hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, digits, size,
                            W, b->n, offsets, counts, B, sorted);
     }
-    if (GT<F>::AW == 12) launch_accumulate_g1(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
-    else launch_accumulate_g2(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
+    }
+    {
+        ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2");
+        if (GT<F>::AW == 12) launch_accumulate_g1(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
+        else launch_accumulate_g2(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
+    }
     CZK_HIP(ctx, hipGetLastError());
+    ProfScope ps_reduce(ctx, "msm_reduce");
 
     // multi-level reduction
     const u64 *P = buckets, *E = nullptr;

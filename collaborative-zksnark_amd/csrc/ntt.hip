@@ -381,6 +381,7 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
         a.post_mode = 0;
         a.in = first ? data : scratch;
         a.out = last ? data : scratch;
+        ProfScope ps(ctx, "ntt_pass");
         if (!last) {
             a.logT = a.s_lo < 4 ? a.s_lo : 4;
             unsigned blocks = (unsigned)(D >> (a.K + a.logT));

@@ -140,6 +140,14 @@ int czk_fixed_base_points(czk_ctx* ctx, int group, const uint64_t* k, size_t n, 
 int czk_witness_map_pre(czk_ctx* ctx, uint64_t* a, uint64_t* b, unsigned log_d, size_t lanes);
 int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, unsigned log_d, size_t lanes);
 
+/* ---- measurement hooks --------------------------------------------------------------------------- */
+/* When enabled, the library brackets its kernel launches with HIP events on the context's stream (the stream the
+ * kernels run on) and accumulates per-kernel elapsed time.  Names: "msm_accumulate_g1", "msm_accumulate_g2",
+ * "msm_sort", "msm_reduce", "ntt_pass", "pointwise".  czk_profile_read synchronises the stream. */
+int czk_profile_enable(czk_ctx* ctx, int on);
+int czk_profile_reset(czk_ctx* ctx);
+int czk_profile_read(czk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif
