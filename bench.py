@@ -156,11 +156,16 @@ class Groth16Local:
         # --- create_proof MSMs (prover.rs:104-156), every share lane -----------------------------------------
         MONT = czk.CZK_SCALAR_MONTGOMERY
         r = self.results
-        r["h"] = ctx.msm(self.h_query, self.ab.data_ptr(), n_scalars=D, lanes=L, scalar_form=MONT, mem=M)
-        r["l"] = ctx.msm(self.l_query, self.wit.data_ptr(), n_scalars=N, lanes=L, scalar_form=MONT, mem=M)
-        r["a"] = ctx.msm(self.a_query, self.asg.data_ptr(), n_scalars=N + 1, lanes=L, scalar_form=MONT, mem=M)
-        r["b_g1"] = ctx.msm(self.b_g1_query, self.asg.data_ptr(), n_scalars=N + 1, lanes=L, scalar_form=MONT, mem=M)
-        r["b_g2"] = ctx.msm(self.b_g2_query, self.asg.data_ptr(), n_scalars=N + 1, lanes=L, scalar_form=MONT, mem=M)
+        for k in ("h", "l", "a", "b_g1"):
+            r.setdefault(k, np.zeros((L, 18), dtype=np.uint64))
+        r.setdefault("b_g2", np.zeros((L, 36), dtype=np.uint64))
+        # enqueue-only: the five MSMs pipeline on the context's internal streams; results are valid after sync()
+        ctx.msm_async(self.b_g2_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g2"])
+        ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"])
+        ctx.msm_async(self.l_query, self.wit.data_ptr(), N, L, MONT, r["l"])
+        ctx.msm_async(self.a_query, self.asg.data_ptr(), N + 1, L, MONT, r["a"])
+        ctx.msm_async(self.b_g1_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g1"])
+        ctx.sync()
 
     def g1_accumulate_algorithmic_bytes(self):
         """an MSM of n points moves n*(96 B base) once + n*32 B of scalars per lane."""

@@ -188,6 +188,12 @@ class Context:
                                C.c_int(mem), _ptr(out)))
         return out
 
+    def msm_async(self, bases: "Bases", scalars_ptr, n_scalars: int, lanes: int, scalar_form: int, out: np.ndarray):
+        """czk_msm_async on device scalars; `out` (numpy, lanes x 18|36) is valid after sync()."""
+        self._ck(lib().czk_msm_async(self._h, bases._h, _ptr(scalars_ptr), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
+                                     C.c_int(CZK_MEM_DEVICE), _ptr(out)))
+        return out
+
     def msm_oneshot(self, group, bases, inf, scalars, lanes=1, scalar_form=CZK_SCALAR_CANONICAL):
         aw, jw = (12, 18) if group == CZK_G1 else (24, 36)
         bases = np.ascontiguousarray(bases, np.uint64)

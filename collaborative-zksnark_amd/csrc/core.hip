@@ -36,15 +36,15 @@ static hipEvent_t take_event(czk_ctx* ctx) {
     (void)hipEventCreate(&e);
     return e;
 }
-ProfScope::ProfScope(czk_ctx* c, const char* n) : ctx(c), name(n) {
+ProfScope::ProfScope(czk_ctx* c, const char* n, hipStream_t s) : ctx(c), name(n), st(s ? s : c->stream) {
     if (!ctx->profiling) return;
     e0 = take_event(ctx);
     e1 = take_event(ctx);
-    (void)hipEventRecord(e0, ctx->stream);
+    (void)hipEventRecord(e0, st);
 }
 ProfScope::~ProfScope() {
     if (!e0) return;
-    (void)hipEventRecord(e1, ctx->stream);
+    (void)hipEventRecord(e1, st);
     ctx->prof[name].pending.emplace_back(e0, e1);
 }
 static void prof_resolve(czk_ctx* ctx) {
@@ -143,6 +143,7 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
     if (ctx->stage.p) (void)hipFree(ctx->stage.p);
     if (ctx->msm_ws.p) (void)hipFree(ctx->msm_ws.p);
+    msm_pipeline_destroy(ctx);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -152,7 +153,7 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
 extern "C" int czk_ctx_sync(czk_ctx* ctx) {
     if (!ctx) return CZK_ERR_ARG;
     CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return CZK_OK;
+    return msm_pipeline_sync(ctx);   // also delivers the results of czk_msm_async calls
 }
 
 extern "C" int czk_profile_enable(czk_ctx* ctx, int on) {
@@ -163,6 +164,7 @@ extern "C" int czk_profile_enable(czk_ctx* ctx, int on) {
 extern "C" int czk_profile_reset(czk_ctx* ctx) {
     if (!ctx) return CZK_ERR_ARG;
     CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CZK_TRY(msm_pipeline_sync(ctx));
     prof_resolve(ctx);
     ctx->prof.clear();
     return CZK_OK;
@@ -170,6 +172,7 @@ extern "C" int czk_profile_reset(czk_ctx* ctx) {
 extern "C" int czk_profile_read(czk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches) {
     if (!ctx || !kernel) return CZK_ERR_ARG;
     CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CZK_TRY(msm_pipeline_sync(ctx));
     prof_resolve(ctx);
     auto it = ctx->prof.find(kernel);
     if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;

@@ -32,11 +32,6 @@ struct GT<Fq2> {
     static constexpr int AW = 24, JW = 36, FW = 12;
 };
 
-struct DeviceBuf {
-    void* p = nullptr;
-    size_t bytes = 0;
-};
-
 }  // namespace czk
 
 namespace czk {
@@ -47,7 +42,32 @@ struct ProfEntry {
 };
 }  // namespace czk
 
+namespace czk {
+struct DeviceBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+struct MsmSlot {
+    DeviceBuf ws_sort, ws_red;
+    hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_red = nullptr;
+    bool used = false;
+};
+struct MsmPending {
+    const char* src;
+    void* dst;
+    size_t bytes;
+};
+}  // namespace czk
+
 struct czk_ctx {
+    // MSM pipeline (msm.hip)
+    hipStream_t s_sort = nullptr, s_acc = nullptr, s_red = nullptr;
+    hipEvent_t ev_in = nullptr;
+    czk::MsmSlot msm_slots[2];
+    int msm_next_slot = 0;
+    char* msm_pinned = nullptr;
+    size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
+    std::vector<czk::MsmPending> msm_pending;
     bool profiling = false;
     std::map<std::string, czk::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
@@ -82,8 +102,9 @@ int get_domain(czk_ctx* ctx, unsigned log_d, DomainTables** out);
 struct ProfScope {
     czk_ctx* ctx;
     const char* name;
+    hipStream_t st;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    ProfScope(czk_ctx* c, const char* n);
+    ProfScope(czk_ctx* c, const char* n, hipStream_t s = nullptr);
     ~ProfScope();
 };
 
@@ -104,12 +125,15 @@ struct ProfScope {
 int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len);
 // implemented in msm.hip
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
-               int scalar_form, u64* out_jac_host);
+               int scalar_form, u64* out_jac_host, bool blocking);
+int msm_pipeline_init(czk_ctx* ctx);
+int msm_pipeline_sync(czk_ctx* ctx);
+void msm_pipeline_destroy(czk_ctx* ctx);
 int fixed_base_points_device(czk_ctx* ctx, int group, const u64* k_dev, size_t n, u64* out_dev);
 // implemented in msm_acc_g1.hip / msm_acc_g2.hip (hot kernels, built with the multiply inlined)
-void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);
-void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);
 
 }  // namespace czk

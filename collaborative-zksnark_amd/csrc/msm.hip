@@ -21,6 +21,8 @@
 //     sum, applied per chunk, with the chunk offsets folded in at the next level).
 //   * `lanes` scalar vectors that share the bases (SPDZ sh / mac lanes) ride on gridDim.y.
 // All arithmetic is 32-bit-limb integer VALU (field.h); nothing here is MFMA-shaped.
+#include <string.h>
+
 #include "czk_internal.h"
 
 namespace czk {
@@ -209,6 +211,60 @@ __global__ void k_scatter(const u32* digits, size_t size, unsigned W, size_t n_b
 }
 
 // ------------------------------------------------------------------------------------------------
+// load balancing: order the buckets by population (descending) so the 64 lanes of a wave fold the same number
+// of points (bucket sizes are ~Poisson: without this a wave waits for its fullest bucket, ~30% of the time)
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned CNT_BINS = 2048;
+__global__ __launch_bounds__(1024) void k_count_hist(const u32* counts, size_t B, u32* hist) {
+    __shared__ u32 h[CNT_BINS];   // block-private histogram: populations cluster on a few values
+    for (unsigned i = threadIdx.x; i < CNT_BINS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        u32 c = counts[(size_t)blockIdx.y * B + b];
+        atomicAdd(&h[c < CNT_BINS ? c : CNT_BINS - 1], 1u);
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < CNT_BINS; i += blockDim.x)
+        if (h[i]) atomicAdd(&hist[(size_t)blockIdx.y * CNT_BINS + i], h[i]);
+}
+// start[v] = number of buckets with a larger population; one block of CNT_BINS/2 threads per lane
+__global__ __launch_bounds__(1024) void k_count_starts(u32* hist) {
+    __shared__ u32 part[CNT_BINS];
+    u32* h = hist + (size_t)blockIdx.x * CNT_BINS;
+    const unsigned tid = threadIdx.x;
+    for (unsigned i = tid; i < CNT_BINS; i += blockDim.x) part[i] = h[CNT_BINS - 1 - i];   // reversed: descending order
+    __syncthreads();
+    if (tid == 0) {
+        u32 run = 0;
+        for (unsigned i = 0; i < CNT_BINS; i++) {
+            u32 c = part[i];
+            part[i] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (unsigned i = tid; i < CNT_BINS; i += blockDim.x) h[CNT_BINS - 1 - i] = part[i];
+}
+__global__ __launch_bounds__(1024) void k_count_scatter(const u32* counts, size_t B, u32* starts, u32* perm) {
+    __shared__ u32 h[CNT_BINS], base[CNT_BINS];
+    for (unsigned i = threadIdx.x; i < CNT_BINS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 bin = 0, rank = 0;
+    if (b < B) {
+        u32 c = counts[(size_t)blockIdx.y * B + b];
+        bin = c < CNT_BINS ? c : CNT_BINS - 1;
+        rank = atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < CNT_BINS; i += blockDim.x)
+        if (h[i]) base[i] = atomicAdd(&starts[(size_t)blockIdx.y * CNT_BINS + i], h[i]);
+    __syncthreads();
+    if (b < B) perm[(size_t)blockIdx.y * B + base[bin] + rank] = (u32)b;
+}
+
+// ------------------------------------------------------------------------------------------------
 // bucket reduction: total = sum_j j * P_j + sum_j E_j over a segment; one level shrinks it by L.
 //   P_out[m] = sum_{t in chunk m} P[t]
 //   E_out[m] = sum_{t in chunk m} E[t] + 2^scale_dbl * sum_{t in chunk m} (t - start_m) * P[t]
@@ -309,77 +365,170 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
     return CZK_OK;
 }
 
+// Enqueue one MSM on the context's three-stage pipeline:
+//   s_sort : digits -> histogram -> offsets -> scatter -> population order          (memory / atomics bound)
+//   s_acc  : bucket accumulation                                                     (integer-VALU bound, fills the chip)
+//   s_red  : multi-level bucket reduction + result copy                              (latency bound, few waves)
+// Consecutive MSMs overlap stage-wise (sort of k+1 and reduce of k-1 hide under accumulate of k); two workspace
+// slots alternate, guarded by events.  Results land in a pinned staging area and are handed to the caller's
+// buffer by msm_collect() after the streams are synchronised.
 template <class F>
-static int msm_impl(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host) {
+static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host) {
     constexpr int JW = GT<F>::JW;
     const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
     const unsigned c = b->c, W = b->W;
     const size_t B = (size_t)1 << (c - 1);
     const unsigned L = 8, logL = 3;
     if ((size_t)W * b->n >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
+    CZK_TRY(msm_pipeline_init(ctx));
+    MsmSlot& slot = ctx->msm_slots[ctx->msm_next_slot];
+    ctx->msm_next_slot ^= 1;
 
-    // workspace
+    // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
-    size_t need = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 2 + B * JW * 8 + 4 * lvl0 * JW * 8 + JW * 8) + (1 << 16);
-    CZK_TRY(ensure_buf(ctx, ctx->msm_ws, need));
-    Bump bump{(char*)ctx->msm_ws.p};
-    u32* digits = bump.take<u32>(lanes * W * size);
-    u32* sorted = bump.take<u32>(lanes * W * size);
-    u32* counts = bump.take<u32>(lanes * B);
-    u32* offsets = bump.take<u32>(lanes * B);
-    u64* buckets = bump.take<u64>(lanes * B * JW);
+    size_t need_sort = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 3 + CNT_BINS * 4) + (1 << 16);
+    size_t need_red = lanes * (B * JW * 8 + 4 * lvl0 * JW * 8 + JW * 8) + (1 << 16);
+    if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
+        CZK_TRY(msm_pipeline_sync(ctx));
+        CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
+        CZK_TRY(ensure_buf(ctx, slot.ws_red, need_red));
+    }
+    Bump bs{(char*)slot.ws_sort.p};
+    u32* digits = bs.take<u32>(lanes * W * size);
+    u32* sorted = bs.take<u32>(lanes * W * size);
+    u32* counts = bs.take<u32>(lanes * B);
+    u32* offsets = bs.take<u32>(lanes * B);
+    u32* perm = bs.take<u32>(lanes * B);
+    u32* chist = bs.take<u32>(lanes * CNT_BINS);
+    Bump br{(char*)slot.ws_red.p};
+    u64* buckets = br.take<u64>(lanes * B * JW);
     u64* lv[4];
-    for (int i = 0; i < 4; i++) lv[i] = bump.take<u64>(lanes * lvl0 * JW);
-    u64* result = bump.take<u64>(lanes * JW);
+    for (int i = 0; i < 4; i++) lv[i] = br.take<u64>(lanes * lvl0 * JW);
+    u64* result = br.take<u64>(lanes * JW);
 
+    // pinned staging for the result
+    const size_t out_bytes = lanes * JW * 8;
+    if (ctx->msm_pinned_used + out_bytes > ctx->msm_pinned_bytes) {
+        CZK_TRY(msm_pipeline_sync(ctx));   // drains pending results first
+        if (out_bytes > ctx->msm_pinned_bytes) return set_err(ctx, CZK_ERR_SIZE, "too many MSM lanes for the result staging area");
+    }
+    char* pinned = ctx->msm_pinned + ctx->msm_pinned_used;
+    ctx->msm_pinned_used += (out_bytes + 255) & ~(size_t)255;
+
+    hipStream_t ss = ctx->s_sort, sa = ctx->s_acc, sr = ctx->s_red;
+    // inputs (scalars) are produced on the caller's stream
+    CZK_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->stream));
+    CZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_in, 0));
+    if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_acc, 0));   // slot's sort buffers are read by its accumulate
     {
-    ProfScope ps(ctx, "msm_sort");
-    CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ctx->stream));
-    if (size) {
-        hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, scalars, n_scalars, size,
-                           form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, counts, B);
+        ProfScope ps(ctx, "msm_sort", ss);
+        CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
+        if (size) {
+            hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
+                               form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, counts, B);
+        }
+        hipLaunchKernelGGL(k_offsets, dim3((unsigned)lanes), dim3(1024), 0, ss, counts, offsets, B);
+        if (size) {
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, digits, size, W,
+                               b->n, offsets, counts, B, sorted);
+        }
+        CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
+        hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
+        hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
+        hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
     }
-    hipLaunchKernelGGL(k_offsets, dim3((unsigned)lanes), dim3(1024), 0, ctx->stream, counts, offsets, B);
-    if (size) {
-        hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, digits, size,
-                           W, b->n, offsets, counts, B, sorted);
-    }
-    }
+    CZK_HIP(ctx, hipEventRecord(slot.ev_sorted, ss));
+    // the caller's stream may overwrite the scalars once the digits are extracted
+    CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
+    CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
+    if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     {
-        ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2");
-        if (GT<F>::AW == 12) launch_accumulate_g1(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
-        else launch_accumulate_g2(ctx->stream, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes);
+        ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
+        if (GT<F>::AW == 12) launch_accumulate_g1(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+        else launch_accumulate_g2(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     }
     CZK_HIP(ctx, hipGetLastError());
-    ProfScope ps_reduce(ctx, "msm_reduce");
-
-    // multi-level reduction
-    const u64 *P = buckets, *E = nullptr;
-    size_t n_in = B;
-    unsigned level = 0;
-    int flip = 0;
-    while (n_in > 1) {
-        size_t n_out = (n_in + L - 1) / L;
-        u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
-        hipLaunchKernelGGL(k_reduce_level<F>, dim3((unsigned)((n_out + 127) / 128), (unsigned)lanes), dim3(128), 0, ctx->stream, P, E, n_in, L,
-                           level * logL, Po, Eo, n_out);
-        P = Po;
-        E = Eo;
-        n_in = n_out;
-        level++;
-        flip ^= 1;
+    CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
+    CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
+    {
+        ProfScope ps(ctx, "msm_reduce", sr);
+        const u64 *P = buckets, *E = nullptr;
+        size_t n_in = B;
+        unsigned level = 0;
+        int flip = 0;
+        while (n_in > 1) {
+            size_t n_out = (n_in + L - 1) / L;
+            u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
+            hipLaunchKernelGGL(k_reduce_level<F>, dim3((unsigned)((n_out + 127) / 128), (unsigned)lanes), dim3(128), 0, sr, P, E, n_in, L,
+                               level * logL, Po, Eo, n_out);
+            P = Po;
+            E = Eo;
+            n_in = n_out;
+            level++;
+            flip ^= 1;
+        }
+        hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, sr, P, E, lanes, result);
     }
-    hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, ctx->stream, P, E, lanes, result);
     CZK_HIP(ctx, hipGetLastError());
-    CZK_HIP(ctx, hipMemcpyAsync(out_host, result, lanes * JW * 8, hipMemcpyDeviceToHost, ctx->stream));
-    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CZK_HIP(ctx, hipMemcpyAsync(pinned, result, out_bytes, hipMemcpyDeviceToHost, sr));
+    CZK_HIP(ctx, hipEventRecord(slot.ev_red, sr));
+    slot.used = true;
+    ctx->msm_pending.push_back(MsmPending{pinned, out_host, out_bytes});
     return CZK_OK;
 }
 
+int msm_pipeline_init(czk_ctx* ctx) {
+    if (ctx->s_sort) return CZK_OK;
+    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_sort, hipStreamNonBlocking));
+    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_acc, hipStreamNonBlocking));
+    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_red, hipStreamNonBlocking));
+    CZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+    for (auto& s : ctx->msm_slots) {
+        CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_sorted, hipEventDisableTiming));
+        CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_acc, hipEventDisableTiming));
+        CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_red, hipEventDisableTiming));
+    }
+    ctx->msm_pinned_bytes = 1 << 20;
+    CZK_HIP(ctx, hipHostMalloc((void**)&ctx->msm_pinned, ctx->msm_pinned_bytes, hipHostMallocDefault));
+    return CZK_OK;
+}
+
+// wait for every enqueued MSM and deliver the results
+int msm_pipeline_sync(czk_ctx* ctx) {
+    if (!ctx->s_sort) return CZK_OK;
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->s_sort));
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->s_acc));
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->s_red));
+    for (auto& p : ctx->msm_pending) memcpy(p.dst, p.src, p.bytes);
+    ctx->msm_pending.clear();
+    ctx->msm_pinned_used = 0;
+    return CZK_OK;
+}
+
+void msm_pipeline_destroy(czk_ctx* ctx) {
+    if (!ctx->s_sort) return;
+    (void)msm_pipeline_sync(ctx);
+    for (auto& s : ctx->msm_slots) {
+        if (s.ws_sort.p) (void)hipFree(s.ws_sort.p);
+        if (s.ws_red.p) (void)hipFree(s.ws_red.p);
+        (void)hipEventDestroy(s.ev_sorted);
+        (void)hipEventDestroy(s.ev_acc);
+        (void)hipEventDestroy(s.ev_red);
+    }
+    (void)hipEventDestroy(ctx->ev_in);
+    (void)hipHostFree(ctx->msm_pinned);
+    (void)hipStreamDestroy(ctx->s_sort);
+    (void)hipStreamDestroy(ctx->s_acc);
+    (void)hipStreamDestroy(ctx->s_red);
+    ctx->s_sort = nullptr;
+}
+
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes, int scalar_form,
-               u64* out_jac_host) {
-    if (bases->group == CZK_G1) return msm_impl<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host);
-    return msm_impl<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host);
+               u64* out_jac_host, bool blocking) {
+    int rc = bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host)
+                                    : msm_enqueue<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host);
+    if (rc != CZK_OK || !blocking) return rc;
+    return msm_pipeline_sync(ctx);
 }
 
 template <class F>
@@ -465,8 +614,8 @@ extern "C" void czk_bases_release(czk_bases* b) {
 
 extern "C" size_t czk_bases_len(const czk_bases* b) { return b ? b->n : 0; }
 
-extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,
-                       uint64_t* out_jac) {
+static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,
+                      uint64_t* out_jac, bool blocking) {
     if (!ctx || !bases || !out_jac) return ctx ? set_err(ctx, CZK_ERR_ARG, "null msm argument") : CZK_ERR_ARG;
     if (n_scalars && !scalars) return set_err(ctx, CZK_ERR_ARG, "null scalars");
     if (scalar_form != CZK_SCALAR_CANONICAL && scalar_form != CZK_SCALAR_MONTGOMERY) return set_err(ctx, CZK_ERR_ARG, "bad scalar_form");
@@ -483,12 +632,17 @@ extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* sca
         }
         sdev = (const u64*)tmp;
     }
-    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac);
-    if (tmp) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipFree(tmp);
-    }
+    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp != nullptr);
+    if (tmp) (void)hipFree(tmp);
     return rc;
+}
+extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,
+                       uint64_t* out_jac) {
+    return msm_common(ctx, bases, scalars, n_scalars, lanes, scalar_form, mem, out_jac, true);
+}
+extern "C" int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form,
+                             int mem, uint64_t* out_jac) {
+    return msm_common(ctx, bases, scalars, n_scalars, lanes, scalar_form, mem, out_jac, false);
 }
 
 static int msm_oneshot(czk_ctx* ctx, int group, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t lanes,

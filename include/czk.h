@@ -115,6 +115,12 @@ size_t czk_bases_len(const czk_bases* b);
 int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
             int scalar_form, int mem, uint64_t* out_jac);
 
+/* Same, but only enqueues: consecutive calls overlap on the context's internal streams (sort / accumulate / reduce
+ * stages of neighbouring MSMs run concurrently).  `out_jac` (host) is valid after the next czk_ctx_sync().  Device
+ * scalars may be overwritten by later work on the context's stream (the library orders that itself). */
+int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
+                  int scalar_form, int mem, uint64_t* out_jac);
+
 /* One-shot forms with the reference's argument order (bases not kept on the GPU). */
 int czk_msm_g1(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
                size_t lanes, int scalar_form, uint64_t* out_jac);

@@ -89,6 +89,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     jac_store<Fq>(data + 18 * t, acc);
 }
 template <int WPE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_madd2(u64* data, int iters) {
+    size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    Affine<Fq2> p = aff_load<Fq2>(data + 24 * t);
+    Jac<Fq2> acc{p.x, p.y, Fq2::one()};
+    acc = jac_double(acc);
+    for (int i = 0; i < iters; i++) acc = jac_add_mixed(acc, p, false);
+    jac_store<Fq2>(data + 36 * t, acc);
+}
+template <int WPE>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_mul2(u64* data, int iters) {
     size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
     Fq2 a = FieldIO<Fq2>::load(data + 12 * t), b = a;
@@ -116,15 +125,17 @@ int main() {
     for (size_t i = 0; i < h.size(); i++) h[i] = (i * 0x9e3779b97f4a7c15ull) >> 9;
     CK(hipMemcpy(data, h.data(), h.size() * 8, hipMemcpyHostToDevice));
     auto timeit = [&](const char* name, auto launch, double ops_per_thread, size_t nthreads) {
-        launch(4); hipDeviceSynchronize(); hipEventRecord(e0); launch(200); hipEventRecord(e1); hipEventSynchronize(e1);
+        launch(4); hipDeviceSynchronize(); hipEventRecord(e0); launch(100); hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("%-28s %8.3f ms  %8.2f G field-mul-equiv/s\n", name, ms, ops_per_thread * 200 * nthreads / ms / 1e6);
+        printf("%-28s %8.3f ms  %8.2f G field-mul-equiv/s\n", name, ms, ops_per_thread * 100 * nthreads / ms / 1e6);
     };
     timeit("Fr mul (256thr x8/CU)", [&](int it) { hipLaunchKernelGGL(k_mul_fr, dim3(blocks), dim3(threads), 0, 0, data, it); }, 2, n);
     timeit("Fq mul (256thr x8/CU)", [&](int it) { hipLaunchKernelGGL(k_mul<Fq>, dim3(blocks), dim3(threads), 0, 0, data, it); }, 2, n);
     timeit("Fq2 mul (=3 Fq mul)", [&](int it) { hipLaunchKernelGGL(k_mul<Fq2>, dim3(blocks), dim3(threads), 0, 0, data, it); }, 6, n);
     timeit("Fq2 mul wpe2", [&](int it) { hipLaunchKernelGGL(k_mul2<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 6, n);
     timeit("Fq2 mul wpe3", [&](int it) { hipLaunchKernelGGL(k_mul2<3>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 6, n);
+    timeit("G2 madd wpe1", [&](int it) { hipLaunchKernelGGL(k_madd2<1>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 33, n);
+    timeit("G2 madd wpe2", [&](int it) { hipLaunchKernelGGL(k_madd2<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 33, n);
     timeit("G1 madd wpe1", [&](int it) { hipLaunchKernelGGL(k_madd<1>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
     timeit("G1 madd wpe2", [&](int it) { hipLaunchKernelGGL(k_madd<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
     timeit("G1 madd wpe3", [&](int it) { hipLaunchKernelGGL(k_madd<3>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 11, n);
