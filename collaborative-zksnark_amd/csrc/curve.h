@@ -56,17 +56,19 @@ CZK_HD Jac<F> jac_add_mixed(const Jac<F>& p, const Affine<F>& q, bool q_inf) {
     F u2 = f_mul(q.x, z1z1);
     F s2 = f_mul(f_mul(q.y, p.z), z1z1);
     if (p.x == u2 && p.y == s2) return jac_double_rare(p);
+    // order chosen to keep few field elements live (register pressure decides this kernel's speed on gfx950):
+    // Z3 first (retires Z1, Z1Z1), then I, J (retire HH, H), r (retires S2), V (retires X1), X3, Y3.
     F h = f_sub(u2, p.x);
     F hh = f_sqr(h);
+    Jac<F> o;
+    o.z = f_sub(f_sub(f_sqr(f_add(p.z, h)), z1z1), hh);
     F i = f_dbl(f_dbl(hh));
     F j = f_mul(h, i);
     F r = f_dbl(f_sub(s2, p.y));
     F v = f_mul(p.x, i);
-    Jac<F> o;
     o.x = f_sub(f_sub(f_sub(f_sqr(r), j), v), v);
     F yj = f_dbl(f_mul(j, p.y));
     o.y = f_sub(f_mul(f_sub(v, o.x), r), yj);
-    o.z = f_sub(f_sub(f_sqr(f_add(p.z, h)), z1z1), hh);
     return o;
 }
 
@@ -74,6 +76,7 @@ template <class F>
 CZK_HD Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
     if (p.is_zero()) return q;
     if (q.is_zero()) return p;
+    // same register-pressure-aware ordering as jac_add_mixed: every product retires an input as early as possible
     F z1z1 = f_sqr(p.z);
     F z2z2 = f_sqr(q.z);
     F u1 = f_mul(p.x, z2z2);
@@ -82,14 +85,14 @@ CZK_HD Jac<F> jac_add(const Jac<F>& p, const Jac<F>& q) {
     F s2 = f_mul(f_mul(q.y, p.z), z1z1);
     if (u1 == u2 && s1 == s2) return jac_double_rare(p);
     F h = f_sub(u2, u1);
+    Jac<F> o;
+    o.z = f_mul(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2), h);
     F i = f_sqr(f_dbl(h));
     F j = f_mul(h, i);
     F r = f_dbl(f_sub(s2, s1));
     F v = f_mul(u1, i);
-    Jac<F> o;
     o.x = f_sub(f_sub(f_sqr(r), j), f_dbl(v));
     o.y = f_sub(f_mul(r, f_sub(v, o.x)), f_dbl(f_mul(s1, j)));
-    o.z = f_mul(f_sub(f_sub(f_sqr(f_add(p.z, q.z)), z1z1), z2z2), h);
     return o;
 }
 

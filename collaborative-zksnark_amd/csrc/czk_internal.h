@@ -130,6 +130,12 @@ int msm_pipeline_init(czk_ctx* ctx);
 int msm_pipeline_sync(czk_ctx* ctx);
 void msm_pipeline_destroy(czk_ctx* ctx);
 int fixed_base_points_device(czk_ctx* ctx, int group, const u64* k_dev, size_t n, u64* out_dev);
+void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
+                            unsigned lanes);
+void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
+                            unsigned lanes);
+void launch_finish_g1(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
+void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
 // implemented in msm_acc_g1.hip / msm_acc_g2.hip (hot kernels, built with the multiply inlined)
 void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);

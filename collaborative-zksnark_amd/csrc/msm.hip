@@ -169,16 +169,32 @@ __global__ void k_digits(const u64* scalars, size_t n_scalars, size_t size, int 
     }
 }
 
-// exclusive scan of counts[lane][0..B) -> offsets; zeroes counts (reused as scatter cursors). One block per lane.
-__global__ __launch_bounds__(1024) void k_offsets(u32* counts, u32* offsets, size_t B) {
+// exclusive scan of counts[lane][0..B) -> offsets, and zero counts (reused as scatter cursors).  Three phases:
+// per-tile sums (tile = 2048 entries), scan of the tile sums (one block per lane), per-tile exclusive scan.
+constexpr unsigned SCAN_TILE = 2048;
+__global__ __launch_bounds__(256) void k_scan_tile_sums(const u32* counts, size_t B, u32* tile_sums, size_t n_tiles) {
+    __shared__ u32 red[256];
+    const size_t tile = blockIdx.x;
+    const u32* cnt = counts + (size_t)blockIdx.y * B + tile * SCAN_TILE;
+    size_t lim = B - tile * SCAN_TILE < SCAN_TILE ? B - tile * SCAN_TILE : SCAN_TILE;
+    u32 s = 0;
+    for (unsigned i = threadIdx.x; i < lim; i += 256) s += cnt[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (unsigned d = 128; d > 0; d >>= 1) {
+        if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[(size_t)blockIdx.y * n_tiles + tile] = red[0];
+}
+__global__ __launch_bounds__(1024) void k_scan_tiles(u32* tile_sums, size_t n_tiles) {
     __shared__ u32 part[1024];
+    u32* ts = tile_sums + (size_t)blockIdx.x * n_tiles;
     const unsigned tid = threadIdx.x;
-    u32* cnt = counts + (size_t)blockIdx.x * B;
-    u32* off = offsets + (size_t)blockIdx.x * B;
-    size_t per = (B + 1023) / 1024;
-    size_t start = tid * per, end = start + per < B ? start + per : B;
+    size_t per = (n_tiles + 1023) / 1024;
+    size_t start = tid * per, end = start + per < n_tiles ? start + per : n_tiles;
     u32 sum = 0;
-    for (size_t i = start; i < end; i++) sum += cnt[i];
+    for (size_t i = start; i < end; i++) sum += ts[i];
     part[tid] = sum;
     __syncthreads();
     for (unsigned d = 1; d < 1024; d <<= 1) {
@@ -189,10 +205,44 @@ __global__ __launch_bounds__(1024) void k_offsets(u32* counts, u32* offsets, siz
     }
     u32 run = tid ? part[tid - 1] : 0;
     for (size_t i = start; i < end; i++) {
-        u32 cval = cnt[i];
-        off[i] = run;
-        run += cval;
-        cnt[i] = 0;
+        u32 v = ts[i];
+        ts[i] = run;
+        run += v;
+    }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(u32* counts, u32* offsets, size_t B, const u32* tile_sums, size_t n_tiles) {
+    __shared__ u32 part[256];
+    const size_t tile = blockIdx.x;
+    u32* cnt = counts + (size_t)blockIdx.y * B + tile * SCAN_TILE;
+    u32* off = offsets + (size_t)blockIdx.y * B + tile * SCAN_TILE;
+    size_t lim = B - tile * SCAN_TILE < SCAN_TILE ? B - tile * SCAN_TILE : SCAN_TILE;
+    const unsigned tid = threadIdx.x;
+    constexpr unsigned PER = SCAN_TILE / 256;
+    u32 v[PER];
+    u32 s = 0;
+#pragma unroll
+    for (unsigned k = 0; k < PER; k++) {
+        unsigned i = tid * PER + k;
+        v[k] = i < lim ? cnt[i] : 0;
+        s += v[k];
+    }
+    part[tid] = s;
+    __syncthreads();
+    for (unsigned d = 1; d < 256; d <<= 1) {
+        u32 x = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    u32 run = tile_sums[(size_t)blockIdx.y * n_tiles + tile] + (tid ? part[tid - 1] : 0);
+#pragma unroll
+    for (unsigned k = 0; k < PER; k++) {
+        unsigned i = tid * PER + k;
+        if (i < lim) {
+            off[i] = run;
+            cnt[i] = 0;
+        }
+        run += v[k];
     }
 }
 
@@ -262,45 +312,6 @@ __global__ __launch_bounds__(1024) void k_count_scatter(const u32* counts, size_
         if (h[i]) base[i] = atomicAdd(&starts[(size_t)blockIdx.y * CNT_BINS + i], h[i]);
     __syncthreads();
     if (b < B) perm[(size_t)blockIdx.y * B + base[bin] + rank] = (u32)b;
-}
-
-// ------------------------------------------------------------------------------------------------
-// bucket reduction: total = sum_j j * P_j + sum_j E_j over a segment; one level shrinks it by L.
-//   P_out[m] = sum_{t in chunk m} P[t]
-//   E_out[m] = sum_{t in chunk m} E[t] + 2^scale_dbl * sum_{t in chunk m} (t - start_m) * P[t]
-// with 2^scale_dbl = L^level, so that  L^(level+1) * sum_m m P_out[m] + sum_m E_out[m]  is unchanged.
-// ------------------------------------------------------------------------------------------------
-template <class F>
-__global__ __launch_bounds__(128) void k_reduce_level(const u64* P_in, const u64* E_in, size_t n_in, unsigned L, unsigned scale_dbl,
-                                                     u64* P_out, u64* E_out, size_t n_out) {
-    constexpr int JW = GT<F>::JW;
-    size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_out) return;
-    const size_t seg = blockIdx.y;
-    const u64* P = P_in + (size_t)JW * seg * n_in;
-    size_t start = m * L, end = start + L < n_in ? start + L : n_in;
-    Jac<F> running = Jac<F>::zero(), A = Jac<F>::zero();
-    for (size_t t = end; t-- > start;) {
-        running = jac_add(running, jac_load<F>(P + JW * t));
-        if (t > start) A = jac_add(A, running);
-    }
-    for (unsigned k = 0; k < scale_dbl; k++) A = jac_double(A);
-    if (E_in) {
-        const u64* E = E_in + (size_t)JW * seg * n_in;
-        for (size_t t = start; t < end; t++) A = jac_add(A, jac_load<F>(E + JW * t));
-    }
-    jac_store<F>(P_out + (size_t)JW * (seg * n_out + m), running);
-    jac_store<F>(E_out + (size_t)JW * (seg * n_out + m), A);
-}
-
-// out[seg] = P[seg] + E[seg]   (weights are b+1: sum_b (b+1) B_b = sum_b b B_b + sum_b B_b)
-template <class F>
-__global__ void k_finish(const u64* P, const u64* E, size_t segs, u64* out) {
-    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= segs) return;
-    Jac<F> r = jac_load<F>(P + (size_t)GT<F>::JW * s);
-    if (E) r = jac_add(r, jac_load<F>(E + (size_t)GT<F>::JW * s));
-    jac_store<F>(out + (size_t)GT<F>::JW * s, r);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,7 +397,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
-    size_t need_sort = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 3 + CNT_BINS * 4) + (1 << 16);
+    size_t need_sort = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 4 + CNT_BINS * 4) + (1 << 16);
     size_t need_red = lanes * (B * JW * 8 + 4 * lvl0 * JW * 8 + JW * 8) + (1 << 16);
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
         CZK_TRY(msm_pipeline_sync(ctx));
@@ -400,6 +411,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     u32* offsets = bs.take<u32>(lanes * B);
     u32* perm = bs.take<u32>(lanes * B);
     u32* chist = bs.take<u32>(lanes * CNT_BINS);
+    const size_t n_tiles = (B + SCAN_TILE - 1) / SCAN_TILE;
+    u32* tile_sums = bs.take<u32>(lanes * n_tiles);
     Bump br{(char*)slot.ws_red.p};
     u64* buckets = br.take<u64>(lanes * B * JW);
     u64* lv[4];
@@ -427,7 +440,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
                                form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, counts, B);
         }
-        hipLaunchKernelGGL(k_offsets, dim3((unsigned)lanes), dim3(1024), 0, ss, counts, offsets, B);
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, B, tile_sums, n_tiles);
+        hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)lanes), dim3(1024), 0, ss, tile_sums, n_tiles);
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, offsets, B, tile_sums, n_tiles);
         if (size) {
             hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, digits, size, W,
                                b->n, offsets, counts, B, sorted);
@@ -459,15 +474,16 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         while (n_in > 1) {
             size_t n_out = (n_in + L - 1) / L;
             u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
-            hipLaunchKernelGGL(k_reduce_level<F>, dim3((unsigned)((n_out + 127) / 128), (unsigned)lanes), dim3(128), 0, sr, P, E, n_in, L,
-                               level * logL, Po, Eo, n_out);
+            if (GT<F>::AW == 12) launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
+            else launch_reduce_level_g2(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
             P = Po;
             E = Eo;
             n_in = n_out;
             level++;
             flip ^= 1;
         }
-        hipLaunchKernelGGL(k_finish<F>, dim3(1), dim3(64), 0, sr, P, E, lanes, result);
+        if (GT<F>::AW == 12) launch_finish_g1(sr, P, E, lanes, result);
+        else launch_finish_g2(sr, P, E, lanes, result);
     }
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipMemcpyAsync(pinned, result, out_bytes, hipMemcpyDeviceToHost, sr));

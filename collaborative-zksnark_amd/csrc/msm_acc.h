@@ -28,6 +28,45 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     jac_store<F>(buckets + (size_t)GT<F>::JW * ((size_t)lane * B + b), acc);
 }
 
+// ------------------------------------------------------------------------------------------------
+// bucket reduction: total = sum_j j * P_j + sum_j E_j over a segment; one level shrinks it by L.
+//   P_out[m] = sum_{t in chunk m} P[t]
+//   E_out[m] = sum_{t in chunk m} E[t] + 2^scale_dbl * sum_{t in chunk m} (t - start_m) * P[t]
+// with 2^scale_dbl = L^level, so that  L^(level+1) * sum_m m P_out[m] + sum_m E_out[m]  is unchanged.
+// ------------------------------------------------------------------------------------------------
+template <class F, int JW, int SHIFT>   // SHIFT = 1: one chunk per lane pair (F = Fq2P)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level(const u64* P_in, const u64* E_in, size_t n_in, unsigned L, unsigned scale_dbl,
+                                                     u64* P_out, u64* E_out, size_t n_out) {
+    size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> SHIFT;
+    if (m >= n_out) return;
+    const size_t seg = blockIdx.y;
+    const u64* P = P_in + (size_t)JW * seg * n_in;
+    size_t start = m * L, end = start + L < n_in ? start + L : n_in;
+    Jac<F> running = Jac<F>::zero(), A = Jac<F>::zero();
+    for (size_t t = end; t-- > start;) {
+        running = jac_add(running, jac_load<F>(P + JW * t));
+        if (t > start) A = jac_add(A, running);
+    }
+    for (unsigned k = 0; k < scale_dbl; k++) A = jac_double(A);
+    if (E_in) {
+        const u64* E = E_in + (size_t)JW * seg * n_in;
+        for (size_t t = start; t < end; t++) A = jac_add(A, jac_load<F>(E + JW * t));
+    }
+    jac_store<F>(P_out + (size_t)JW * (seg * n_out + m), running);
+    jac_store<F>(E_out + (size_t)JW * (seg * n_out + m), A);
+}
+
+// out[seg] = P[seg] + E[seg]   (weights are b+1: sum_b (b+1) B_b = sum_b b B_b + sum_b B_b)
+template <class F, int JW, int SHIFT>
+__global__ void k_finish(const u64* P, const u64* E, size_t segs, u64* out) {
+    size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> SHIFT;
+    if (s >= segs) return;
+    Jac<F> r = jac_load<F>(P + (size_t)JW * s);
+    if (E) r = jac_add(r, jac_load<F>(E + (size_t)JW * s));
+    jac_store<F>(out + (size_t)JW * s, r);
+}
+
+
 // G2 variant: one bucket per lane PAIR (fq2p.h).  Same algorithm, same memory formats.
 template <class FP>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_pair(
