@@ -252,26 +252,19 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import czk_amd as czk
+    from czk_amd import parallel
+    rank, world, local_rank = parallel.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    import czk_amd as czk
+    parallel.init("nccl")          # RCCL; only the timing reduction uses it (units are independent)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = czk.Context(local_rank, stream)
     prover = Groth16Local(czk, ctx, args.log_n, args.parties)
 
     def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        parallel.barrier(torch.cuda.synchronize)
 
     for _ in range(args.warmup):
         prover.step()
@@ -284,10 +277,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = parallel.max_over_ranks(dt, device="cuda")
 
     # MAC-check vectors of the two opens must be all zero (share/spdz.rs:176-183)
     assert not bool(prover.chk.any().item()), "SPDZ MAC check failed"
@@ -336,7 +326,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
-        dist.destroy_process_group()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -11,3 +11,4 @@ from .binding import (CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT, CZK_MEM_
                       CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY, CZK_G1, CZK_G2, CzkError, Context, Bases, lib,
                       lib_path, exported_symbols, header_symbols)
 from .build import build  # noqa: F401
+from . import parallel  # noqa: F401

@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests (CPU) of the N>1 host logic: unit partitioning, the max-over-ranks timing contract of
+bench.py, and the mpc-net style share exchange of an open."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    from czk_amd import parallel
+    import orc
+    from util import rand_fr_canonical
+    r, w, _ = parallel.init("gloo")
+    assert (r, w) == (rank, world)
+    units = parallel.partition_units(5, world, rank)
+    # each rank "takes" 0.1 s * (rank + 1): the job time is the slowest rank's
+    rate, t = parallel.aggregate_throughput(float(len(units)), 0.1 * (rank + 1))
+    # an SPDZ open: additive shares of a secret vector, one share per party (share/spdz.rs:150-185)
+    n = 64
+    secret = orc.fr_from_repr(rand_fr_canonical(7, n))
+    share0 = orc.fr_from_repr(rand_fr_canonical(8, n))
+    mine = share0 if rank == 0 else orc.fr_sub(secret, share0)
+    gathered = parallel.all_gather_shares(torch.from_numpy(mine.view(np.int64)))
+    total = gathered[0].numpy().view(np.uint64)
+    for k in range(1, world):
+        total = orc.fr_add(total, gathered[k].numpy().view(np.uint64))
+    parallel.barrier()
+    q.put((rank, units, rate, t, bool(np.array_equal(total, secret))))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_partition_timing_and_open():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1, 2] and res[1][1] == [3, 4]          # 5 units over 2 ranks
+    for _, _, rate, t, ok in res:
+        assert ok                                                   # opened value == secret on every party
+        assert abs(t - 0.2) < 1e-9 and abs(rate - 5 / 0.2) < 1e-6   # all units / max-over-ranks time
+
+
+def test_partition_units_covers_everything():
+    sys.path.insert(0, ROOT)
+    from czk_amd import parallel
+    for n in (0, 1, 7, 8, 9):
+        for w in (1, 2, 3, 8):
+            parts = [parallel.partition_units(n, w, r) for r in range(w)]
+            assert sum(parts, []) == list(range(n))
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
