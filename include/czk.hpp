@@ -1,0 +1,257 @@
+// czk.hpp -- C++ host layer over the C ABI (czk.h), mirroring the reference's Rust surface for this path so
+// that calling code reads like the reference's.  Header-only; link with libczk_hip.so.
+//
+//   reference (Rust)                                                         here (C++)
+//   ------------------------------------------------------------------------------------------------------------
+//   ark_poly::EvaluationDomain::new(n) -> Option<Self>                       Radix2EvaluationDomain::create(n) -> std::optional
+//     (algebra/poly/src/domain/radix2/mod.rs:51-82)
+//   domain.{fft,ifft,coset_fft,coset_ifft}_in_place(&mut Vec<T>)             same names, T = Fr or MpcField (share lanes)
+//     (algebra/poly/src/domain/mod.rs:79,90,139,155)
+//   domain.divide_by_vanishing_poly_on_coset_in_place(&mut [F])              same name (domain/mod.rs:184-191)
+//   VariableBaseMSM::multi_scalar_mul(&[G], &[BigInt]) -> G::Projective      VariableBaseMSM::multi_scalar_mul(bases, scalars)
+//     (algebra/ec/src/msm/variable_base.rs:12-15)
+//   AffineCurve::multi_scalar_mul(&[Self], &[Fr]) -> Projective              G1Affine::multi_scalar_mul / G2Affine::multi_scalar_mul
+//     (algebra/ec/src/lib.rs:300-311)
+//   MpcField::{Public, Shared}, SpdzFieldShare{sh, mac}                      MpcField{shared, sh, mac}
+//     (mpc-algebra/src/wire/field.rs:27-30, share/spdz.rs:50-53)
+//   GroupShare::multi_scale_pub_group(bases, &[share]) (SPDZ)                SpdzGroupShare::multi_scale_pub_group
+//     (mpc-algebra/src/share/spdz.rs:440-446)
+//   R1CStoQAP::witness_map (mpc-snarks/src/groth/r1cs_to_qap.rs:47-113)      R1CStoQAP::witness_map(domain, a, b, c, batch_product)
+//
+// Error behaviour: where the reference returns None the mirror returns std::nullopt; where it `assert!`s /
+// `unwrap()`s the mirror throws czk::Panic carrying czk_last_error() (a Rust shim would `expect()` the status).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "czk.h"
+
+namespace czk {
+
+struct Panic : std::runtime_error {
+    int code;
+    Panic(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// Plain-old-data views of the reference's values (little-endian u64 limbs, Montgomery form).
+struct Fr { uint64_t l[4]; };
+struct BigInteger256 { uint64_t l[4]; };
+struct Fq { uint64_t l[6]; };
+struct Fq2 { Fq c0, c1; };
+struct G1Projective { Fq x, y, z; };
+struct G2Projective { Fq2 x, y, z; };
+
+class Context {
+  public:
+    explicit Context(int device = 0, void* hip_stream = nullptr) {
+        int rc = czk_ctx_create(&ctx_, device, hip_stream);
+        if (rc != CZK_OK) throw Panic(rc, "czk_ctx_create failed (no GPU visible? the product path has no CPU fallback)");
+    }
+    ~Context() { czk_ctx_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    czk_ctx* raw() const { return ctx_; }
+    void check(int rc) const {
+        if (rc != CZK_OK) throw Panic(rc, czk_last_error(ctx_));
+    }
+    void sync() const { check(czk_ctx_sync(ctx_)); }
+
+  private:
+    czk_ctx* ctx_ = nullptr;
+};
+
+// mpc-algebra/src/wire/field.rs:27-30 -- MpcField<Fr, SpdzFieldShare<Fr>>: Public(x) or Shared{sh, mac}
+struct MpcField {
+    bool shared = false;
+    Fr sh{};   // Public: the value; Shared: the additive share
+    Fr mac{};  // Shared only: the MAC share (share/spdz.rs:50-53)
+};
+
+// SoA lanes of a share vector.  Public(x) entries are lifted to (king ? x : 0) on BOTH lanes, which is what the
+// reference's `shift` does the first time a public value meets a share (share/spdz.rs:204-208, add.rs:141-146);
+// all butterfly operations are lane-wise linear, so the lifted lanes give the same sh / mac vectors.
+struct ShareLanes {
+    std::vector<Fr> data;   // 2 x D: lane 0 = sh, lane 1 = mac
+    size_t len = 0;
+};
+inline ShareLanes unpack_lanes(const std::vector<MpcField>& v, size_t domain_size, bool am_king) {
+    ShareLanes out;
+    out.len = v.size();
+    out.data.assign(2 * domain_size, Fr{});
+    for (size_t i = 0; i < v.size(); i++) {
+        if (v[i].shared) {
+            out.data[i] = v[i].sh;
+            out.data[domain_size + i] = v[i].mac;
+        } else if (am_king) {
+            out.data[i] = v[i].sh;
+            out.data[domain_size + i] = v[i].sh;
+        }
+    }
+    return out;
+}
+inline void repack_lanes(const ShareLanes& lanes, size_t domain_size, std::vector<MpcField>& v) {
+    v.resize(domain_size);
+    for (size_t i = 0; i < domain_size; i++) {
+        v[i].shared = true;   // Reveal::from_add_shared (mpc-algebra/src/reveal.rs:15-43)
+        v[i].sh = lanes.data[i];
+        v[i].mac = lanes.data[domain_size + i];
+    }
+}
+
+// algebra/poly/src/domain/radix2/mod.rs:23-117
+class Radix2EvaluationDomain {
+  public:
+    // EvaluationDomain::new: None when log2(size) > TWO_ADICITY (radix2/mod.rs:61-63)
+    static std::optional<Radix2EvaluationDomain> create(const Context& ctx, size_t num_coeffs, bool am_king = true) {
+        size_t size = 1;
+        unsigned lg = 0;
+        while (size < num_coeffs) {
+            size <<= 1;
+            lg++;
+        }
+        Radix2EvaluationDomain d(ctx, am_king);
+        d.size_ = size;
+        d.log_size_of_group = lg;
+        uint64_t k[24];
+        if (czk_domain_constants(ctx.raw(), lg, k) != CZK_OK) return std::nullopt;
+        auto cp = [&](Fr& f, int idx) { for (int i = 0; i < 4; i++) f.l[i] = k[4 * idx + i]; };
+        cp(d.size_inv, 0); cp(d.group_gen, 1); cp(d.group_gen_inv, 2); cp(d.generator, 3); cp(d.generator_inv, 4); cp(d.vanishing_inv_, 5);
+        return d;
+    }
+    size_t size() const { return size_; }
+
+    void fft_in_place(std::vector<Fr>& coeffs) const { run(coeffs, CZK_FFT); }
+    void ifft_in_place(std::vector<Fr>& evals) const { run(evals, CZK_IFFT); }
+    void coset_fft_in_place(std::vector<Fr>& coeffs) const { run(coeffs, CZK_COSET_FFT); }
+    void coset_ifft_in_place(std::vector<Fr>& evals) const { run(evals, CZK_COSET_IFFT); }
+    // T = MpcField: two Fr lanes per vector
+    void fft_in_place(std::vector<MpcField>& v) const { run_shared(v, CZK_FFT); }
+    void ifft_in_place(std::vector<MpcField>& v) const { run_shared(v, CZK_IFFT); }
+    void coset_fft_in_place(std::vector<MpcField>& v) const { run_shared(v, CZK_COSET_FFT); }
+    void coset_ifft_in_place(std::vector<MpcField>& v) const { run_shared(v, CZK_COSET_IFFT); }
+
+    // domain/mod.rs:184-191
+    void divide_by_vanishing_poly_on_coset_in_place(std::vector<Fr>& evals) const {
+        ctx_->check(czk_fr_vec_scale(ctx_->raw(), evals[0].l, vanishing_inv_.l, evals[0].l, evals.size(), CZK_MEM_HOST));
+    }
+
+    unsigned log_size_of_group = 0;
+    Fr size_inv{}, group_gen{}, group_gen_inv{}, generator{}, generator_inv{};
+
+  private:
+    Radix2EvaluationDomain(const Context& c, bool king) : ctx_(&c), am_king_(king) {}
+    void run(std::vector<Fr>& v, int kind) const {
+        if (v.size() > size_) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");   // radix2/mod.rs:100
+        size_t in_len = v.size();
+        v.resize(size_, Fr{});                                                                              // :101
+        ctx_->check(czk_ntt_fr(ctx_->raw(), v[0].l, log_size_of_group, 1, kind, in_len, CZK_MEM_HOST));
+    }
+    void run_shared(std::vector<MpcField>& v, int kind) const {
+        if (v.size() > size_) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");
+        ShareLanes lanes = unpack_lanes(v, size_, am_king_);
+        ctx_->check(czk_ntt_fr(ctx_->raw(), lanes.data[0].l, log_size_of_group, 2, kind, lanes.len, CZK_MEM_HOST));
+        repack_lanes(lanes, size_, v);
+    }
+    const Context* ctx_;
+    bool am_king_;
+    size_t size_ = 0;
+    Fr vanishing_inv_{};
+};
+
+// A proving-key query pinned on the GPU (groth16/src/data_structures.rs:132-149).
+template <int GROUP>
+class Bases {
+  public:
+    Bases(const Context& ctx, const uint64_t* xy, const uint8_t* inf, size_t n) : ctx_(&ctx) {
+        ctx.check(czk_bases_register(ctx.raw(), GROUP, xy, inf, n, CZK_MEM_HOST, &b_));
+    }
+    ~Bases() { czk_bases_release(b_); }
+    Bases(const Bases&) = delete;
+    Bases& operator=(const Bases&) = delete;
+    size_t len() const { return czk_bases_len(b_); }
+    czk_bases* raw() const { return b_; }
+    const Context& ctx() const { return *ctx_; }
+
+  private:
+    const Context* ctx_;
+    czk_bases* b_ = nullptr;
+};
+using G1Bases = Bases<CZK_G1>;
+using G2Bases = Bases<CZK_G2>;
+
+// algebra/ec/src/msm/variable_base.rs:12-106
+struct VariableBaseMSM {
+    static G1Projective multi_scalar_mul(const G1Bases& bases, const std::vector<BigInteger256>& scalars) {
+        G1Projective out;
+        bases.ctx().check(czk_msm(bases.ctx().raw(), bases.raw(), scalars.empty() ? nullptr : scalars[0].l, scalars.size(), 1,
+                                  CZK_SCALAR_CANONICAL, CZK_MEM_HOST, out.x.l));
+        return out;
+    }
+    static G2Projective multi_scalar_mul(const G2Bases& bases, const std::vector<BigInteger256>& scalars) {
+        G2Projective out;
+        bases.ctx().check(czk_msm(bases.ctx().raw(), bases.raw(), scalars.empty() ? nullptr : scalars[0].l, scalars.size(), 1,
+                                  CZK_SCALAR_CANONICAL, CZK_MEM_HOST, out.x.c0.l));
+        return out;
+    }
+};
+
+// algebra/ec/src/lib.rs:300-311 -- AffineCurve::multi_scalar_mul: Fr scalars, into_repr on the way in
+struct G1Affine {
+    static G1Projective multi_scalar_mul(const G1Bases& bases, const std::vector<Fr>& scalars) {
+        G1Projective out;
+        bases.ctx().check(czk_msm(bases.ctx().raw(), bases.raw(), scalars.empty() ? nullptr : scalars[0].l, scalars.size(), 1,
+                                  CZK_SCALAR_MONTGOMERY, CZK_MEM_HOST, out.x.l));
+        return out;
+    }
+};
+struct G2Affine {
+    static G2Projective multi_scalar_mul(const G2Bases& bases, const std::vector<Fr>& scalars) {
+        G2Projective out;
+        bases.ctx().check(czk_msm(bases.ctx().raw(), bases.raw(), scalars.empty() ? nullptr : scalars[0].l, scalars.size(), 1,
+                                  CZK_SCALAR_MONTGOMERY, CZK_MEM_HOST, out.x.c0.l));
+        return out;
+    }
+};
+
+// mpc-algebra/src/share/spdz.rs:440-446 -- SPDZ multi_scale_pub_group: two MSMs over the same bases.
+// Like the reference (line 442 re-reads `.sh.val`), BOTH results are computed from the sh values; they are
+// issued as two lanes of one call so the bases are gathered once.
+struct SpdzGroupShareG1 {
+    G1Projective sh, mac;
+    static SpdzGroupShareG1 multi_scale_pub_group(const G1Bases& bases, const std::vector<MpcField>& scalars) {
+        std::vector<Fr> lanes(2 * scalars.size());
+        for (size_t i = 0; i < scalars.size(); i++) lanes[i] = lanes[scalars.size() + i] = scalars[i].sh;
+        G1Projective out[2];
+        bases.ctx().check(czk_msm(bases.ctx().raw(), bases.raw(), lanes.empty() ? nullptr : lanes[0].l, scalars.size(), 2,
+                                  CZK_SCALAR_MONTGOMERY, CZK_MEM_HOST, out[0].x.l));
+        return SpdzGroupShareG1{out[0], out[1]};
+    }
+};
+
+// mpc-snarks/src/groth/r1cs_to_qap.rs:47-113 -- the NTT / pointwise sequence of witness_map for a single prover
+// (T = Fr).  `a`, `b`, `c` are the evaluated constraint rows (a[0..N), then the instance copy; :67-83, :95-100).
+// `batch_product` is F::batch_product_in_place (:92) -- a plain product here, the Beaver protocol for shares.
+struct R1CStoQAP {
+    static std::vector<Fr> witness_map(const Context& ctx, const Radix2EvaluationDomain& domain, std::vector<Fr> a, std::vector<Fr> b,
+                                       std::vector<Fr> c) {
+        domain.ifft_in_place(a);
+        domain.ifft_in_place(b);
+        domain.coset_fft_in_place(a);
+        domain.coset_fft_in_place(b);
+        std::vector<Fr> ab = a;
+        ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_MUL, ab[0].l, b[0].l, ab[0].l, ab.size(), CZK_MEM_HOST));
+        domain.ifft_in_place(c);
+        domain.coset_fft_in_place(c);
+        ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_SUB, ab[0].l, c[0].l, ab[0].l, ab.size(), CZK_MEM_HOST));
+        domain.divide_by_vanishing_poly_on_coset_in_place(ab);
+        domain.coset_ifft_in_place(ab);
+        return ab;
+    }
+};
+
+}  // namespace czk

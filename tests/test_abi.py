@@ -37,3 +37,28 @@ def test_no_gpu_means_loud_failure():
         czk_amd.Context(0)
     # null-context calls are rejected, not crashed
     assert czk_amd.lib().czk_ntt_fr(None, None, C.c_uint(3), C.c_size_t(1), 0, C.c_size_t(8), 0) == 3
+
+
+def _build_host_demo():
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "tools", "host_demo.bin")
+    pkg = os.path.join(root, "collaborative-zksnark_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "host_demo.cpp"),
+                           "-L" + pkg, "-lczk_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out])
+    return out
+
+
+def test_cpp_host_mirror_compiles_against_the_abi():
+    # include/czk.hpp (the C++ mirror of the reference's EvaluationDomain / VariableBaseMSM / MpcField surface)
+    # must compile with plain g++ against czk.h and link against libczk_hip.so
+    import os
+    assert os.path.exists(_build_host_demo())
+
+
+@pytest.mark.gpu
+def test_cpp_host_mirror_runs_on_gpu():
+    import subprocess
+    out = subprocess.run([_build_host_demo()], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "host_demo OK" in out.stdout, out.stdout + out.stderr
