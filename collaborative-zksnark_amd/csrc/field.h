@@ -283,7 +283,9 @@ CZK_MUL_ATTR Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
     return r;
 }
 
-// square: same value as fp_mul(a, a) (fields/arithmetic.rs:84-170 computes the same residue).
+// square: same value as fp_mul(a, a) (fields/arithmetic.rs:84-170 computes the same residue).  A dedicated
+// squaring (N(N+1)/2 products, off-diagonal part doubled per column) was evaluated and is break-even here: a
+// product costs only 2 instructions (v_mad_u64_u32 + v_addc), and the per-column doubling/merge costs ~6.
 template <class P>
 CZK_HD Fp<P> fp_sqr(const Fp<P>& a) {
     return fp_mul(a, a);

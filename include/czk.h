@@ -128,7 +128,8 @@ int czk_msm_g2(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const
                size_t lanes, int scalar_form, uint64_t* out_jac);
 
 /* From<GroupProjective> for GroupAffine (short_weierstrass_jacobian.rs:768-789): n host Jacobian points ->
- * n host affine points + infinity flags.  This is what AffineMsm::msm's `.into()` does (share/msm.rs:31-37). */
+ * n host affine points + infinity flags.  This is what AffineMsm::msm's `.into()` does (share/msm.rs:31-37).
+ * Host-side arithmetic (one inversion per point); `ctx` may be NULL. */
 int czk_jac_to_affine(czk_ctx* ctx, int group, const uint64_t* jac, size_t n, uint64_t* out_aff, uint8_t* out_inf);
 
 /* Synthetic public bases P_i = [k_i] * generator for i < n, k_i = canonical scalars (n x 4 u64), written as
