@@ -14,6 +14,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <type_traits>
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define CZK_HD __host__ __device__ __forceinline__
@@ -128,10 +130,232 @@ struct alignas(16) Fp {
     CZK_HD bool operator!=(const Fp& b) const { return !(*this == b); }
 };
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---------------------------------------------------------------------------------------------
+// Device add / sub / reduce as explicit carry chains (generated for N = 8 and N = 12).  hipcc lowers the
+// portable u64 carry emulation below to ~100 instructions per operation (64-bit adds, compares, sign
+// extensions); these are 3N: add-with-carry, subtract-with-borrow, select.
+// ---------------------------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ Fp<P> fp_add_asm(const Fp<P>& a, const Fp<P>& b, std::integral_constant<int, 8>) {
+    Fp<P> r;
+    u32 d[8];
+    asm("v_add_co_u32 %0, vcc, %16, %24\n\t"
+            "v_addc_co_u32 %1, vcc, %17, %25, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %18, %26, vcc\n\t"
+            "v_addc_co_u32 %3, vcc, %19, %27, vcc\n\t"
+            "v_addc_co_u32 %4, vcc, %20, %28, vcc\n\t"
+            "v_addc_co_u32 %5, vcc, %21, %29, vcc\n\t"
+            "v_addc_co_u32 %6, vcc, %22, %30, vcc\n\t"
+            "v_addc_co_u32 %7, vcc, %23, %31, vcc\n\t"
+            "v_sub_co_u32 %8, vcc, %0, %32\n\t"
+            "v_subb_co_u32 %9, vcc, %1, %33, vcc\n\t"
+            "v_subb_co_u32 %10, vcc, %2, %34, vcc\n\t"
+            "v_subb_co_u32 %11, vcc, %3, %35, vcc\n\t"
+            "v_subb_co_u32 %12, vcc, %4, %36, vcc\n\t"
+            "v_subb_co_u32 %13, vcc, %5, %37, vcc\n\t"
+            "v_subb_co_u32 %14, vcc, %6, %38, vcc\n\t"
+            "v_subb_co_u32 %15, vcc, %7, %39, vcc\n\t"
+            "v_cndmask_b32 %0, %8, %0, vcc\n\t"
+            "v_cndmask_b32 %1, %9, %1, vcc\n\t"
+            "v_cndmask_b32 %2, %10, %2, vcc\n\t"
+            "v_cndmask_b32 %3, %11, %3, vcc\n\t"
+            "v_cndmask_b32 %4, %12, %4, vcc\n\t"
+            "v_cndmask_b32 %5, %13, %5, vcc\n\t"
+            "v_cndmask_b32 %6, %14, %6, vcc\n\t"
+            "v_cndmask_b32 %7, %15, %7, vcc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "v"(P::p(0)), "v"(P::p(1)), "v"(P::p(2)), "v"(P::p(3)), "v"(P::p(4)), "v"(P::p(5)), "v"(P::p(6)), "v"(P::p(7))
+        : "vcc");
+    return r;
+}
+template <class P>
+__device__ __forceinline__ Fp<P> fp_sub_asm(const Fp<P>& a, const Fp<P>& b, std::integral_constant<int, 8>) {
+    Fp<P> r;
+    u32 d[8];
+    asm("v_sub_co_u32 %0, vcc, %16, %24\n\t"
+            "v_subb_co_u32 %1, vcc, %17, %25, vcc\n\t"
+            "v_subb_co_u32 %2, vcc, %18, %26, vcc\n\t"
+            "v_subb_co_u32 %3, vcc, %19, %27, vcc\n\t"
+            "v_subb_co_u32 %4, vcc, %20, %28, vcc\n\t"
+            "v_subb_co_u32 %5, vcc, %21, %29, vcc\n\t"
+            "v_subb_co_u32 %6, vcc, %22, %30, vcc\n\t"
+            "v_subb_co_u32 %7, vcc, %23, %31, vcc\n\t"
+            "v_cndmask_b32 %8, 0, %32, vcc\n\t"
+            "v_cndmask_b32 %9, 0, %33, vcc\n\t"
+            "v_cndmask_b32 %10, 0, %34, vcc\n\t"
+            "v_cndmask_b32 %11, 0, %35, vcc\n\t"
+            "v_cndmask_b32 %12, 0, %36, vcc\n\t"
+            "v_cndmask_b32 %13, 0, %37, vcc\n\t"
+            "v_cndmask_b32 %14, 0, %38, vcc\n\t"
+            "v_cndmask_b32 %15, 0, %39, vcc\n\t"
+            "v_add_co_u32 %0, vcc, %0, %8\n\t"
+            "v_addc_co_u32 %1, vcc, %1, %9, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %2, %10, vcc\n\t"
+            "v_addc_co_u32 %3, vcc, %3, %11, vcc\n\t"
+            "v_addc_co_u32 %4, vcc, %4, %12, vcc\n\t"
+            "v_addc_co_u32 %5, vcc, %5, %13, vcc\n\t"
+            "v_addc_co_u32 %6, vcc, %6, %14, vcc\n\t"
+            "v_addc_co_u32 %7, vcc, %7, %15, vcc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "v"(P::p(0)), "v"(P::p(1)), "v"(P::p(2)), "v"(P::p(3)), "v"(P::p(4)), "v"(P::p(5)), "v"(P::p(6)), "v"(P::p(7))
+        : "vcc");
+    return r;
+}
+template <class P>
+__device__ __forceinline__ void fp_reduce_asm(Fp<P>& r, std::integral_constant<int, 8>) {
+    u32 d[8];
+    asm("v_sub_co_u32 %8, vcc, %0, %16\n\t"
+            "v_subb_co_u32 %9, vcc, %1, %17, vcc\n\t"
+            "v_subb_co_u32 %10, vcc, %2, %18, vcc\n\t"
+            "v_subb_co_u32 %11, vcc, %3, %19, vcc\n\t"
+            "v_subb_co_u32 %12, vcc, %4, %20, vcc\n\t"
+            "v_subb_co_u32 %13, vcc, %5, %21, vcc\n\t"
+            "v_subb_co_u32 %14, vcc, %6, %22, vcc\n\t"
+            "v_subb_co_u32 %15, vcc, %7, %23, vcc\n\t"
+            "v_cndmask_b32 %0, %8, %0, vcc\n\t"
+            "v_cndmask_b32 %1, %9, %1, vcc\n\t"
+            "v_cndmask_b32 %2, %10, %2, vcc\n\t"
+            "v_cndmask_b32 %3, %11, %3, vcc\n\t"
+            "v_cndmask_b32 %4, %12, %4, vcc\n\t"
+            "v_cndmask_b32 %5, %13, %5, vcc\n\t"
+            "v_cndmask_b32 %6, %14, %6, vcc\n\t"
+            "v_cndmask_b32 %7, %15, %7, vcc"
+        : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7])
+        : "v"(P::p(0)), "v"(P::p(1)), "v"(P::p(2)), "v"(P::p(3)), "v"(P::p(4)), "v"(P::p(5)), "v"(P::p(6)), "v"(P::p(7))
+        : "vcc");
+}
+template <class P>
+__device__ __forceinline__ Fp<P> fp_add_asm(const Fp<P>& a, const Fp<P>& b, std::integral_constant<int, 12>) {
+    Fp<P> r;
+    u32 d[12];
+    asm("v_add_co_u32 %0, vcc, %24, %36\n\t"
+            "v_addc_co_u32 %1, vcc, %25, %37, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %26, %38, vcc\n\t"
+            "v_addc_co_u32 %3, vcc, %27, %39, vcc\n\t"
+            "v_addc_co_u32 %4, vcc, %28, %40, vcc\n\t"
+            "v_addc_co_u32 %5, vcc, %29, %41, vcc\n\t"
+            "v_addc_co_u32 %6, vcc, %30, %42, vcc\n\t"
+            "v_addc_co_u32 %7, vcc, %31, %43, vcc\n\t"
+            "v_addc_co_u32 %8, vcc, %32, %44, vcc\n\t"
+            "v_addc_co_u32 %9, vcc, %33, %45, vcc\n\t"
+            "v_addc_co_u32 %10, vcc, %34, %46, vcc\n\t"
+            "v_addc_co_u32 %11, vcc, %35, %47, vcc\n\t"
+            "v_sub_co_u32 %12, vcc, %0, %48\n\t"
+            "v_subb_co_u32 %13, vcc, %1, %49, vcc\n\t"
+            "v_subb_co_u32 %14, vcc, %2, %50, vcc\n\t"
+            "v_subb_co_u32 %15, vcc, %3, %51, vcc\n\t"
+            "v_subb_co_u32 %16, vcc, %4, %52, vcc\n\t"
+            "v_subb_co_u32 %17, vcc, %5, %53, vcc\n\t"
+            "v_subb_co_u32 %18, vcc, %6, %54, vcc\n\t"
+            "v_subb_co_u32 %19, vcc, %7, %55, vcc\n\t"
+            "v_subb_co_u32 %20, vcc, %8, %56, vcc\n\t"
+            "v_subb_co_u32 %21, vcc, %9, %57, vcc\n\t"
+            "v_subb_co_u32 %22, vcc, %10, %58, vcc\n\t"
+            "v_subb_co_u32 %23, vcc, %11, %59, vcc\n\t"
+            "v_cndmask_b32 %0, %12, %0, vcc\n\t"
+            "v_cndmask_b32 %1, %13, %1, vcc\n\t"
+            "v_cndmask_b32 %2, %14, %2, vcc\n\t"
+            "v_cndmask_b32 %3, %15, %3, vcc\n\t"
+            "v_cndmask_b32 %4, %16, %4, vcc\n\t"
+            "v_cndmask_b32 %5, %17, %5, vcc\n\t"
+            "v_cndmask_b32 %6, %18, %6, vcc\n\t"
+            "v_cndmask_b32 %7, %19, %7, vcc\n\t"
+            "v_cndmask_b32 %8, %20, %8, vcc\n\t"
+            "v_cndmask_b32 %9, %21, %9, vcc\n\t"
+            "v_cndmask_b32 %10, %22, %10, vcc\n\t"
+            "v_cndmask_b32 %11, %23, %11, vcc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(r.l[8]), "=&v"(r.l[9]), "=&v"(r.l[10]), "=&v"(r.l[11]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(a.l[9]), "v"(a.l[10]), "v"(a.l[11]), "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "v"(b.l[8]), "v"(b.l[9]), "v"(b.l[10]), "v"(b.l[11]), "v"(P::p(0)), "v"(P::p(1)), "v"(P::p(2)), "v"(P::p(3)), "v"(P::p(4)), "v"(P::p(5)), "v"(P::p(6)), "v"(P::p(7)), "v"(P::p(8)), "v"(P::p(9)), "v"(P::p(10)), "v"(P::p(11))
+        : "vcc");
+    return r;
+}
+template <class P>
+__device__ __forceinline__ Fp<P> fp_sub_asm(const Fp<P>& a, const Fp<P>& b, std::integral_constant<int, 12>) {
+    Fp<P> r;
+    u32 d[12];
+    asm("v_sub_co_u32 %0, vcc, %24, %36\n\t"
+            "v_subb_co_u32 %1, vcc, %25, %37, vcc\n\t"
+            "v_subb_co_u32 %2, vcc, %26, %38, vcc\n\t"
+            "v_subb_co_u32 %3, vcc, %27, %39, vcc\n\t"
+            "v_subb_co_u32 %4, vcc, %28, %40, vcc\n\t"
+            "v_subb_co_u32 %5, vcc, %29, %41, vcc\n\t"
+            "v_subb_co_u32 %6, vcc, %30, %42, vcc\n\t"
+            "v_subb_co_u32 %7, vcc, %31, %43, vcc\n\t"
+            "v_subb_co_u32 %8, vcc, %32, %44, vcc\n\t"
+            "v_subb_co_u32 %9, vcc, %33, %45, vcc\n\t"
+            "v_subb_co_u32 %10, vcc, %34, %46, vcc\n\t"
+            "v_subb_co_u32 %11, vcc, %35, %47, vcc\n\t"
+            "v_cndmask_b32 %12, 0, %48, vcc\n\t"
+            "v_cndmask_b32 %13, 0, %49, vcc\n\t"
+            "v_cndmask_b32 %14, 0, %50, vcc\n\t"
+            "v_cndmask_b32 %15, 0, %51, vcc\n\t"
+            "v_cndmask_b32 %16, 0, %52, vcc\n\t"
+            "v_cndmask_b32 %17, 0, %53, vcc\n\t"
+            "v_cndmask_b32 %18, 0, %54, vcc\n\t"
+            "v_cndmask_b32 %19, 0, %55, vcc\n\t"
+            "v_cndmask_b32 %20, 0, %56, vcc\n\t"
+            "v_cndmask_b32 %21, 0, %57, vcc\n\t"
+            "v_cndmask_b32 %22, 0, %58, vcc\n\t"
+            "v_cndmask_b32 %23, 0, %59, vcc\n\t"
+            "v_add_co_u32 %0, vcc, %0, %12\n\t"
+            "v_addc_co_u32 %1, vcc, %1, %13, vcc\n\t"
+            "v_addc_co_u32 %2, vcc, %2, %14, vcc\n\t"
+            "v_addc_co_u32 %3, vcc, %3, %15, vcc\n\t"
+            "v_addc_co_u32 %4, vcc, %4, %16, vcc\n\t"
+            "v_addc_co_u32 %5, vcc, %5, %17, vcc\n\t"
+            "v_addc_co_u32 %6, vcc, %6, %18, vcc\n\t"
+            "v_addc_co_u32 %7, vcc, %7, %19, vcc\n\t"
+            "v_addc_co_u32 %8, vcc, %8, %20, vcc\n\t"
+            "v_addc_co_u32 %9, vcc, %9, %21, vcc\n\t"
+            "v_addc_co_u32 %10, vcc, %10, %22, vcc\n\t"
+            "v_addc_co_u32 %11, vcc, %11, %23, vcc"
+        : "=&v"(r.l[0]), "=&v"(r.l[1]), "=&v"(r.l[2]), "=&v"(r.l[3]), "=&v"(r.l[4]), "=&v"(r.l[5]), "=&v"(r.l[6]), "=&v"(r.l[7]), "=&v"(r.l[8]), "=&v"(r.l[9]), "=&v"(r.l[10]), "=&v"(r.l[11]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11])
+        : "v"(a.l[0]), "v"(a.l[1]), "v"(a.l[2]), "v"(a.l[3]), "v"(a.l[4]), "v"(a.l[5]), "v"(a.l[6]), "v"(a.l[7]), "v"(a.l[8]), "v"(a.l[9]), "v"(a.l[10]), "v"(a.l[11]), "v"(b.l[0]), "v"(b.l[1]), "v"(b.l[2]), "v"(b.l[3]), "v"(b.l[4]), "v"(b.l[5]), "v"(b.l[6]), "v"(b.l[7]), "v"(b.l[8]), "v"(b.l[9]), "v"(b.l[10]), "v"(b.l[11]), "v"(P::p(0)), "v"(P::p(1)), "v"(P::p(2)), "v"(P::p(3)), "v"(P::p(4)), "v"(P::p(5)), "v"(P::p(6)), "v"(P::p(7)), "v"(P::p(8)), "v"(P::p(9)), "v"(P::p(10)), "v"(P::p(11))
+        : "vcc");
+    return r;
+}
+template <class P>
+__device__ __forceinline__ void fp_reduce_asm(Fp<P>& r, std::integral_constant<int, 12>) {
+    u32 d[12];
+    asm("v_sub_co_u32 %12, vcc, %0, %24\n\t"
+            "v_subb_co_u32 %13, vcc, %1, %25, vcc\n\t"
+            "v_subb_co_u32 %14, vcc, %2, %26, vcc\n\t"
+            "v_subb_co_u32 %15, vcc, %3, %27, vcc\n\t"
+            "v_subb_co_u32 %16, vcc, %4, %28, vcc\n\t"
+            "v_subb_co_u32 %17, vcc, %5, %29, vcc\n\t"
+            "v_subb_co_u32 %18, vcc, %6, %30, vcc\n\t"
+            "v_subb_co_u32 %19, vcc, %7, %31, vcc\n\t"
+            "v_subb_co_u32 %20, vcc, %8, %32, vcc\n\t"
+            "v_subb_co_u32 %21, vcc, %9, %33, vcc\n\t"
+            "v_subb_co_u32 %22, vcc, %10, %34, vcc\n\t"
+            "v_subb_co_u32 %23, vcc, %11, %35, vcc\n\t"
+            "v_cndmask_b32 %0, %12, %0, vcc\n\t"
+            "v_cndmask_b32 %1, %13, %1, vcc\n\t"
+            "v_cndmask_b32 %2, %14, %2, vcc\n\t"
+            "v_cndmask_b32 %3, %15, %3, vcc\n\t"
+            "v_cndmask_b32 %4, %16, %4, vcc\n\t"
+            "v_cndmask_b32 %5, %17, %5, vcc\n\t"
+            "v_cndmask_b32 %6, %18, %6, vcc\n\t"
+            "v_cndmask_b32 %7, %19, %7, vcc\n\t"
+            "v_cndmask_b32 %8, %20, %8, vcc\n\t"
+            "v_cndmask_b32 %9, %21, %9, vcc\n\t"
+            "v_cndmask_b32 %10, %22, %10, vcc\n\t"
+            "v_cndmask_b32 %11, %23, %11, vcc"
+        : "+v"(r.l[0]), "+v"(r.l[1]), "+v"(r.l[2]), "+v"(r.l[3]), "+v"(r.l[4]), "+v"(r.l[5]), "+v"(r.l[6]), "+v"(r.l[7]), "+v"(r.l[8]), "+v"(r.l[9]), "+v"(r.l[10]), "+v"(r.l[11]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]), "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11])
+        : "v"(P::p(0)), "v"(P::p(1)), "v"(P::p(2)), "v"(P::p(3)), "v"(P::p(4)), "v"(P::p(5)), "v"(P::p(6)), "v"(P::p(7)), "v"(P::p(8)), "v"(P::p(9)), "v"(P::p(10)), "v"(P::p(11))
+        : "vcc");
+}
+#endif
+
 // r = a - p if a >= p else a   (macros.rs:237-246 reduce)
 template <class P>
 CZK_HD void fp_reduce(Fp<P>& a) {
     constexpr int N = P::N;
+#if defined(__HIP_DEVICE_COMPILE__)
+    fp_reduce_asm(a, std::integral_constant<int, N>{});
+    return;
+#endif
     u32 d[N];
     u32 borrow = 0;
 #pragma unroll
@@ -150,6 +374,9 @@ CZK_HD void fp_reduce(Fp<P>& a) {
 template <class P>
 CZK_HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
     constexpr int N = P::N;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fp_add_asm(a, b, std::integral_constant<int, N>{});
+#endif
     Fp<P> r;
     u32 c = 0;
 #pragma unroll
@@ -166,6 +393,9 @@ CZK_HD Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
 template <class P>
 CZK_HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
     constexpr int N = P::N;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fp_sub_asm(a, b, std::integral_constant<int, N>{});
+#endif
     Fp<P> r;
     u32 borrow = 0;
 #pragma unroll
@@ -189,6 +419,9 @@ CZK_HD Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
 template <class P>
 CZK_HD Fp<P> fp_dbl(const Fp<P>& a) {
     constexpr int N = P::N;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fp_add_asm(a, a, std::integral_constant<int, N>{});   // same value as mul2 + reduce; same 3N instructions
+#endif
     Fp<P> r;
     u32 top = 0;
 #pragma unroll
@@ -251,34 +484,375 @@ CZK_HD void acc_shift(Acc96& a) {
     a.hi = 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// acc += sum_t x[t] * y[t] for CNT products in ONE asm statement.  hipcc pads every asm statement with an
+// s_nop (it cannot see inside), so one statement per product costs 3 issue slots per product instead of 2;
+// a whole column per statement brings that back to 2 + 1/CNT.  (generated: CNT = 1..12)
+// ---------------------------------------------------------------------------------------------
+template <int CNT>
+struct MadN;
+template <>
+struct MadN<1> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0])
+            : "vcc");
+#else
+        for (int t = 0; t < 1; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<2> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1])
+            : "vcc");
+#else
+        for (int t = 0; t < 2; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<3> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2])
+            : "vcc");
+#else
+        for (int t = 0; t < 3; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<4> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3])
+            : "vcc");
+#else
+        for (int t = 0; t < 4; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<5> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4])
+            : "vcc");
+#else
+        for (int t = 0; t < 5; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<6> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5])
+            : "vcc");
+#else
+        for (int t = 0; t < 6; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<7> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6])
+            : "vcc");
+#else
+        for (int t = 0; t < 7; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<8> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %16, %17, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7])
+            : "vcc");
+#else
+        for (int t = 0; t < 8; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<9> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %16, %17, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %18, %19, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8])
+            : "vcc");
+#else
+        for (int t = 0; t < 9; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<10> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %16, %17, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %18, %19, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %20, %21, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9])
+            : "vcc");
+#else
+        for (int t = 0; t < 10; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<11> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %16, %17, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %18, %19, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %20, %21, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %22, %23, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10])
+            : "vcc");
+#else
+        for (int t = 0; t < 11; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+template <>
+struct MadN<12> {
+    static CZK_HD void run(Acc96& a, const u32* x, const u32* y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm(
+            "v_mad_u64_u32 %0, vcc, %2, %3, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %4, %5, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %6, %7, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %8, %9, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %10, %11, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %12, %13, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %14, %15, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %16, %17, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %18, %19, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %20, %21, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %22, %23, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+            "v_mad_u64_u32 %0, vcc, %24, %25, %0\n\t"
+            "v_addc_co_u32 %1, vcc, 0, %1, vcc"
+            : "+v"(a.lo), "+v"(a.hi)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11])
+            : "vcc");
+#else
+        for (int t = 0; t < 12; t++) acc_mad(a, x[t], y[t]);
+#endif
+    }
+};
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, class F>
+CZK_HD void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
 // Montgomery product a*b*R^-1 mod p, fully reduced == fields/arithmetic.rs:7-56 (value-identical).
+// Column k of the product-scanning schedule: sum_i a[i] b[k-i]  +  sum_i m[i] p[k-i]  (m[k] = -acc0 for k < N).
 template <class P>
 CZK_MUL_ATTR Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
     constexpr int N = P::N;
     u32 m[N];
     Fp<P> r;
     Acc96 acc = {0, 0};
+    static_for<0, 2 * N - 1>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        constexpr int i0 = k < N ? 0 : k - N + 1;
+        constexpr int cab = (k < N ? k : N - 1) - i0 + 1;         // products a[i] b[k-i], i = i0 .. min(k, N-1)
+        {
+            u32 xs[cab], ys[cab];
 #pragma unroll
-    for (int k = 0; k < N; k++) {
+            for (int t = 0; t < cab; t++) {
+                xs[t] = a.l[i0 + t];
+                ys[t] = b.l[k - i0 - t];
+            }
+            MadN<cab>::run(acc, xs, ys);
+        }
+        constexpr int cmp = (k < N ? k - 1 : N - 1) - i0 + 1;      // products m[i] p[k-i], p index >= 1
+        if constexpr (cmp > 0) {
+            u32 xs[cmp], ys[cmp];
 #pragma unroll
-        for (int i = 0; i < k; i++) acc_mad(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-        for (int i = 0; i < k; i++) acc_mad(acc, m[i], P::p(k - i));
-        acc_mad(acc, a.l[k], b.l[0]);
-        m[k] = 0u - (u32)acc.lo;          // -p^-1 mod 2^32 == 0xffffffff for both fields
-        acc_add32(acc, m[k]);             // + m[k]*p[0], p[0] == 1  -> low word becomes 0
+            for (int t = 0; t < cmp; t++) {
+                xs[t] = m[i0 + t];
+                ys[t] = P::p(k - i0 - t);
+            }
+            MadN<cmp>::run(acc, xs, ys);
+        }
+        if constexpr (k < N) {
+            m[k] = 0u - (u32)acc.lo;          // -p^-1 mod 2^32 == 0xffffffff for both fields
+            acc_add32(acc, m[k]);             // + m[k]*p[0], p[0] == 1  -> low word becomes 0
+        } else {
+            r.l[k - N] = (u32)acc.lo;
+        }
         acc_shift(acc);
-    }
-#pragma unroll
-    for (int k = N; k < 2 * N - 1; k++) {
-#pragma unroll
-        for (int i = k - N + 1; i < N; i++) acc_mad(acc, a.l[i], b.l[k - i]);
-#pragma unroll
-        for (int i = k - N + 1; i < N; i++) acc_mad(acc, m[i], P::p(k - i));
-        r.l[k - N] = (u32)acc.lo;
-        acc_shift(acc);
-    }
-    r.l[N - 1] = (u32)acc.lo;             // < 2p < 2^(32N): nothing above this word
+    });
+    r.l[N - 1] = (u32)acc.lo;                 // < 2p < 2^(32N): nothing above this word
     fp_reduce(r);
     return r;
 }
