@@ -25,6 +25,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the MSM pipeline uses 3 internal streams (csrc/core.hip)
+
 import numpy as np
 import torch
 

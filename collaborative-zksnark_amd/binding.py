@@ -43,6 +43,7 @@ def lib():
         # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes cannot share a process, so let
         # torch's copy load first (same SONAME -> libczk_hip.so binds to it).  torch is plumbing here: device
         # memory, streams, torch.distributed.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see csrc/core.hip: must be set before HIP initialises
         try:
             import torch  # noqa: F401
         except ImportError:
