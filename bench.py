@@ -143,6 +143,17 @@ class Groth16Local:
         D, N, L, ld = self.D, self.N, self.lanes, self.log_d
         M = czk.CZK_MEM_DEVICE
         ADD = 0
+        MONT = czk.CZK_SCALAR_MONTGOMERY
+        r = self.results
+        for k in ("h", "l", "a", "b_g1"):
+            r.setdefault(k, np.zeros((L, 18), dtype=np.uint64))
+        r.setdefault("b_g2", np.zeros((L, 36), dtype=np.uint64))
+        # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
+        # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
+        ctx.msm_async(self.b_g2_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g2"], stable=True)
+        ctx.msm_async(self.l_query, self.wit.data_ptr(), N, L, MONT, r["l"], stable=True)
+        ctx.msm_async(self.a_query, self.asg.data_ptr(), N + 1, L, MONT, r["a"], stable=True)
+        ctx.msm_async(self.b_g1_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g1"], stable=True)
         self.a.copy_(self.a0); self.b.copy_(self.b0); self.c.copy_(self.c0)   # fresh inputs (in-place transforms)
         # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
         ctx.witness_map_pre(self.a.data_ptr(), self.b.data_ptr(), ld, L)       # ifft, ifft, coset_fft, coset_fft
@@ -155,18 +166,8 @@ class Groth16Local:
             ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
                                   self.oy.data_ptr(), ln < 2, out=self.ab[ln].data_ptr(), n=D, mem=M)
         ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L)     # h = ab
-        # --- create_proof MSMs (prover.rs:104-156), every share lane -----------------------------------------
-        MONT = czk.CZK_SCALAR_MONTGOMERY
-        r = self.results
-        for k in ("h", "l", "a", "b_g1"):
-            r.setdefault(k, np.zeros((L, 18), dtype=np.uint64))
-        r.setdefault("b_g2", np.zeros((L, 36), dtype=np.uint64))
-        # enqueue-only: the five MSMs pipeline on the context's internal streams; results are valid after sync()
-        ctx.msm_async(self.b_g2_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g2"])
-        ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"])
-        ctx.msm_async(self.l_query, self.wit.data_ptr(), N, L, MONT, r["l"])
-        ctx.msm_async(self.a_query, self.asg.data_ptr(), N + 1, L, MONT, r["a"])
-        ctx.msm_async(self.b_g1_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g1"])
+        # --- the h MSM (prover.rs:104) needs the witness map's output
+        ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"], stable=True)
         ctx.sync()
 
     def g1_accumulate_algorithmic_bytes(self):
@@ -261,8 +262,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     parallel.init("nccl")          # RCCL; only the timing reduction uses it (units are independent)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = czk.Context(local_rank, stream)
+    # torch's default stream has handle 0, which the C ABI reads as "make a private stream": use an explicit torch
+    # stream so that torch's copies and the library's kernels are ordered on ONE stream.
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    ctx = czk.Context(local_rank, tstream.cuda_stream)
+    assert tstream.cuda_stream != 0
     prover = Groth16Local(czk, ctx, args.log_n, args.parties)
 
     def barrier():

@@ -78,7 +78,11 @@ def _ptr(x):
 
 
 class Context:
-    """czk_ctx: one GPU + one HIP stream = one MPC party."""
+    """czk_ctx: one GPU + one HIP stream = one MPC party.
+
+    `stream` is a hipStream_t handle (e.g. `torch.cuda.Stream().cuda_stream`).  None / 0 makes the context create its
+    own non-blocking stream -- note torch's DEFAULT stream has handle 0, so to share a stream with torch ops use an
+    explicit `torch.cuda.Stream()` (bench.py does)."""
 
     def __init__(self, device: int = 0, stream: int | None = None):
         self._h = C.c_void_p(0)
@@ -189,10 +193,11 @@ class Context:
                                C.c_int(mem), _ptr(out)))
         return out
 
-    def msm_async(self, bases: "Bases", scalars_ptr, n_scalars: int, lanes: int, scalar_form: int, out: np.ndarray):
-        """czk_msm_async on device scalars; `out` (numpy, lanes x 18|36) is valid after sync()."""
+    def msm_async(self, bases: "Bases", scalars_ptr, n_scalars: int, lanes: int, scalar_form: int, out: np.ndarray, stable: bool = False):
+        """czk_msm_async on device scalars; `out` (numpy, lanes x 18|36) is valid after sync().  stable=True promises
+        the scalars stay untouched until then (CZK_MEM_STABLE)."""
         self._ck(lib().czk_msm_async(self._h, bases._h, _ptr(scalars_ptr), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
-                                     C.c_int(CZK_MEM_DEVICE), _ptr(out)))
+                                     C.c_int(CZK_MEM_DEVICE | (16 if stable else 0)), _ptr(out)))
         return out
 
     def msm_oneshot(self, group, bases, inf, scalars, lanes=1, scalar_form=CZK_SCALAR_CANONICAL):

@@ -125,7 +125,7 @@ struct ProfScope {
 int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len);
 // implemented in msm.hip
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
-               int scalar_form, u64* out_jac_host, bool blocking);
+               int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable);
 int msm_pipeline_init(czk_ctx* ctx);
 int msm_pipeline_sync(czk_ctx* ctx);
 void msm_pipeline_destroy(czk_ctx* ctx);

@@ -384,7 +384,8 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
 // slots alternate, guarded by events.  Results land in a pinned staging area and are handed to the caller's
 // buffer by msm_collect() after the streams are synchronised.
 template <class F>
-static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host) {
+static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host,
+                       bool scalars_stable) {
     constexpr int JW = GT<F>::JW;
     const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
     const unsigned c = b->c, W = b->W;
@@ -454,7 +455,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_sorted, ss));
     // the caller's stream may overwrite the scalars once the digits are extracted
-    CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
+    if (!scalars_stable) CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
     CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     {
@@ -540,9 +541,9 @@ void msm_pipeline_destroy(czk_ctx* ctx) {
 }
 
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes, int scalar_form,
-               u64* out_jac_host, bool blocking) {
-    int rc = bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host)
-                                    : msm_enqueue<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host);
+               u64* out_jac_host, bool blocking, bool scalars_stable) {
+    int rc = bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable)
+                                    : msm_enqueue<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable);
     if (rc != CZK_OK || !blocking) return rc;
     return msm_pipeline_sync(ctx);
 }
@@ -637,6 +638,8 @@ static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scal
     if (scalar_form != CZK_SCALAR_CANONICAL && scalar_form != CZK_SCALAR_MONTGOMERY) return set_err(ctx, CZK_ERR_ARG, "bad scalar_form");
     if (!lanes) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
+    const bool stable = (mem & CZK_MEM_STABLE) != 0;
+    mem &= ~CZK_MEM_STABLE;
     const u64* sdev = scalars;
     void* tmp = nullptr;
     if (mem == CZK_MEM_HOST && n_scalars) {
@@ -648,7 +651,7 @@ static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scal
         }
         sdev = (const u64*)tmp;
     }
-    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp != nullptr);
+    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp != nullptr, stable && !blocking);
     if (tmp) (void)hipFree(tmp);
     return rc;
 }

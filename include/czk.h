@@ -44,7 +44,14 @@ typedef enum {
     CZK_ERR_NOMEM = 4
 } czk_status;
 
-typedef enum { CZK_MEM_HOST = 0, CZK_MEM_DEVICE = 1 } czk_mem;
+typedef enum {
+    CZK_MEM_HOST = 0,
+    CZK_MEM_DEVICE = 1,
+    /* czk_msm_async only, OR-ed with CZK_MEM_DEVICE: the caller will not modify the scalar buffer before the next
+     * czk_ctx_sync(), so the context's stream need not wait for the MSM's digit extraction (lets independent work
+     * enqueued afterwards on that stream -- e.g. the witness-map NTTs -- overlap with the MSM). */
+    CZK_MEM_STABLE = 16
+} czk_mem;
 
 /* EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (algebra/poly/src/domain/mod.rs:79,90,139,155) */
 typedef enum { CZK_FFT = 0, CZK_IFFT = 1, CZK_COSET_FFT = 2, CZK_COSET_IFFT = 3 } czk_ntt_kind;
