@@ -133,6 +133,121 @@ CZK_HD void jac_store(u64* p, const Jac<F>& a) {
     FieldIO<F>::store(p + 2 * W, a.z);
 }
 
+// ---------------------------------------------------------------------------------------------
+// XYZZ coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; infinity <=> ZZ == 0) for the MSM's internal bucket
+// arithmetic: mixed addition 8M + 2S and general addition 12M + 2S (EFD madd-2008-s / add-2008-s, a = 0), against
+// 7M + 4S / 11M + 5S for the Jacobian forms above.  Only internal: every result leaves the library as the
+// reference's Jacobian triple (xyzz_to_jac) and is compared in affine form.  Edge cases mirror
+// short_weierstrass_jacobian.rs:570-597 / :666-689: infinity operands, equal points (-> doubling), opposite
+// points (-> infinity).
+// ---------------------------------------------------------------------------------------------
+template <class F>
+struct XYZZ {
+    F x, y, zz, zzz;
+    static CZK_HD XYZZ zero() { return XYZZ{F::one(), F::one(), F::zero(), F::zero()}; }
+    CZK_HD bool is_zero() const { return zz.is_zero(); }
+};
+
+// 2 * (x, y) for an affine point (mdbl-2008-s-1, a = 0)
+template <class F>
+CZK_HD XYZZ<F> xyzz_double_affine(const Affine<F>& q) {
+    F u = f_dbl(q.y);
+    F v = f_sqr(u);
+    F w = f_mul(u, v);
+    F s = f_mul(q.x, v);
+    F xx = f_sqr(q.x);
+    F m = f_add(f_dbl(xx), xx);
+    XYZZ<F> o;
+    o.x = f_sub(f_sqr(m), f_dbl(s));
+    o.y = f_sub(f_mul(m, f_sub(s, o.x)), f_mul(w, q.y));
+    o.zz = v;
+    o.zzz = w;
+    return o;
+}
+// 2 * p (dbl-2008-s-1, a = 0)
+template <class F>
+CZK_HD XYZZ<F> xyzz_double(const XYZZ<F>& p) {
+    if (p.is_zero()) return p;
+    F u = f_dbl(p.y);
+    F v = f_sqr(u);
+    F w = f_mul(u, v);
+    F s = f_mul(p.x, v);
+    F xx = f_sqr(p.x);
+    F m = f_add(f_dbl(xx), xx);
+    XYZZ<F> o;
+    o.x = f_sub(f_sqr(m), f_dbl(s));
+    o.y = f_sub(f_mul(m, f_sub(s, o.x)), f_mul(w, p.y));
+    o.zz = f_mul(v, p.zz);
+    o.zzz = f_mul(w, p.zzz);
+    return o;
+}
+
+// p + q, q affine and not infinity (madd-2008-s); product order keeps few values live
+template <class F>
+CZK_HD XYZZ<F> xyzz_add_mixed(const XYZZ<F>& p, const Affine<F>& q) {
+    if (p.is_zero()) return XYZZ<F>{q.x, q.y, F::one(), F::one()};
+    F pp = f_sub(f_mul(q.x, p.zz), p.x);        // P = U2 - X1
+    F r = f_sub(f_mul(q.y, p.zzz), p.y);        // R = S2 - Y1
+    if (pp.is_zero()) {
+        if (r.is_zero()) return xyzz_double_affine(q);   // same point
+        return XYZZ<F>::zero();                          // opposite points
+    }
+    F p2 = f_sqr(pp);                            // PP
+    XYZZ<F> o;
+    o.zz = f_mul(p.zz, p2);
+    F p3 = f_mul(pp, p2);                        // PPP
+    o.zzz = f_mul(p.zzz, p3);
+    F qv = f_mul(p.x, p2);                       // Q
+    o.x = f_sub(f_sub(f_sqr(r), p3), f_dbl(qv));
+    o.y = f_sub(f_mul(r, f_sub(qv, o.x)), f_mul(p.y, p3));
+    return o;
+}
+
+// p + q (add-2008-s)
+template <class F>
+CZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& p, const XYZZ<F>& q) {
+    if (p.is_zero()) return q;
+    if (q.is_zero()) return p;
+    F u1 = f_mul(p.x, q.zz);
+    F pp = f_sub(f_mul(q.x, p.zz), u1);          // P = U2 - U1
+    F s1 = f_mul(p.y, q.zzz);
+    F r = f_sub(f_mul(q.y, p.zzz), s1);          // R = S2 - S1
+    if (pp.is_zero()) {
+        if (r.is_zero()) return xyzz_double(p);
+        return XYZZ<F>::zero();
+    }
+    F p2 = f_sqr(pp);
+    F p3 = f_mul(pp, p2);
+    XYZZ<F> o;
+    o.zz = f_mul(f_mul(p.zz, q.zz), p2);
+    o.zzz = f_mul(f_mul(p.zzz, q.zzz), p3);
+    F qv = f_mul(u1, p2);
+    o.x = f_sub(f_sub(f_sqr(r), p3), f_dbl(qv));
+    o.y = f_sub(f_mul(r, f_sub(qv, o.x)), f_mul(s1, p3));
+    return o;
+}
+
+// (X, Y, ZZ, ZZZ) -> the Jacobian triple (X ZZ, Y ZZZ, ZZ): x = X ZZ / ZZ^2, y = Y ZZZ / ZZ^3 = Y / ZZZ
+template <class F>
+CZK_HD Jac<F> xyzz_to_jac(const XYZZ<F>& p) {
+    if (p.is_zero()) return Jac<F>::zero();
+    return Jac<F>{f_mul(p.x, p.zz), f_mul(p.y, p.zzz), p.zz};
+}
+
+template <class F>
+CZK_HD XYZZ<F> xyzz_load(const u64* p) {
+    constexpr int W = FieldIO<F>::W64;
+    return XYZZ<F>{FieldIO<F>::load(p), FieldIO<F>::load(p + W), FieldIO<F>::load(p + 2 * W), FieldIO<F>::load(p + 3 * W)};
+}
+template <class F>
+CZK_HD void xyzz_store(u64* p, const XYZZ<F>& a) {
+    constexpr int W = FieldIO<F>::W64;
+    FieldIO<F>::store(p, a.x);
+    FieldIO<F>::store(p + W, a.y);
+    FieldIO<F>::store(p + 2 * W, a.zz);
+    FieldIO<F>::store(p + 3 * W, a.zzz);
+}
+
 typedef Affine<Fq> G1Affine;
 typedef Jac<Fq> G1Jac;
 typedef Affine<Fq2> G2Affine;

@@ -25,11 +25,11 @@ template <class F>
 struct GT;
 template <>
 struct GT<Fq> {
-    static constexpr int AW = 12, JW = 18, FW = 6;   // u64 words: affine, Jacobian, field element
+    static constexpr int AW = 12, JW = 18, FW = 6, XW = 24;   // u64 words: affine, Jacobian, field element, XYZZ
 };
 template <>
 struct GT<Fq2> {
-    static constexpr int AW = 24, JW = 36, FW = 12;
+    static constexpr int AW = 24, JW = 36, FW = 12, XW = 48;
 };
 
 }  // namespace czk

@@ -386,7 +386,7 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
 template <class F>
 static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host,
                        bool scalars_stable) {
-    constexpr int JW = GT<F>::JW;
+    constexpr int JW = GT<F>::JW, XW = GT<F>::XW;   // results leave as Jacobian; buckets are XYZZ internally
     const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
     const unsigned c = b->c, W = b->W;
     const size_t B = (size_t)1 << (c - 1);
@@ -399,7 +399,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
     size_t need_sort = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 4 + CNT_BINS * 4) + (1 << 16);
-    size_t need_red = lanes * (B * JW * 8 + 4 * lvl0 * JW * 8 + JW * 8) + (1 << 16);
+    size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8) + (1 << 16);
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
         CZK_TRY(msm_pipeline_sync(ctx));
         CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
@@ -415,9 +415,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     const size_t n_tiles = (B + SCAN_TILE - 1) / SCAN_TILE;
     u32* tile_sums = bs.take<u32>(lanes * n_tiles);
     Bump br{(char*)slot.ws_red.p};
-    u64* buckets = br.take<u64>(lanes * B * JW);
+    u64* buckets = br.take<u64>(lanes * B * XW);
     u64* lv[4];
-    for (int i = 0; i < 4; i++) lv[i] = br.take<u64>(lanes * lvl0 * JW);
+    for (int i = 0; i < 4; i++) lv[i] = br.take<u64>(lanes * lvl0 * XW);
     u64* result = br.take<u64>(lanes * JW);
 
     // pinned staging for the result

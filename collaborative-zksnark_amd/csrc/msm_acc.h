@@ -7,8 +7,8 @@
 namespace czk {
 
 // sorted[off .. off+cnt) lists this bucket's points as (w * n_bases + i) | sign<<31; pts holds the window
-// multiples 2^(c*w) * P_i in affine Montgomery form.  acc += (+/-) P with madd-2007-bl
-// (short_weierstrass_jacobian.rs:570-638, edge cases included).
+// multiples 2^(c*w) * P_i in affine Montgomery form.  acc += (+/-) P in XYZZ coordinates (curve.h; same edge cases as
+// short_weierstrass_jacobian.rs:570-597).
 template <class F>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts,
                                                    const u32* perm, size_t B, size_t sorted_stride, u64* buckets) {
@@ -18,14 +18,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t b = perm[(size_t)lane * B + t];   // buckets in descending-population order: equal work per wave
     const u32* srt = sorted + (size_t)lane * sorted_stride;
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
-    Jac<F> acc = Jac<F>::zero();
+    XYZZ<F> acc = XYZZ<F>::zero();
     for (u32 e = 0; e < cnt; e++) {
         u32 code = srt[off + e];
         Affine<F> p = aff_load<F>(pts + (size_t)GT<F>::AW * (code & 0x7fffffffu));
         if (code & 0x80000000u) p.y = f_neg(p.y);
-        acc = jac_add_mixed(acc, p, false);
+        acc = xyzz_add_mixed(acc, p);
     }
-    jac_store<F>(buckets + (size_t)GT<F>::JW * ((size_t)lane * B + b), acc);
+    xyzz_store<F>(buckets + (size_t)GT<F>::XW * ((size_t)lane * B + b), acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 //   E_out[m] = sum_{t in chunk m} E[t] + 2^scale_dbl * sum_{t in chunk m} (t - start_m) * P[t]
 // with 2^scale_dbl = L^level, so that  L^(level+1) * sum_m m P_out[m] + sum_m E_out[m]  is unchanged.
 // ------------------------------------------------------------------------------------------------
-template <class F, int JW, int SHIFT>   // SHIFT = 1: one chunk per lane pair (F = Fq2P)
+template <class F, int JW, int SHIFT>   // JW = u64 words per XYZZ point; SHIFT = 1: one chunk per lane pair (F = Fq2P)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level(const u64* P_in, const u64* E_in, size_t n_in, unsigned L, unsigned scale_dbl,
                                                      u64* P_out, u64* E_out, size_t n_out) {
     size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> SHIFT;
@@ -42,18 +42,18 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t seg = blockIdx.y;
     const u64* P = P_in + (size_t)JW * seg * n_in;
     size_t start = m * L, end = start + L < n_in ? start + L : n_in;
-    Jac<F> running = Jac<F>::zero(), A = Jac<F>::zero();
+    XYZZ<F> running = XYZZ<F>::zero(), A = XYZZ<F>::zero();
     for (size_t t = end; t-- > start;) {
-        running = jac_add(running, jac_load<F>(P + JW * t));
-        if (t > start) A = jac_add(A, running);
+        running = xyzz_add(running, xyzz_load<F>(P + JW * t));
+        if (t > start) A = xyzz_add(A, running);
     }
-    for (unsigned k = 0; k < scale_dbl; k++) A = jac_double(A);
+    for (unsigned k = 0; k < scale_dbl; k++) A = xyzz_double(A);
     if (E_in) {
         const u64* E = E_in + (size_t)JW * seg * n_in;
-        for (size_t t = start; t < end; t++) A = jac_add(A, jac_load<F>(E + JW * t));
+        for (size_t t = start; t < end; t++) A = xyzz_add(A, xyzz_load<F>(E + JW * t));
     }
-    jac_store<F>(P_out + (size_t)JW * (seg * n_out + m), running);
-    jac_store<F>(E_out + (size_t)JW * (seg * n_out + m), A);
+    xyzz_store<F>(P_out + (size_t)JW * (seg * n_out + m), running);
+    xyzz_store<F>(E_out + (size_t)JW * (seg * n_out + m), A);
 }
 
 // out[seg] = P[seg] + E[seg]   (weights are b+1: sum_b (b+1) B_b = sum_b b B_b + sum_b B_b)
@@ -61,9 +61,9 @@ template <class F, int JW, int SHIFT>
 __global__ void k_finish(const u64* P, const u64* E, size_t segs, u64* out) {
     size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> SHIFT;
     if (s >= segs) return;
-    Jac<F> r = jac_load<F>(P + (size_t)JW * s);
-    if (E) r = jac_add(r, jac_load<F>(E + (size_t)JW * s));
-    jac_store<F>(out + (size_t)JW * s, r);
+    XYZZ<F> r = xyzz_load<F>(P + (size_t)JW * s);
+    if (E) r = xyzz_add(r, xyzz_load<F>(E + (size_t)JW * s));
+    jac_store<F>(out + (size_t)(JW / 4 * 3) * s, xyzz_to_jac(r));   // leave as the reference's Jacobian triple
 }
 
 
@@ -77,14 +77,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t b = perm[(size_t)lane * B + t];
     const u32* srt = sorted + (size_t)lane * sorted_stride;
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
-    Jac<FP> acc = Jac<FP>::zero();
+    XYZZ<FP> acc = XYZZ<FP>::zero();
     for (u32 e = 0; e < cnt; e++) {
         u32 code = srt[off + e];
         Affine<FP> p = aff_load<FP>(pts + (size_t)24 * (code & 0x7fffffffu));
         if (code & 0x80000000u) p.y = f_neg(p.y);
-        acc = jac_add_mixed(acc, p, false);
+        acc = xyzz_add_mixed(acc, p);
     }
-    jac_store<FP>(buckets + (size_t)36 * ((size_t)lane * B + b), acc);
+    xyzz_store<FP>(buckets + (size_t)48 * ((size_t)lane * B + b), acc);
 }
 
 }  // namespace czk

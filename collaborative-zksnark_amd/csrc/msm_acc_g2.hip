@@ -17,9 +17,9 @@ void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, con
 }
 void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
                             unsigned lanes) {
-    hipLaunchKernelGGL((k_reduce_level<Fq2P, 36, 1>), dim3((unsigned)(((n_out << 1) + 127) / 128), lanes), dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
+    hipLaunchKernelGGL((k_reduce_level<Fq2P, 48, 1>), dim3((unsigned)(((n_out << 1) + 127) / 128), lanes), dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
 }
 void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out) {
-    hipLaunchKernelGGL((k_finish<Fq2P, 36, 1>), dim3((unsigned)(((segs << 1) + 63) / 64)), dim3(64), 0, st, P, E, segs, out);
+    hipLaunchKernelGGL((k_finish<Fq2P, 48, 1>), dim3((unsigned)(((segs << 1) + 63) / 64)), dim3(64), 0, st, P, E, segs, out);
 }
 }  // namespace czk
