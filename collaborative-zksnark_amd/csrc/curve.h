@@ -203,6 +203,37 @@ CZK_HD XYZZ<F> xyzz_add_mixed(const XYZZ<F>& p, const Affine<F>& q) {
     return o;
 }
 
+// In-place form of xyzz_add_mixed for hot loops: the accumulator is four separate values updated in place (a
+// struct returned from several exits made hipcc keep X and Y in a stack slot across iterations: 24 scratch stores and
+// loads per addition).
+template <class F>
+CZK_HD void xyzz_acc_mixed(F& ax, F& ay, F& azz, F& azzz, const F& qx, const F& qy) {
+    if (azz.is_zero()) {
+        ax = qx;
+        ay = qy;
+        azz = F::one();
+        azzz = F::one();
+        return;
+    }
+    F pp = f_sub(f_mul(qx, azz), ax);
+    F r = f_sub(f_mul(qy, azzz), ay);
+    if (pp.is_zero()) {
+        XYZZ<F> d = r.is_zero() ? xyzz_double_affine(Affine<F>{qx, qy}) : XYZZ<F>::zero();
+        ax = d.x;
+        ay = d.y;
+        azz = d.zz;
+        azzz = d.zzz;
+        return;
+    }
+    F p2 = f_sqr(pp);
+    azz = f_mul(azz, p2);
+    F p3 = f_mul(pp, p2);
+    azzz = f_mul(azzz, p3);
+    F qv = f_mul(ax, p2);
+    ax = f_sub(f_sub(f_sqr(r), p3), f_dbl(qv));
+    ay = f_sub(f_mul(r, f_sub(qv, ax)), f_mul(ay, p3));
+}
+
 // p + q (add-2008-s)
 template <class F>
 CZK_HD XYZZ<F> xyzz_add(const XYZZ<F>& p, const XYZZ<F>& q) {

@@ -18,14 +18,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const size_t b = perm[(size_t)lane * B + t];   // buckets in descending-population order: equal work per wave
     const u32* srt = sorted + (size_t)lane * sorted_stride;
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
-    XYZZ<F> acc = XYZZ<F>::zero();
+    F ax = F::one(), ay = F::one(), azz = F::zero(), azzz = F::zero();   // XYZZ infinity
     for (u32 e = 0; e < cnt; e++) {
         u32 code = srt[off + e];
         Affine<F> p = aff_load<F>(pts + (size_t)GT<F>::AW * (code & 0x7fffffffu));
         if (code & 0x80000000u) p.y = f_neg(p.y);
-        acc = xyzz_add_mixed(acc, p);
+        xyzz_acc_mixed(ax, ay, azz, azzz, p.x, p.y);
     }
-    xyzz_store<F>(buckets + (size_t)GT<F>::XW * ((size_t)lane * B + b), acc);
+    xyzz_store<F>(buckets + (size_t)GT<F>::XW * ((size_t)lane * B + b), XYZZ<F>{ax, ay, azz, azzz});
 }
 
 // ------------------------------------------------------------------------------------------------
