@@ -63,8 +63,10 @@ struct czk_ctx {
     // MSM pipeline (msm.hip)
     hipStream_t s_sort = nullptr, s_acc = nullptr, s_red = nullptr;
     hipEvent_t ev_in = nullptr;
-    czk::MsmSlot msm_slots[2];
+    static constexpr int MSM_SLOTS = 4;   // workspace ring: accumulate(k + MSM_SLOTS) waits for reduce(k)
+    czk::MsmSlot msm_slots[MSM_SLOTS];
     int msm_next_slot = 0;
+    int msm_slots_in_use = 3;
     char* msm_pinned = nullptr;
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
     std::vector<czk::MsmPending> msm_pending;

@@ -21,6 +21,7 @@
 //     sum, applied per chunk, with the chunk offsets folded in at the next level).
 //   * `lanes` scalar vectors that share the bases (SPDZ sh / mac lanes) ride on gridDim.y.
 // All arithmetic is 32-bit-limb integer VALU (field.h); nothing here is MFMA-shaped.
+#include <stdlib.h>
 #include <string.h>
 
 #include "czk_internal.h"
@@ -380,8 +381,8 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
 //   s_sort : digits -> histogram -> offsets -> scatter -> population order          (memory / atomics bound)
 //   s_acc  : bucket accumulation                                                     (integer-VALU bound, fills the chip)
 //   s_red  : multi-level bucket reduction + result copy                              (latency bound, few waves)
-// Consecutive MSMs overlap stage-wise (sort of k+1 and reduce of k-1 hide under accumulate of k); two workspace
-// slots alternate, guarded by events.  Results land in a pinned staging area and are handed to the caller's
+// Consecutive MSMs overlap stage-wise (sort of k+1 and reduce of k-1 hide under accumulate of k); a ring of
+// workspace slots is guarded by events.  Results land in a pinned staging area and are handed to the caller's
 // buffer by msm_collect() after the streams are synchronised.
 template <class F>
 static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host,
@@ -394,7 +395,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if ((size_t)W * b->n >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
     CZK_TRY(msm_pipeline_init(ctx));
     MsmSlot& slot = ctx->msm_slots[ctx->msm_next_slot];
-    ctx->msm_next_slot ^= 1;
+    ctx->msm_next_slot = (ctx->msm_next_slot + 1) % ctx->msm_slots_in_use;
 
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
@@ -496,9 +497,18 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 
 int msm_pipeline_init(czk_ctx* ctx) {
     if (ctx->s_sort) return CZK_OK;
-    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_sort, hipStreamNonBlocking));
-    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_acc, hipStreamNonBlocking));
-    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_red, hipStreamNonBlocking));
+    // the accumulate kernel saturates every SIMD for tens of ms; give the short sort / reduce stages priority so
+    // they are not starved behind it (they are on the critical path of the NEXT accumulate)
+    int prio_lo = 0, prio_hi = 0;
+    CZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lower = higher priority
+    if (!getenv("CZK_STREAM_PRIO")) prio_hi = prio_lo;   // measured: no gain from prioritising sort / reduce (default off)
+    if (const char* e = getenv("CZK_MSM_SLOTS")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= czk_ctx::MSM_SLOTS) ctx->msm_slots_in_use = v;
+    }
+    CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_sort, hipStreamNonBlocking, prio_hi));
+    CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_acc, hipStreamNonBlocking, prio_lo));
+    CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_red, hipStreamNonBlocking, prio_hi));
     CZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
     for (auto& s : ctx->msm_slots) {
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_sorted, hipEventDisableTiming));
