@@ -153,8 +153,6 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
         if (d.coset_inv) (void)hipFree(d.coset_inv);
     }
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
-    if (ctx->stage.p) (void)hipFree(ctx->stage.p);
-    if (ctx->msm_ws.p) (void)hipFree(ctx->msm_ws.p);
     msm_pipeline_destroy(ctx);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

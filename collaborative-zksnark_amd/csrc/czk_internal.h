@@ -79,8 +79,6 @@ struct czk_ctx {
     std::string err;
     std::map<unsigned, czk::DomainTables> domains;
     czk::DeviceBuf ntt_scratch;   // one lane-batch for the out-of-place NTT passes
-    czk::DeviceBuf stage;         // staging for CZK_MEM_HOST arguments
-    czk::DeviceBuf msm_ws;        // MSM workspace
     int num_cu = 256;
 };
 

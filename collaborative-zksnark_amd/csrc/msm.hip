@@ -15,10 +15,14 @@
 //     doubling chain (256 dependent doublings in the reference) at all.
 //   * signed digits: 2^(c-1) buckets of weight 1..2^(c-1); a negative digit adds -P (y -> p - y).
 //   * digits are counting-sorted by bucket (histogram -> scan -> scatter), then one thread owns one bucket
-//     and folds its points with the mixed addition (madd-2007-bl, same formulas / edge cases as
-//     short_weierstrass_jacobian.rs:570-638) -- no atomics or locks on group elements.
+//     and folds its points with the mixed addition (same edge cases as short_weierstrass_jacobian.rs:570-597)
+//     -- no atomics or locks on group elements; buckets are visited in descending-population order so the 64
+//     lanes of a wave do equal work.
+//   * buckets live in XYZZ coordinates (curve.h): mixed addition 8M + 2S instead of 7M + 4S, addition 12M + 2S
+//     instead of 11M + 5S; one conversion back to the reference's Jacobian triple per result.
 //   * bucket reduction sum_b (b+1) * B_b: multi-level chunked running sums (the reference's :82-86 running
 //     sum, applied per chunk, with the chunk offsets folded in at the next level).
+//   * consecutive MSMs pipeline over three internal streams (msm_enqueue below).
 //   * `lanes` scalar vectors that share the bases (SPDZ sh / mac lanes) ride on gridDim.y.
 // All arithmetic is 32-bit-limb integer VALU (field.h); nothing here is MFMA-shaped.
 #include <stdlib.h>
