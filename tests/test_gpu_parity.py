@@ -210,12 +210,13 @@ def test_msm_empty_and_all_zero(ctx, czk, orc):
     b0.release()
 
 
-@pytest.mark.parametrize("g,log_n", [(1, 20), (2, 17)])
-def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, log_n):
+@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (2, (1 << 17) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7)])
+def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, n):
     """Size-independent check at BASELINE scale: bases P_i = [k_i] G, so MSM(P, s) must equal
-    [sum k_i s_i mod r] G; plus linearity between the two lanes."""
+    [sum k_i s_i mod r] G; plus linearity between the two lanes.  Sizes: the Groth16 a/b queries at 2^20
+    constraints (configs[1]), a G2 query, a KZG commit of a 2^18-coefficient polynomial (Plonk, configs[2]) and a
+    non-power-of-two ~3N commit as Marlin's largest polynomials at 2^20 (configs[3]; poly-commit/src/kzg10/mod.rs:159-162)."""
     import torch
-    n = (1 << log_n) + 1
     k = rand_fr_canonical(0xBA5E5, n)
     aw = 12 if g == 1 else 24
     kd = torch.from_numpy(k.view(np.int64)).cuda()

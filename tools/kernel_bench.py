@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Per-kernel timings mirroring the reference's bench shapes (algebra/poly-benches/benches/fft.rs:13-15: FFT
+2^15..2^22; curves/curve-benches/src/macros/ec.rs:199-213: msm_131072) plus the BASELINE sizes.  Device-resident
+inputs, HIP-event timing through the library's profiling hooks.  Prints a markdown table and writes JSON.
+
+    python tools/kernel_bench.py [out.json]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np
+import torch
+
+import czk_amd as czk
+from util import rand_fr_canonical
+
+ts = torch.cuda.Stream()
+torch.cuda.set_stream(ts)
+ctx = czk.Context(0, ts.cuda_stream)
+rows = []
+
+
+def timed(fn, reps):
+    fn()
+    ctx.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    ctx.sync()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+print("| kernel | size | lanes | ms | algorithmic GB/s | frac of 8 TB/s | field mul/s |")
+print("|---|---|---|---|---|---|---|")
+for log_d in (15, 17, 19, 20, 21, 22, 23):
+    for lanes in (1, 4):
+        d = 1 << log_d
+        x = torch.from_numpy(rand_fr_canonical(log_d, 4096).view(np.int64)).cuda().repeat((lanes * d) // 4096 + 1, 1)[: lanes * d].contiguous()
+        dt = timed(lambda: ctx.ntt_fr(x.data_ptr(), log_d, czk.CZK_FFT, lanes=lanes, mem=czk.CZK_MEM_DEVICE), 5)
+        gb = lanes * 2 * d * 32 / dt / 1e9                      # 2 * D * 32 B per lane
+        muls = lanes * (d // 2) * log_d / dt
+        rows.append({"kernel": "ntt_fft", "log_size": log_d, "lanes": lanes, "ms": dt * 1e3, "alg_gbs": gb, "frac": gb / 8000, "mul_per_s": muls})
+        print(f"| NTT (fft_in_place) | 2^{log_d} | {lanes} | {dt*1e3:.3f} | {gb:.0f} | {gb/8000:.3f} | {muls:.3g} Fr |")
+        del x
+for g, sizes in ((czk.CZK_G1, (17, 20, 21, 22)), (czk.CZK_G2, (17, 20))):
+    for log_n in sizes:
+        n = 1 << log_n
+        aw = 12 if g == czk.CZK_G1 else 24
+        k = torch.from_numpy(rand_fr_canonical(0xBA5E5, n).view(np.int64)).cuda()
+        pts = torch.empty((n, aw), dtype=torch.int64, device="cuda")
+        ctx.fixed_base_points(g, k.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+        b = ctx.register_bases(g, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
+        del pts, k
+        for lanes in (1, 4):
+            s = torch.from_numpy(rand_fr_canonical(0xC0FFEE + lanes, lanes * n).view(np.int64)).cuda()
+            dt = timed(lambda: ctx.msm(b, s.data_ptr(), n_scalars=n, lanes=lanes, mem=czk.CZK_MEM_DEVICE), 3)
+            gb = (n * aw * 8 + lanes * n * 32) / dt / 1e9        # bases once + scalars per lane
+            rows.append({"kernel": f"msm_g{g}", "log_size": log_n, "lanes": lanes, "ms": dt * 1e3, "alg_gbs": gb, "frac": gb / 8000,
+                         "points_per_s": lanes * n / dt})
+            print(f"| MSM G{g} (blocking czk_msm) | 2^{log_n} | {lanes} | {dt*1e3:.2f} | {gb:.1f} | {gb/8000:.5f} | {lanes*n/dt:.3g} pts/s |")
+            del s
+        b.release()
+if len(sys.argv) > 1:
+    json.dump(rows, open(sys.argv[1], "w"), indent=1)
