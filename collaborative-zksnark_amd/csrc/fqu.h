@@ -1,0 +1,428 @@
+// fqu.h -- Fq in an UNSATURATED representation for the MSM's hottest loop (device only).
+//
+// 14 limbs of 28 bits (392 bits), Montgomery radix R' = 2^392.  A column of the product-scanning multiply sums at
+// most 14 + 13 products of 2 x 30-bit limbs plus a carry: < 2^64, so the column accumulator is a plain u64 and every
+// partial product is ONE v_mad_u64_u32 (the saturated form in field.h needs a v_addc per product to track the
+// 65th..96th bits).  p == 1 mod 2^28, so the quotient digit is again m = -acc mod 2^28.  392 - 377 = 15 spare bits
+// let additions and subtractions stay LAZY: a multiply accepts operands up to 2^7 p with limbs < 2^30 and returns
+// a value < 1.01 p with normalised limbs (no final subtraction), so only the two stored accumulator coordinates
+// are re-normalised per mixed addition.  ~486 instructions per multiply against ~620.
+//
+// Values: a field element a is held as a * R' mod p (+ a multiple of p when lazy).  Bases are converted once at
+// registration (multiply by R' mod p in the saturated form, stored as canonical 12 x u32 integers); bucket results
+// are converted back with one saturated multiply by 2^376 = R^2 / R', so everything outside the accumulate kernel
+// keeps the reference's Montgomery form.  Group elements are unchanged; only the residue system differs.
+#pragma once
+#include "curve.h"
+
+namespace czk {
+
+struct FqU {
+    u32 l[14];
+};
+constexpr u32 FQU_MASK = (1u << 28) - 1u;
+
+__device__ __forceinline__ u32 fqu_p(int i) {
+    constexpr u32 m[14] = {0x00000001u, 0x008c0000u, 0x00000085u, 0x05d44300u, 0x0800170bu, 0x02fba094u, 0x0f1ef362u,
+                           0x000f5138u, 0x0a22d9f3u, 0x0a1493b1u, 0x0b05c06cu, 0x010eac63u, 0x0a4617c5u, 0x00001ae3u};
+    return m[i];
+}
+// K p in redundant limb form: every limb but the top is >= U * 2^28, so a_i + L_i - b_i (- ...) never goes negative
+// for subtrahend limbs < U * 2^28  (generated; sum L_i 2^(28 i) == K p exactly)
+__device__ __forceinline__ u32 fqu_4p(int i) {
+    constexpr u32 m[14] = {0x10000004u, 0x122fffffu, 0x10000213u, 0x17510bffu, 0x10005c2cu, 0x1bee8251u, 0x1c7bcd87u,
+                           0x103d44e2u, 0x188b67cbu, 0x18524ec5u, 0x1c1701b1u, 0x143ab18du, 0x19185f13u, 0x00006b8du};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_8p(int i) {
+    constexpr u32 m[14] = {0x10000008u, 0x145fffffu, 0x10000427u, 0x1ea217ffu, 0x1000b859u, 0x17dd04a3u, 0x18f79b10u,
+                           0x107a89c6u, 0x1116cf97u, 0x10a49d8cu, 0x182e0364u, 0x1875631cu, 0x1230be27u, 0x0000d71cu};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_16p(int i) {
+    constexpr u32 m[14] = {0x10000010u, 0x18bfffffu, 0x1000084fu, 0x1d442fffu, 0x100170b4u, 0x1fba0947u, 0x11ef3621u,
+                           0x10f5138eu, 0x122d9f2fu, 0x11493b19u, 0x105c06c9u, 0x10eac63au, 0x14617c50u, 0x0001ae39u};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_8p_wide(int i) {   // limbs >= 3 * 2^28: absorbs three normalised subtrahends
+    constexpr u32 m[14] = {0x30000008u, 0x345ffffdu, 0x30000425u, 0x3ea217fdu, 0x3000b857u, 0x37dd04a1u, 0x38f79b0eu,
+                           0x307a89c4u, 0x3116cf95u, 0x30a49d8au, 0x382e0362u, 0x3875631au, 0x3230be25u, 0x0000d71au};
+    return m[i];
+}
+__device__ __forceinline__ FqU fqu_one() {   // R' mod p
+    constexpr u32 m[14] = {0x0fff67acu, 0x020fffffu, 0x0fb0d727u, 0x0e9203ffu, 0x0249b0e4u, 0x0e172345u, 0x0955d771u,
+                           0x02bf89aau, 0x0b2833b2u, 0x098e116bu, 0x07dc5c97u, 0x00d43e93u, 0x02e3314bu, 0x000003b4u};
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = m[i];
+    return r;
+}
+// saturated-form constants for the conversions (32-bit limbs)
+__device__ __forceinline__ Fq fqu_k_to_u() {   // R' mod p
+    constexpr u32 m[12] = {0xffff67acu, 0x2720ffffu, 0x3fffb0d7u, 0xb0e4e920u, 0x72345249u, 0x55d771e1u,
+                           0x2bf89aa9u, 0xbb2833b2u, 0x9798e116u, 0xe937dc5cu, 0x314b0d43u, 0x003b42e3u};
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = m[i];
+    return r;
+}
+__device__ __forceinline__ Fq fqu_k_from_u() {   // R^2 / R' = 2^376
+    Fq r = Fq::zero();
+    r.l[11] = 0x01000000u;
+    return r;
+}
+
+// acc += sum_t x[t] * y[t], one v_mad_u64_u32 per product, one asm statement per column (generated: CNT = 1..14)
+template <int CNT>
+struct MadU;
+template <>
+struct MadU<1> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<2> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<3> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<4> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<5> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<6> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<7> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<8> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<9> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<10> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<11> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<12> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %23, %24, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<13> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %23, %24, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %25, %26, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]), "v"(x[12]), "v"(y[12])
+            : "vcc");
+    }
+};
+template <>
+struct MadU<14> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %23, %24, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %25, %26, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %27, %28, %0"
+            : "+v"(a)
+            : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]), "v"(x[9]), "v"(y[9]), "v"(x[10]), "v"(y[10]), "v"(x[11]), "v"(y[11]), "v"(x[12]), "v"(y[12]), "v"(x[13]), "v"(y[13])
+            : "vcc");
+    }
+};
+
+// a * b / R' mod p (+ possibly p): operands may be lazy (limbs < 2^30, value < 2^7 p); result limbs normalised
+// (< 2^28, top limb small), value < 1.01 p.
+__device__ __forceinline__ FqU fqu_mul(const FqU& a, const FqU& b) {
+    constexpr int N = 14;
+    u32 m[N];
+    FqU r;
+    u64 acc = 0;
+    static_for<0, 2 * N - 1>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        constexpr int i0 = k < N ? 0 : k - N + 1;
+        constexpr int cab = (k < N ? k : N - 1) - i0 + 1;
+        {
+            u32 xs[cab], ys[cab];
+#pragma unroll
+            for (int t = 0; t < cab; t++) {
+                xs[t] = a.l[i0 + t];
+                ys[t] = b.l[k - i0 - t];
+            }
+            MadU<cab>::run(acc, xs, ys);
+        }
+        constexpr int cmp = (k < N ? k - 1 : N - 1) - i0 + 1;
+        if constexpr (cmp > 0) {
+            u32 xs[cmp], ys[cmp];
+#pragma unroll
+            for (int t = 0; t < cmp; t++) {
+                xs[t] = m[i0 + t];
+                ys[t] = fqu_p(k - i0 - t);
+            }
+            MadU<cmp>::run(acc, xs, ys);
+        }
+        if constexpr (k < N) {
+            m[k] = (0u - (u32)acc) & FQU_MASK;   // -p^-1 == -1 mod 2^28
+            acc += m[k];                         // + m[k] * p[0]: the low 28 bits become 0
+        } else {
+            r.l[k - N] = (u32)acc & FQU_MASK;
+        }
+        acc >>= 28;
+    });
+    r.l[N - 1] = (u32)acc;
+    return r;
+}
+
+// carry-propagate: limbs < 2^28 afterwards (top limb takes the rest)
+__device__ __forceinline__ FqU fqu_normalize(const FqU& a) {
+    FqU r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        u32 t = a.l[i] + c;
+        r.l[i] = t & FQU_MASK;
+        c = t >> 28;
+    }
+    r.l[13] = a.l[13] + c;
+    return r;
+}
+// a - b + K p, lazy result (limbs < 2^30): a lazy-or-normalised (< 2^29.x), b normalised
+template <int K>
+__device__ __forceinline__ FqU fqu_sub_lazy(const FqU& a, const FqU& b) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        u32 L = K == 4 ? fqu_4p(i) : K == 8 ? fqu_8p(i) : fqu_16p(i);
+        r.l[i] = a.l[i] + (L - b.l[i]);
+    }
+    return r;
+}
+// a - b - 2 c + 8 p, normalised: a, b, c normalised
+__device__ __forceinline__ FqU fqu_sub3_norm(const FqU& a, const FqU& b, const FqU& c) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + (fqu_8p_wide(i) - b.l[i] - c.l[i] - c.l[i]);
+    return fqu_normalize(r);
+}
+
+// 12 x 32-bit canonical integer -> 14 x 28-bit limbs
+__device__ __forceinline__ FqU fqu_unpack(const Fq& s) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const int bit = 28 * i, w = bit >> 5, off = bit & 31;
+        u32 lo = w < 12 ? s.l[w] : 0u, hi = (w + 1) < 12 ? s.l[w + 1] : 0u;
+        u32 v = off == 0 ? lo : ((lo >> off) | (hi << (32 - off)));
+        r.l[i] = i < 13 ? (v & FQU_MASK) : v;
+    }
+    return r;
+}
+// normalised 14 x 28-bit limbs (value < 2^384) -> 12 x 32-bit integer
+__device__ __forceinline__ Fq fqu_pack(const FqU& a) {
+    Fq s;
+#pragma unroll
+    for (int w = 0; w < 12; w++) {
+        // bits [32 w, 32 w + 32) of sum a_i 2^(28 i)
+        const int lo_limb = (32 * w) / 28, sh = 32 * w - 28 * lo_limb;
+        u32 v = a.l[lo_limb] >> sh;
+        int have = 28 - sh;
+        int nxt = lo_limb + 1;
+        if (have < 32 && nxt < 14) {
+            v |= a.l[nxt] << have;
+            have += 28;
+            nxt++;
+        }
+        if (have < 32 && nxt < 14) v |= a.l[nxt] << have;
+        s.l[w] = v;
+    }
+    return s;
+}
+
+// In-place XYZZ mixed addition in the unsaturated residue system (madd-2008-s; see curve.h xyzz_acc_mixed).
+// Accumulator invariants: ax, ay normalised with values < 9.5 p / 5.5 p; azz, azzz multiply outputs.
+// Returns false when the exceptional case P == +-Q (H == 0 mod p) may have occurred: the caller then redoes this
+// addition in the saturated form.  (H = U2 - X1 + 16 p lies in (6 p, 18 p); it is 0 mod p only if it equals j p,
+// and p == 1 mod 2^28 makes the low 28 bits of j p equal j.)
+__device__ __forceinline__ bool fqu_xyzz_acc_mixed(FqU& ax, FqU& ay, FqU& azz, FqU& azzz, const FqU& qx, const FqU& qy_lazy) {
+    FqU u2 = fqu_mul(qx, azz);
+    FqU pp = fqu_sub_lazy<16>(u2, ax);
+    if (((pp.l[0] & FQU_MASK) - 6u) <= 12u) return false;
+    FqU s2 = fqu_mul(qy_lazy, azzz);
+    FqU r = fqu_sub_lazy<8>(s2, ay);
+    FqU p2 = fqu_mul(pp, pp);
+    azz = fqu_mul(azz, p2);
+    FqU p3 = fqu_mul(pp, p2);
+    azzz = fqu_mul(azzz, p3);
+    FqU qv = fqu_mul(ax, p2);
+    FqU t = fqu_mul(r, r);
+    ax = fqu_sub3_norm(t, p3, qv);                       // < 1.01 p + 8 p
+    FqU d = fqu_sub_lazy<16>(qv, ax);
+    FqU e = fqu_mul(r, d);
+    FqU f = fqu_mul(ay, p3);
+    ay = fqu_normalize(fqu_sub_lazy<4>(e, f));           // < 1.01 p + 4 p
+    return true;
+}
+
+}  // namespace czk

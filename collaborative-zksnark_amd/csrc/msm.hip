@@ -378,6 +378,14 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
         CZK_HIP(ctx, hipFree(jac));
         CZK_HIP(ctx, hipFree(scr));
     }
+    if (GT<F>::AW == 12 && !getenv("CZK_MSM_SAT")) {
+        // G1 tables go to the unsaturated residue system of fqu.h (infinity flags are unaffected); CZK_MSM_SAT=1
+        // keeps the saturated kernel (k_accumulate<Fq>) for A/B runs
+        launch_convert_to_u(ctx->stream, b->pts, (size_t)W * n * 2);
+        CZK_HIP(ctx, hipGetLastError());
+        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        b->unsat = true;
+    }
     return CZK_OK;
 }
 
@@ -404,7 +412,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
     size_t need_sort = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 4 + CNT_BINS * 4) + (1 << 16);
-    size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8) + (1 << 16);
+    size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B) + (1 << 17);
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
         CZK_TRY(msm_pipeline_sync(ctx));
         CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
@@ -424,6 +432,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     u64* lv[4];
     for (int i = 0; i < 4; i++) lv[i] = br.take<u64>(lanes * lvl0 * XW);
     u64* result = br.take<u64>(lanes * JW);
+    uint8_t* dirty = br.take<uint8_t>(lanes * B + 64 + 3 * 4096 * 4 + 64);   // unsaturated kernel: dirty flags + exception list
 
     // pinned staging for the result
     const size_t out_bytes = lanes * JW * 8;
@@ -465,7 +474,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     {
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
-        if (GT<F>::AW == 12) launch_accumulate_g1(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+        if (GT<F>::AW == 12 && b->unsat) launch_accumulate_g1_u(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else if (GT<F>::AW == 12) launch_accumulate_g1(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
         else launch_accumulate_g2(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     }
     CZK_HIP(ctx, hipGetLastError());

@@ -67,6 +67,113 @@ __global__ void k_finish(const u64* P, const u64* E, size_t segs, u64* out) {
 }
 
 
+#ifdef CZK_WITH_FQU
+// G1 accumulation in the unsaturated residue system (fqu.h): `pts` holds x R' mod p, y R' mod p as canonical
+// 12 x u32 integers (converted at registration).  Buckets leave in the usual saturated XYZZ Montgomery form.
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_u(
+    const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets,
+    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const unsigned lane = blockIdx.y;
+    const size_t b = perm[(size_t)lane * B + t];
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
+    FqU ax, ay, azz, azzz;
+    bool inf = true;
+    for (u32 e = 0; e < cnt; e++) {
+        u32 code = srt[off + e];
+        const u64* pp = pts + (size_t)12 * (code & 0x7fffffffu);
+        FqU qx = fqu_unpack(fp_load<FqParams>(pp));
+        FqU qy = fqu_unpack(fp_load<FqParams>(pp + 6));
+        if (code & 0x80000000u) {
+#pragma unroll
+            for (int i = 0; i < 14; i++) qy.l[i] = fqu_4p(i) - qy.l[i];   // 4p - y, lazy limbs < 2^29
+        }
+        if (inf) {
+            ax = qx;
+            ay = fqu_normalize(qy);
+            azz = fqu_one();
+            azzz = azz;
+            inf = false;
+            continue;
+        }
+        if (!fqu_xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy)) {
+            // possible P == +-Q (about 1 in 2^24 additions for honest inputs).  Addition commutes, so the point is
+            // deferred: k_accumulate_u_cleanup adds it to the finished bucket with the saturated formulas (all edge
+            // cases).  If the list is full (adversarial inputs), the whole bucket goes to k_accumulate_u_fix instead.
+            u32 slot = atomicAdd(exc_count, 1u);
+            if (slot < exc_cap) {
+                exc_list[3 * slot] = lane;
+                exc_list[3 * slot + 1] = (u32)b;
+                exc_list[3 * slot + 2] = code;
+                continue;
+            }
+            dirty[(size_t)lane * B + b] = 1;
+            return;
+        }
+    }
+    XYZZ<Fq> out = XYZZ<Fq>::zero();
+    if (!inf) {
+        const Fq kf = fqu_k_from_u();
+        out.x = fp_mul(fqu_pack(ax), kf);
+        out.y = fp_mul(fqu_pack(ay), kf);
+        out.zz = fp_mul(fqu_pack(azz), kf);
+        out.zzz = fp_mul(fqu_pack(azzz), kf);
+    }
+    xyzz_store<Fq>(buckets + (size_t)24 * ((size_t)lane * B + b), out);
+}
+
+// recomputes the buckets k_accumulate_u gave up on, in the saturated residue system (points converted on the fly)
+__global__ __launch_bounds__(128) void k_accumulate_u_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+                                                         size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned lane = blockIdx.y;
+    if (!dirty[(size_t)lane * B + b]) return;
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
+    const Fq kf = fqu_k_from_u();
+    Fq ax = Fq::one(), ay = Fq::one(), azz = Fq::zero(), azzz = Fq::zero();
+    for (u32 e = 0; e < cnt; e++) {
+        u32 code = srt[off + e];
+        const u64* pp = pts + (size_t)12 * (code & 0x7fffffffu);
+        Fq qx = fp_mul(fp_load<FqParams>(pp), kf), qy = fp_mul(fp_load<FqParams>(pp + 6), kf);
+        if (code & 0x80000000u) qy = fp_neg(qy);
+        xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy);
+    }
+    xyzz_store<Fq>(buckets + (size_t)24 * ((size_t)lane * B + b), XYZZ<Fq>{ax, ay, azz, azzz});
+}
+
+// adds the deferred points into the finished buckets (sequentially: several may hit one bucket); buckets that were
+// recomputed from scratch by k_accumulate_u_fix already contain theirs
+__global__ void k_accumulate_u_cleanup(const u64* pts, size_t B, u64* buckets, const uint8_t* dirty, const u32* exc_count, const u32* exc_list,
+                                       u32 exc_cap) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    u32 n = *exc_count;
+    if (n > exc_cap) n = exc_cap;
+    const Fq kf = fqu_k_from_u();
+    for (u32 k = 0; k < n; k++) {
+        u32 lane = exc_list[3 * k], b = exc_list[3 * k + 1], code = exc_list[3 * k + 2];
+        if (dirty[(size_t)lane * B + b]) continue;
+        u64* slot = buckets + (size_t)24 * ((size_t)lane * B + b);
+        XYZZ<Fq> acc = xyzz_load<Fq>(slot);
+        const u64* pp = pts + (size_t)12 * (code & 0x7fffffffu);
+        Fq qx = fp_mul(fp_load<FqParams>(pp), kf), qy = fp_mul(fp_load<FqParams>(pp + 6), kf);
+        if (code & 0x80000000u) qy = fp_neg(qy);
+        xyzz_acc_mixed(acc.x, acc.y, acc.zz, acc.zzz, qx, qy);
+        xyzz_store<Fq>(slot, acc);
+    }
+}
+
+// one-time conversion of registered G1 window tables: coordinate <- coordinate * R' / R  (canonical integer)
+__global__ void k_convert_to_u(u64* pts, size_t n_coords) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_coords) return;
+    fp_store<FqParams>(pts + 6 * i, fp_mul(fp_load<FqParams>(pts + 6 * i), fqu_k_to_u()));
+}
+#endif
+
 // G2 variant: one bucket per lane PAIR (fq2p.h).  Same algorithm, same memory formats.
 template <class FP>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_pair(

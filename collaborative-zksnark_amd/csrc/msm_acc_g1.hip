@@ -1,4 +1,6 @@
 // msm_acc_g1.hip -- bucket accumulation kernel instantiated for G1 (base field Fq).
+#define CZK_WITH_FQU 1
+#include "fqu.h"
 #include "msm_acc.h"
 
 namespace czk {
@@ -6,6 +8,22 @@ void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, con
                           size_t sorted_stride, u64* buckets, unsigned lanes) {
     hipLaunchKernelGGL(k_accumulate<Fq>, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
                        sorted_stride, buckets);
+}
+void launch_accumulate_g1_u(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty) {
+    // workspace behind the dirty flags: [count][list of EXC_CAP x 3 u32]
+    constexpr u32 EXC_CAP = 4096;
+    size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
+    u32* exc = (u32*)(dirty + flags);
+    (void)hipMemsetAsync(dirty, 0, flags + 16, st);
+    hipLaunchKernelGGL(k_accumulate_u, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
+                       sorted_stride, buckets, dirty, exc, exc + 4, EXC_CAP);
+    hipLaunchKernelGGL(k_accumulate_u_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
+                       sorted_stride, buckets, dirty);
+    hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, EXC_CAP);
+}
+void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords) {
+    hipLaunchKernelGGL(k_convert_to_u, dim3((unsigned)((n_coords + 255) / 256)), dim3(256), 0, st, pts, n_coords);
 }
 void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
                             unsigned lanes) {

@@ -321,3 +321,35 @@ def test_groth16_local_pipeline_config0_matches_reference(ctx, czk, orc):
             want = orc.multi_scalar_mul(g, bases, inf, scal[ln].reshape(-1, 4))
             assert _same_point(ctx, orc, g, p.results[name][ln], want), (name, ln)
     c2.close()
+
+
+def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch):
+    """CZK_MSM_SAT=1 selects the saturated G1 accumulate kernel (k_accumulate<Fq>); keep it covered."""
+    monkeypatch.setenv("CZK_MSM_SAT", "1")
+    c2 = czk.Context(0)
+    _, bases = _bases(c2, 1, 500, 41)
+    sc = rand_fr_canonical(42, 500)
+    inf = np.zeros(500, dtype=np.uint8)
+    b = c2.register_bases(1, bases, inf)
+    assert _same_point(c2, orc, 1, c2.msm(b, sc)[0], orc.msm(1, bases, inf, sc))
+    b.release()
+    c2.close()
+
+
+def test_msm_adversarial_equal_and_opposite_bases(ctx, czk, orc):
+    """Worst case for the unsaturated accumulate kernel's exceptional-case hand-off: every base is +-P and the
+    scalars collide, so almost every bucket addition is P + P or P + (-P).  The result must still be the exact
+    group element (the reference's add_assign_mixed handles these cases inline: short_weierstrass_jacobian.rs:587-597)."""
+    n = 3000
+    _, one = _bases(ctx, 1, 1, 99)
+    neg = one[0].copy()
+    neg[6:] = orc.fq_neg(one[0][6:])
+    bases = np.tile(one[0], (n, 1))
+    bases[1::3] = neg
+    sc = rand_fr_canonical(77, 8)
+    scal = sc[np.arange(n) % 8].copy()          # only 8 distinct scalars -> heavy bucket collisions
+    inf = np.zeros(n, dtype=np.uint8)
+    b = ctx.register_bases(1, bases, inf)
+    got = ctx.msm(b, scal, lanes=1)
+    assert _same_point(ctx, orc, 1, got[0], orc.msm(1, bases, inf, scal))
+    b.release()

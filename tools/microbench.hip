@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <vector>
 #include "curve.h"
+#include "fqu.h"
 using namespace czk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)
@@ -88,6 +89,30 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     for (int i = 0; i < iters; i++) acc = jac_add_mixed(acc, p, false);
     jac_store<Fq>(data + 18 * t, acc);
 }
+__global__ void k_mul_u(u64* data, int iters) {
+    size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    FqU a = fqu_unpack(fp_load<FqParams>(data + 6 * t)), b = a;
+    for (int i = 0; i < iters; i++) { a = fqu_mul(a, b); b = fqu_mul(b, a); }
+    fp_store<FqParams>(data + 6 * t, fqu_pack(fqu_normalize(fqu_sub_lazy<4>(a, b))));
+}
+template <int WPE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_madd_u(u64* data, int iters) {
+    size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    FqU qx = fqu_unpack(fp_load<FqParams>(data + 12 * t)), qy = fqu_unpack(fp_load<FqParams>(data + 12 * t + 6));
+    FqU ax = qy, ay = qx, azz = fqu_one(), azzz = fqu_one();
+    int bad = 0;
+    for (int i = 0; i < iters; i++) bad += fqu_xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy) ? 0 : 1;
+    fp_store<FqParams>(data + 18 * t, fqu_pack(fqu_normalize(fqu_sub_lazy<4>(ax, azz))));
+    if (bad == 12345) data[0] = 1;
+}
+template <int WPE>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_madd_x(u64* data, int iters) {
+    size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
+    Affine<Fq> p = aff_load<Fq>(data + 12 * t);
+    Fq ax = p.y, ay = p.x, azz = Fq::one(), azzz = Fq::one();
+    for (int i = 0; i < iters; i++) xyzz_acc_mixed(ax, ay, azz, azzz, p.x, p.y);
+    fp_store<FqParams>(data + 18 * t, fp_add(ax, azz));
+}
 template <int WPE>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void k_madd2(u64* data, int iters) {
     size_t t = threadIdx.x + (size_t)blockIdx.x * blockDim.x;
@@ -131,6 +156,10 @@ int main() {
     };
     timeit("Fr mul (256thr x8/CU)", [&](int it) { hipLaunchKernelGGL(k_mul_fr, dim3(blocks), dim3(threads), 0, 0, data, it); }, 2, n);
     timeit("Fq mul (256thr x8/CU)", [&](int it) { hipLaunchKernelGGL(k_mul<Fq>, dim3(blocks), dim3(threads), 0, 0, data, it); }, 2, n);
+    timeit("FqU mul (14x28 unsat)", [&](int it) { hipLaunchKernelGGL(k_mul_u, dim3(blocks), dim3(threads), 0, 0, data, it); }, 2, n);
+    timeit("G1 xyzz madd sat wpe2 (10M)", [&](int it) { hipLaunchKernelGGL(k_madd_x<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 10, n);
+    timeit("G1 xyzz madd UNSAT wpe2", [&](int it) { hipLaunchKernelGGL(k_madd_u<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 10, n);
+    timeit("G1 xyzz madd UNSAT wpe3", [&](int it) { hipLaunchKernelGGL(k_madd_u<3>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 10, n);
     timeit("Fq2 mul (=3 Fq mul)", [&](int it) { hipLaunchKernelGGL(k_mul<Fq2>, dim3(blocks), dim3(threads), 0, 0, data, it); }, 6, n);
     timeit("Fq2 mul wpe2", [&](int it) { hipLaunchKernelGGL(k_mul2<2>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 6, n);
     timeit("Fq2 mul wpe3", [&](int it) { hipLaunchKernelGGL(k_mul2<3>, dim3(blocks * 2), dim3(128), 0, 0, data, it); }, 6, n);
