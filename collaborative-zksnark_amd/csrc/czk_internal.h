@@ -88,7 +88,7 @@ struct czk_bases {
     size_t n = 0;
     unsigned c = 0;            // signed-digit window width chosen at registration
     unsigned W = 0;            // number of windows = ceil(254 / c)
-    bool unsat = false;        // G1 only: window tables hold coordinates * R' (fqu.h), used by k_accumulate_u
+    bool unsat = false;        // window tables hold coordinates * R' (fqu.h), used by k_accumulate_u / k_accumulate_u2
     uint64_t* pts = nullptr;   // device, W x n x (12|24) u64: window w holds 2^(c*w) * P_i, affine Montgomery
     uint8_t* inf = nullptr;    // device, W x n infinity flags (never null)
 };
@@ -143,6 +143,8 @@ void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, con
 void launch_accumulate_g1_u(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords);
+void launch_accumulate_g2_u(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);
 

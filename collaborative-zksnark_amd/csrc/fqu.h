@@ -425,4 +425,139 @@ __device__ __forceinline__ bool fqu_xyzz_acc_mixed(FqU& ax, FqU& ay, FqU& azz, F
     return true;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fq2 over the unsaturated residue system (G2 accumulation).  Discipline: every value is re-normalised after every
+// add / sub (limbs < 2^28), so only VALUE bounds need tracking; the lazy-subtraction constants below (K p in
+// redundant limb form, generated) were chosen with an interval analysis of the whole mixed addition -- stable
+// bounds: X < 85 p, Y < 49 p, H < 145 p, r < 81 p, every multiply output < 26 p, capacity 2^392 = 38968 p.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 fqu_8p_u2(int i) {   // 8 p, every limb but the top >= 2 * 2^28
+    constexpr u32 m[14] = {0x20000008u, 0x245ffffeu, 0x20000426u, 0x2ea217feu, 0x2000b858u, 0x27dd04a2u, 0x28f79b0fu,
+                           0x207a89c5u, 0x2116cf96u, 0x20a49d8bu, 0x282e0363u, 0x2875631bu, 0x2230be26u, 0x0000d71bu};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_16p_u5(int i) {   // 16 p, every limb but the top >= 5 * 2^28
+    constexpr u32 m[14] = {0x50000010u, 0x58bffffbu, 0x5000084bu, 0x5d442ffbu, 0x500170b0u, 0x5fba0943u, 0x51ef361du,
+                           0x50f5138au, 0x522d9f2bu, 0x51493b15u, 0x505c06c5u, 0x50eac636u, 0x54617c4cu, 0x0001ae35u};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_16p_u4(int i) {   // 16 p, every limb but the top >= 4 * 2^28
+    constexpr u32 m[14] = {0x40000010u, 0x48bffffcu, 0x4000084cu, 0x4d442ffcu, 0x400170b1u, 0x4fba0944u, 0x41ef361eu,
+                           0x40f5138bu, 0x422d9f2cu, 0x41493b16u, 0x405c06c6u, 0x40eac637u, 0x44617c4du, 0x0001ae36u};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_256p(int i) {   // 256 p, every limb but the top >= 1 * 2^28
+    constexpr u32 m[14] = {0x10000100u, 0x1bffffffu, 0x10008507u, 0x1442ffffu, 0x10170b5cu, 0x1ba0947fu, 0x1ef3622eu,
+                           0x1f5138f0u, 0x12d9f2ffu, 0x1493b1a1u, 0x15c06ca0u, 0x1eac63afu, 0x1617c50fu, 0x001ae3a3u};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_128p(int i) {   // 128 p, every limb but the top >= 1 * 2^28
+    constexpr u32 m[14] = {0x10000080u, 0x15ffffffu, 0x10004283u, 0x1a217fffu, 0x100b85adu, 0x1dd04a3fu, 0x1f79b116u,
+                           0x17a89c77u, 0x116cf97fu, 0x1a49d8d0u, 0x12e0364fu, 0x175631d7u, 0x130be287u, 0x000d71d1u};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_64p(int i) {   // 64 p, every limb but the top >= 1 * 2^28
+    constexpr u32 m[14] = {0x10000040u, 0x12ffffffu, 0x10002141u, 0x1510bfffu, 0x1005c2d6u, 0x1ee8251fu, 0x17bcd88au,
+                           0x13d44e3bu, 0x18b67cbfu, 0x1524ec67u, 0x11701b27u, 0x13ab18ebu, 0x1185f143u, 0x0006b8e8u};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_64p_u3(int i) {   // 64 p, every limb but the top >= 3 * 2^28
+    constexpr u32 m[14] = {0x30000040u, 0x32fffffdu, 0x3000213fu, 0x3510bffdu, 0x3005c2d4u, 0x3ee8251du, 0x37bcd888u,
+                           0x33d44e39u, 0x38b67cbdu, 0x3524ec65u, 0x31701b25u, 0x33ab18e9u, 0x3185f141u, 0x0006b8e6u};
+    return m[i];
+}
+__device__ __forceinline__ u32 fqu_32p(int i) {   // 32 p, every limb but the top >= 1 * 2^28
+    constexpr u32 m[14] = {0x10000020u, 0x117fffffu, 0x100010a0u, 0x1a885fffu, 0x1002e16au, 0x1f74128fu, 0x13de6c44u,
+                           0x11ea271du, 0x145b3e5fu, 0x12927633u, 0x10b80d93u, 0x11d58c75u, 0x18c2f8a1u, 0x00035c73u};
+    return m[i];
+}
+
+struct Fq2U {
+    FqU c0, c1;
+};
+__device__ __forceinline__ FqU fqu_add_lazy(const FqU& a, const FqU& b) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+#define FQU_SUBN(NAME, CONST)                                                        \
+    __device__ __forceinline__ FqU NAME(const FqU& a, const FqU& b) {               \
+        FqU r;                                                                       \
+        _Pragma("unroll") for (int i = 0; i < 14; i++) r.l[i] = a.l[i] + (CONST(i) - b.l[i]); \
+        return fqu_normalize(r);                                                     \
+    }
+FQU_SUBN(fqu_subn_32, fqu_32p)
+FQU_SUBN(fqu_subn_64, fqu_64p)
+FQU_SUBN(fqu_subn_128, fqu_128p)
+#undef FQU_SUBN
+
+// (a0 + a1 u)(b0 + b1 u), u^2 = -5: Karatsuba (quadratic_extension.rs:571-583), operands normalised
+__device__ __forceinline__ Fq2U fq2u_mul(const Fq2U& a, const Fq2U& b) {
+    FqU v0 = fqu_mul(a.c0, b.c0);
+    FqU v1 = fqu_mul(a.c1, b.c1);
+    FqU m = fqu_mul(fqu_add_lazy(a.c0, a.c1), fqu_add_lazy(b.c0, b.c1));
+    Fq2U r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.c1.l[i] = m.l[i] + (fqu_8p_u2(i) - v0.l[i] - v1.l[i]);          // m - v0 - v1 + 8p
+        r.c0.l[i] = v0.l[i] + (fqu_16p_u5(i) - 5u * v1.l[i]);             // v0 - 5 v1 + 16p
+    }
+    r.c0 = fqu_normalize(r.c0);
+    r.c1 = fqu_normalize(r.c1);
+    return r;
+}
+// (a0 + a1 u)^2: c0 = (a0 - a1)(a0 + 5 a1) - 4 a0 a1, c1 = 2 a0 a1 (quadratic_extension.rs:257-305 with beta = -5)
+__device__ __forceinline__ Fq2U fq2u_sqr(const Fq2U& a) {
+    FqU d1, d2;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        d1.l[i] = a.c0.l[i] + (fqu_256p(i) - a.c1.l[i]);                  // lazy, limbs < 2^30
+        d2.l[i] = a.c0.l[i] + 5u * a.c1.l[i];
+    }
+    d2 = fqu_normalize(d2);
+    FqU v = fqu_mul(d1, d2);
+    FqU v2 = fqu_mul(a.c0, a.c1);
+    Fq2U r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        r.c0.l[i] = v.l[i] + (fqu_16p_u4(i) - 4u * v2.l[i]);
+        r.c1.l[i] = v2.l[i] + v2.l[i];
+    }
+    r.c0 = fqu_normalize(r.c0);
+    r.c1 = fqu_normalize(r.c1);
+    return r;
+}
+__device__ __forceinline__ bool fqu_low_in(const FqU& a, u32 lo, u32 hi) { return (a.l[0] - lo) <= (hi - lo); }
+
+// In-place XYZZ mixed addition over Fq2U.  Returns false when H == 0 mod p is possible (both components of
+// H = U2 - X1 + 128 p equal j p for some j in (43, 145): low normalised limb == j).
+__device__ __forceinline__ bool fq2u_xyzz_acc_mixed(Fq2U& ax, Fq2U& ay, Fq2U& azz, Fq2U& azzz, const Fq2U& qx, const Fq2U& qy) {
+    Fq2U u2 = fq2u_mul(qx, azz);
+    Fq2U pp{fqu_subn_128(u2.c0, ax.c0), fqu_subn_128(u2.c1, ax.c1)};
+    if (fqu_low_in(pp.c0, 40, 150) && fqu_low_in(pp.c1, 40, 150)) return false;
+    Fq2U s2 = fq2u_mul(qy, azzz);
+    Fq2U r{fqu_subn_64(s2.c0, ay.c0), fqu_subn_64(s2.c1, ay.c1)};
+    Fq2U p2 = fq2u_sqr(pp);
+    azz = fq2u_mul(azz, p2);
+    Fq2U p3 = fq2u_mul(pp, p2);
+    azzz = fq2u_mul(azzz, p3);
+    Fq2U qv = fq2u_mul(ax, p2);
+    Fq2U t = fq2u_sqr(r);
+#pragma unroll
+    for (int i = 0; i < 14; i++) {                                        // X3 = t - p3 - 2 qv + 64 p
+        ax.c0.l[i] = t.c0.l[i] + (fqu_64p_u3(i) - p3.c0.l[i] - qv.c0.l[i] - qv.c0.l[i]);
+        ax.c1.l[i] = t.c1.l[i] + (fqu_64p_u3(i) - p3.c1.l[i] - qv.c1.l[i] - qv.c1.l[i]);
+    }
+    ax.c0 = fqu_normalize(ax.c0);
+    ax.c1 = fqu_normalize(ax.c1);
+    Fq2U d{fqu_subn_128(qv.c0, ax.c0), fqu_subn_128(qv.c1, ax.c1)};
+    Fq2U e = fq2u_mul(r, d);
+    Fq2U f = fq2u_mul(ay, p3);
+    ay.c0 = fqu_subn_32(e.c0, f.c0);
+    ay.c1 = fqu_subn_32(e.c1, f.c1);
+    return true;
+}
+
 }  // namespace czk

@@ -378,10 +378,10 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
         CZK_HIP(ctx, hipFree(jac));
         CZK_HIP(ctx, hipFree(scr));
     }
-    if (GT<F>::AW == 12 && !getenv("CZK_MSM_SAT")) {
-        // G1 tables go to the unsaturated residue system of fqu.h (infinity flags are unaffected); CZK_MSM_SAT=1
-        // keeps the saturated kernel (k_accumulate<Fq>) for A/B runs
-        launch_convert_to_u(ctx->stream, b->pts, (size_t)W * n * 2);
+    if (!getenv("CZK_MSM_SAT") && (GT<F>::AW == 12 || !getenv("CZK_MSM_SAT_G2"))) {
+        // window tables go to the unsaturated residue system of fqu.h (infinity flags are unaffected); CZK_MSM_SAT=1
+        // (or CZK_MSM_SAT_G2=1 for G2 only) keeps the saturated kernels for A/B runs
+        launch_convert_to_u(ctx->stream, b->pts, (size_t)W * n * (GT<F>::AW / 6));
         CZK_HIP(ctx, hipGetLastError());
         CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         b->unsat = true;
@@ -476,6 +476,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
         if (GT<F>::AW == 12 && b->unsat) launch_accumulate_g1_u(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
         else if (GT<F>::AW == 12) launch_accumulate_g1(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+        else if (b->unsat) launch_accumulate_g2_u(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
         else launch_accumulate_g2(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     }
     CZK_HIP(ctx, hipGetLastError());

@@ -67,7 +67,7 @@ __global__ void k_finish(const u64* P, const u64* E, size_t segs, u64* out) {
 }
 
 
-#ifdef CZK_WITH_FQU
+#ifdef CZK_FQU_G1
 // G1 accumulation in the unsaturated residue system (fqu.h): `pts` holds x R' mod p, y R' mod p as canonical
 // 12 x u32 integers (converted at registration).  Buckets leave in the usual saturated XYZZ Montgomery form.
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_u(
@@ -166,12 +166,120 @@ __global__ void k_accumulate_u_cleanup(const u64* pts, size_t B, u64* buckets, c
     }
 }
 
-// one-time conversion of registered G1 window tables: coordinate <- coordinate * R' / R  (canonical integer)
+// one-time conversion of registered window tables (G1 and G2): Fq coordinate <- coordinate * R' / R  (canonical integer)
 __global__ void k_convert_to_u(u64* pts, size_t n_coords) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_coords) return;
     fp_store<FqParams>(pts + 6 * i, fp_mul(fp_load<FqParams>(pts + 6 * i), fqu_k_to_u()));
 }
+#endif
+#ifdef CZK_FQU_G2
+// ---- G2: the same three kernels over Fq2U / Fq2 ---------------------------------------------------------------
+__device__ __forceinline__ Fq2U fq2u_load(const u64* p) {
+    return Fq2U{fqu_unpack(fp_load<FqParams>(p)), fqu_unpack(fp_load<FqParams>(p + 6))};
+}
+__device__ __forceinline__ Fq2 fq2u_to_sat(const Fq2U& a) {
+    const Fq kf = fqu_k_from_u();
+    return Fq2{fp_mul(fqu_pack(a.c0), kf), fp_mul(fqu_pack(a.c1), kf)};
+}
+__device__ __forceinline__ Fq2 fq2_from_table_u(const u64* p) {   // table coordinate (x R' mod p) -> saturated Montgomery
+    const Fq kf = fqu_k_from_u();
+    return Fq2{fp_mul(fp_load<FqParams>(p), kf), fp_mul(fp_load<FqParams>(p + 6), kf)};
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_u2(
+    const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets,
+    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const unsigned lane = blockIdx.y;
+    const size_t b = perm[(size_t)lane * B + t];
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
+    Fq2U ax, ay, azz, azzz;
+    bool inf = true;
+    for (u32 e = 0; e < cnt; e++) {
+        u32 code = srt[off + e];
+        const u64* pp = pts + (size_t)24 * (code & 0x7fffffffu);
+        Fq2U qx = fq2u_load(pp), qy = fq2u_load(pp + 12);
+        if (code & 0x80000000u) {
+#pragma unroll
+            for (int i = 0; i < 14; i++) {
+                qy.c0.l[i] = fqu_4p(i) - qy.c0.l[i];
+                qy.c1.l[i] = fqu_4p(i) - qy.c1.l[i];
+            }
+            qy.c0 = fqu_normalize(qy.c0);
+            qy.c1 = fqu_normalize(qy.c1);
+        }
+        if (inf) {
+            ax = qx;
+            ay = qy;
+            azz = Fq2U{fqu_one(), FqU{}};
+#pragma unroll
+            for (int i = 0; i < 14; i++) azz.c1.l[i] = 0;
+            azzz = azz;
+            inf = false;
+            continue;
+        }
+        if (!fq2u_xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy)) {
+            u32 slot = atomicAdd(exc_count, 1u);
+            if (slot < exc_cap) {
+                exc_list[3 * slot] = lane;
+                exc_list[3 * slot + 1] = (u32)b;
+                exc_list[3 * slot + 2] = code;
+                continue;
+            }
+            dirty[(size_t)lane * B + b] = 1;
+            return;
+        }
+    }
+    XYZZ<Fq2> out = XYZZ<Fq2>::zero();
+    if (!inf) {
+        out.x = fq2u_to_sat(ax);
+        out.y = fq2u_to_sat(ay);
+        out.zz = fq2u_to_sat(azz);
+        out.zzz = fq2u_to_sat(azzz);
+    }
+    xyzz_store<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), out);
+}
+
+__global__ __launch_bounds__(128) void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+                                                          size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned lane = blockIdx.y;
+    if (!dirty[(size_t)lane * B + b]) return;
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
+    Fq2 ax = Fq2::one(), ay = Fq2::one(), azz = Fq2::zero(), azzz = Fq2::zero();
+    for (u32 e = 0; e < cnt; e++) {
+        u32 code = srt[off + e];
+        const u64* pp = pts + (size_t)24 * (code & 0x7fffffffu);
+        Fq2 qx = fq2_from_table_u(pp), qy = fq2_from_table_u(pp + 12);
+        if (code & 0x80000000u) qy = f_neg(qy);
+        xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy);
+    }
+    xyzz_store<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), XYZZ<Fq2>{ax, ay, azz, azzz});
+}
+
+__global__ void k_accumulate_u2_cleanup(const u64* pts, size_t B, u64* buckets, const uint8_t* dirty, const u32* exc_count, const u32* exc_list,
+                                        u32 exc_cap) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    u32 n = *exc_count;
+    if (n > exc_cap) n = exc_cap;
+    for (u32 k = 0; k < n; k++) {
+        u32 lane = exc_list[3 * k], b = exc_list[3 * k + 1], code = exc_list[3 * k + 2];
+        if (dirty[(size_t)lane * B + b]) continue;
+        u64* slot = buckets + (size_t)48 * ((size_t)lane * B + b);
+        XYZZ<Fq2> acc = xyzz_load<Fq2>(slot);
+        const u64* pp = pts + (size_t)24 * (code & 0x7fffffffu);
+        Fq2 qx = fq2_from_table_u(pp), qy = fq2_from_table_u(pp + 12);
+        if (code & 0x80000000u) qy = f_neg(qy);
+        xyzz_acc_mixed(acc.x, acc.y, acc.zz, acc.zzz, qx, qy);
+        xyzz_store<Fq2>(slot, acc);
+    }
+}
+
 #endif
 
 // G2 variant: one bucket per lane PAIR (fq2p.h).  Same algorithm, same memory formats.

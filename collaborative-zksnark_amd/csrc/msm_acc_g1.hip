@@ -1,5 +1,5 @@
 // msm_acc_g1.hip -- bucket accumulation kernel instantiated for G1 (base field Fq).
-#define CZK_WITH_FQU 1
+#define CZK_FQU_G1 1
 #include "fqu.h"
 #include "msm_acc.h"
 
