@@ -140,10 +140,10 @@ void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u
 // implemented in msm_acc_g1.hip / msm_acc_g2.hip (hot kernels, built with the multiply inlined)
 void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);
-void launch_accumulate_g1_u(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords);
-void launch_accumulate_g2_u(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+void launch_accumulate_g2_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);

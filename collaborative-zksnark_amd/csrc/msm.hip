@@ -472,11 +472,13 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (!scalars_stable) CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
     CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
-    {
+    if (b->unsat) {
+        // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
+        if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else launch_accumulate_g2_u(ctx, sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+    } else {
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
-        if (GT<F>::AW == 12 && b->unsat) launch_accumulate_g1_u(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
-        else if (GT<F>::AW == 12) launch_accumulate_g1(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
-        else if (b->unsat) launch_accumulate_g2_u(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        if (GT<F>::AW == 12) launch_accumulate_g1(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
         else launch_accumulate_g2(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     }
     CZK_HIP(ctx, hipGetLastError());

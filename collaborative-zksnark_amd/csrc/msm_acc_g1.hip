@@ -9,15 +9,18 @@ void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, con
     hipLaunchKernelGGL(k_accumulate<Fq>, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
                        sorted_stride, buckets);
 }
-void launch_accumulate_g1_u(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty) {
     // workspace behind the dirty flags: [count][list of EXC_CAP x 3 u32]
     constexpr u32 EXC_CAP = 4096;
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
     (void)hipMemsetAsync(dirty, 0, flags + 16, st);
-    hipLaunchKernelGGL(k_accumulate_u, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                       sorted_stride, buckets, dirty, exc, exc + 4, EXC_CAP);
+    {
+        ProfScope ps(ctx, "msm_accumulate_g1", st);   // brackets the dominant kernel only
+        hipLaunchKernelGGL(k_accumulate_u, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
+                           sorted_stride, buckets, dirty, exc, exc + 4, EXC_CAP);
+    }
     hipLaunchKernelGGL(k_accumulate_u_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
                        sorted_stride, buckets, dirty);
     hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, EXC_CAP);
