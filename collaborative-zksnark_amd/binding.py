@@ -220,6 +220,26 @@ class Context:
         self._ck(lib().czk_jac_to_affine(self._h, C.c_int(group), _ptr(jac), C.c_size_t(n), _ptr(aff), _ptr(inf)))
         return aff, inf
 
+    def jac_add(self, group, a, b):
+        jw = 18 if group == CZK_G1 else 36
+        a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
+        out = np.zeros(jw, dtype=np.uint64)
+        self._ck(lib().czk_jac_add(self._h, C.c_int(group), _ptr(a), _ptr(b), _ptr(out)))
+        return out
+
+    def jac_add_mixed(self, group, a, b_aff, b_inf=False):
+        jw = 18 if group == CZK_G1 else 36
+        a, b_aff = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b_aff, np.uint64)
+        out = np.zeros(jw, dtype=np.uint64)
+        self._ck(lib().czk_jac_add_mixed(self._h, C.c_int(group), _ptr(a), _ptr(b_aff), C.c_int(int(b_inf)), _ptr(out)))
+        return out
+
+    def fr_spdz_open(self, shares_ptr, parties: int, n: int, out_value_ptr) -> int:
+        """Local part of SpdzFieldShare::batch_open on device buffers; returns the number of failed MAC checks."""
+        bad = C.c_uint64(0)
+        self._ck(lib().czk_fr_spdz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(out_value_ptr), C.byref(bad)))
+        return bad.value
+
     def fixed_base_points(self, group, k, out=None, n=None, mem=CZK_MEM_HOST):
         aw = 12 if group == CZK_G1 else 24
         if mem == CZK_MEM_HOST:

@@ -112,9 +112,56 @@ static void host_jac_to_affine(const u64* jac, size_t n, u64* out_aff, uint8_t* 
     }
 }
 
+template <class F>
+static void load_jac(const u64* p, Jac<F>& j) {
+    constexpr int W = FieldIO<F>::W64;
+    limbs_to_field<F>(p, j.x);
+    limbs_to_field<F>(p + W, j.y);
+    limbs_to_field<F>(p + 2 * W, j.z);
+}
+template <class F>
+static void store_jac(const Jac<F>& j, u64* p) {
+    constexpr int W = FieldIO<F>::W64;
+    field_to_limbs(j.x, p);
+    field_to_limbs(j.y, p + W);
+    field_to_limbs(j.z, p + 2 * W);
+}
+template <class F>
+static void host_jac_add(const u64* a, const u64* b, u64* out) {
+    Jac<F> x, y;
+    load_jac<F>(a, x);
+    load_jac<F>(b, y);
+    store_jac<F>(jac_add(x, y), out);
+}
+template <class F>
+static void host_jac_add_mixed(const u64* a, const u64* b_aff, bool b_inf, u64* out) {
+    constexpr int W = FieldIO<F>::W64;
+    Jac<F> x;
+    load_jac<F>(a, x);
+    Affine<F> q;
+    limbs_to_field<F>(b_aff, q.x);
+    limbs_to_field<F>(b_aff + W, q.y);
+    store_jac<F>(jac_add_mixed(x, q, b_inf), out);
+}
+
 }  // namespace czk
 
 using namespace czk;
+
+extern "C" int czk_jac_add(czk_ctx* ctx, int group, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    if (!a || !b || !out) return set_err(ctx, CZK_ERR_ARG, "null jac_add argument");
+    if (group == CZK_G1) host_jac_add<Fq>(a, b, out);
+    else if (group == CZK_G2) host_jac_add<Fq2>(a, b, out);
+    else return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    return CZK_OK;
+}
+extern "C" int czk_jac_add_mixed(czk_ctx* ctx, int group, const uint64_t* a, const uint64_t* b_aff, int b_inf, uint64_t* out) {
+    if (!a || !b_aff || !out) return set_err(ctx, CZK_ERR_ARG, "null jac_add_mixed argument");
+    if (group == CZK_G1) host_jac_add_mixed<Fq>(a, b_aff, b_inf != 0, out);
+    else if (group == CZK_G2) host_jac_add_mixed<Fq2>(a, b_aff, b_inf != 0, out);
+    else return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    return CZK_OK;
+}
 
 extern "C" const char* czk_version(void) { return "czk-mi355x 0.1 (gfx950)"; }
 

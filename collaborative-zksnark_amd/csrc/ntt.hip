@@ -244,6 +244,22 @@ __global__ void k_repr(int to_mont, const u64* a, u64* out, size_t n) {
     }
 }
 
+// SpdzFieldShare::batch_open, local part (share/spdz.rs:166-185): value = sum of the parties' sh lanes; the MAC
+// check sum_p (mac_share_p * value - mac_p) must vanish; non-zero entries are counted
+__global__ void k_spdz_open(const u64* shares, size_t parties, size_t n, u64* out_value, unsigned long long* bad) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        Fr v = gfr_load(shares, i);                       // party 0, sh lane
+        Fr chk = fp_neg(gfr_load(shares + 4 * n, i));     // - mac_0
+        for (size_t p = 1; p < parties; p++) {
+            v = fp_add(v, gfr_load(shares + 4 * n * (2 * p), i));
+            chk = fp_sub(chk, gfr_load(shares + 4 * n * (2 * p + 1), i));
+        }
+        chk = fp_add(chk, v);                             // + mac_share_0 * value, mac_share_0 = 1 (king)
+        gfr_store(out_value, i, v);
+        if (!chk.is_zero()) atomicAdd(bad, 1ull);
+    }
+}
+
 static unsigned grid_for(czk_ctx* ctx, size_t n) {
     size_t blocks = (n + 255) / 256;
     size_t cap = (size_t)ctx->num_cu * 8;
@@ -514,6 +530,24 @@ extern "C" int czk_fr_beaver_combine(czk_ctx* ctx, const uint64_t* x, const uint
                        (const u64*)s3.dev, (const u64*)s4.dev, add_open, (u64*)so.dev, n);
     CZK_HIP(ctx, hipGetLastError());
     return so.to_host(out, n * 32);
+}
+
+extern "C" int czk_fr_spdz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t n, uint64_t* out_value, uint64_t* out_bad) {
+    if (!ctx || !out_bad || (n && (!shares || !out_value)) || parties == 0) return ctx ? set_err(ctx, CZK_ERR_ARG, "bad spdz_open argument") : CZK_ERR_ARG;
+    *out_bad = 0;
+    if (!n) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long* bad = nullptr;
+    CZK_HIP(ctx, hipMalloc(&bad, 8));
+    CZK_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_spdz_open, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (const u64*)shares, parties, n, (u64*)out_value, bad);
+    CZK_HIP(ctx, hipGetLastError());
+    unsigned long long hb = 0;
+    CZK_HIP(ctx, hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CZK_HIP(ctx, hipFree(bad));
+    *out_bad = hb;
+    return CZK_OK;
 }
 
 static int repr_common(czk_ctx* ctx, int to_mont, const uint64_t* a, uint64_t* out, size_t n, int mem) {

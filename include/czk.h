@@ -99,6 +99,14 @@ int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_
  * (king for the sh lane, mac_share != 0 for the mac lane; share/spdz.rs:31-37,204-208). */
 int czk_fr_beaver_combine(czk_ctx* ctx, const uint64_t* x, const uint64_t* y, const uint64_t* z, const uint64_t* sx,
                           const uint64_t* oy, int add_open, uint64_t* out, size_t n, int mem);
+/* Local arithmetic of SpdzFieldShare::batch_open (mpc-algebra/src/share/spdz.rs:166-185) once every party's shares
+ * are on this GPU (parties as lanes, or after the all-gather of mpc-net's broadcast):
+ *   shares: parties x 2 x n Fr (party-major; lane 0 = sh, lane 1 = mac), DEVICE memory
+ *   value[i]  = sum_p sh_p[i]                                             -> out_value (n Fr, device)
+ *   check[i]  = sum_p (mac_share_p * value[i] - mac_p[i]),  mac_share_p = (p == 0)   (spdz.rs:31-37, :176-183)
+ * *out_bad (host) receives the number of i with check[i] != 0 (the reference asserts it is 0). */
+int czk_fr_spdz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t n, uint64_t* out_value, uint64_t* out_bad);
+
 /* Fr::into_repr / from_repr over a vector (fields/arithmetic.rs:59-81, macros.rs:443-454) -- also the wire format. */
 int czk_fr_into_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
 int czk_fr_from_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
@@ -138,6 +146,12 @@ int czk_msm_g2(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const
  * n host affine points + infinity flags.  This is what AffineMsm::msm's `.into()` does (share/msm.rs:31-37).
  * Host-side arithmetic (one inversion per point); `ctx` may be NULL. */
 int czk_jac_to_affine(czk_ctx* ctx, int group, const uint64_t* jac, size_t n, uint64_t* out_aff, uint8_t* out_inf);
+
+/* GroupProjective += (add_assign, short_weierstrass_jacobian.rs:666-728) and += affine (add_assign_mixed, :570-638) on
+ * host Jacobian values: the O(1) group steps around the MSMs (calculate_coeff, prover.rs:216-232; KZG10::commit's
+ * `commitment.add_assign_mixed(&random_commitment)`, poly-commit/src/kzg10/mod.rs:188).  Host arithmetic; ctx may be NULL. */
+int czk_jac_add(czk_ctx* ctx, int group, const uint64_t* a_jac, const uint64_t* b_jac, uint64_t* out_jac);
+int czk_jac_add_mixed(czk_ctx* ctx, int group, const uint64_t* a_jac, const uint64_t* b_aff, int b_inf, uint64_t* out_jac);
 
 /* Synthetic public bases P_i = [k_i] * generator for i < n, k_i = canonical scalars (n x 4 u64), written as
  * affine Montgomery points to `out` (device or host).  Stands in for a trusted-setup run when benchmarking

@@ -233,6 +233,25 @@ struct SpdzGroupShareG1 {
     }
 };
 
+// poly-commit/src/kzg10/mod.rs:141-193 -- KZG10::commit for a single prover: MSM over powers_of_g plus, when hiding, an
+// MSM over powers_of_gamma_g joined with add_assign_mixed (Marlin / Plonk reach the MSM kernel through this).
+struct KZG10 {
+    static G1Projective commit(const G1Bases& powers_of_g, const std::vector<Fr>& coeffs, const G1Bases* powers_of_gamma_g = nullptr,
+                               const std::vector<Fr>* blinding_coeffs = nullptr) {
+        if (coeffs.size() > powers_of_g.len()) throw Panic(CZK_ERR_SIZE, "TooManyCoefficients (check_degree_is_too_large)");
+        G1Projective commitment = G1Affine::multi_scalar_mul(powers_of_g, coeffs);
+        if (powers_of_gamma_g && blinding_coeffs) {
+            G1Projective random_commitment = G1Affine::multi_scalar_mul(*powers_of_gamma_g, *blinding_coeffs);
+            uint64_t aff[12];
+            uint8_t inf = 0;
+            const Context& ctx = powers_of_g.ctx();
+            ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, random_commitment.x.l, 1, aff, &inf));     // .into_affine()
+            ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, commitment.x.l, aff, inf, commitment.x.l));  // add_assign_mixed
+        }
+        return commitment;
+    }
+};
+
 // mpc-snarks/src/groth/r1cs_to_qap.rs:47-113 -- the NTT / pointwise sequence of witness_map for a single prover
 // (T = Fr).  `a`, `b`, `c` are the evaluated constraint rows (a[0..N), then the instance copy; :67-83, :95-100).
 // `batch_product` is F::batch_product_in_place (:92) -- a plain product here, the Beaver protocol for shares.

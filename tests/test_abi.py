@@ -93,3 +93,17 @@ def test_host_side_field_code_matches_checker(orc):
         for i in range(n):
             want, winf = orc.jac_to_affine(g, jac[i])
             assert bool(inf[i]) == winf and (winf or np.array_equal(aff[i], want)), (g, i)
+        # czk_jac_add / czk_jac_add_mixed (host group law) against the checker, incl. doubling and infinity operands
+        L = czk_amd.lib()
+        pv = lambda a: a.ctypes.data_as(C.c_void_p)
+        for i, j in ((0, 1), (2, 2), (3, n - 1), (n - 1, 4)):
+            out = np.zeros(3 * width, dtype=np.uint64)
+            assert L.czk_jac_add(None, C.c_int(g), pv(jac[i]), pv(jac[j]), pv(out)) == 0
+            w1, i1 = orc.jac_to_affine(g, orc.jac_add(g, jac[i], jac[j]))
+            w2, i2 = orc.jac_to_affine(g, out)
+            assert i1 == i2 and (i1 or np.array_equal(w1, w2)), (g, i, j)
+            a_aff, a_inf = orc.jac_to_affine(g, jac[j])
+            out2 = np.zeros(3 * width, dtype=np.uint64)
+            assert L.czk_jac_add_mixed(None, C.c_int(g), pv(jac[i]), pv(a_aff), C.c_int(int(a_inf)), pv(out2)) == 0
+            w3, i3 = orc.jac_to_affine(g, out2)
+            assert i1 == i3 and (i1 or np.array_equal(w1, w3)), (g, i, j)

@@ -359,3 +359,45 @@ def test_msm_adversarial_equal_and_opposite_bases(ctx, czk, orc, g):
     got = ctx.msm(b, scal, lanes=1)
     assert _same_point(ctx, orc, g, got[0], orc.msm(g, bases, inf, scal))
     b.release()
+
+
+def test_spdz_open_with_mac_check(ctx, czk, orc):
+    """czk_fr_spdz_open: the local arithmetic of SpdzFieldShare::batch_open (share/spdz.rs:166-185) with all parties'
+    shares on the GPU; a corrupted MAC share must be counted."""
+    import torch
+    n, parties = 5000, 3
+    secret = orc.fr_from_repr(rand_fr_canonical(61, n))
+    sh = [orc.fr_from_repr(rand_fr_canonical(62 + p, n)) for p in range(parties - 1)]
+    last = secret.copy()
+    for s_ in sh:
+        last = orc.fr_sub(last, s_)
+    sh.append(last)
+    lanes = np.stack([np.stack([s_, s_]) for s_ in sh])          # mac share = sh * mac(), mac() = 1 (spdz.rs:41-47)
+    t = torch.from_numpy(lanes.view(np.int64).copy()).cuda()
+    out = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    assert ctx.fr_spdz_open(t.data_ptr(), parties, n, out.data_ptr()) == 0
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), secret)
+    t[1, 1, 17, 0] += 1                                           # party 1 tampers with one MAC share
+    assert ctx.fr_spdz_open(t.data_ptr(), parties, n, out.data_ptr()) == 1
+
+
+def test_kzg10_commit_matches_reference_composition(ctx, czk, orc):
+    """KZG10::commit (poly-commit/src/kzg10/mod.rs:141-193): MSM over powers_of_g, hiding MSM over powers_of_gamma_g,
+    into_affine + add_assign_mixed -- composed from the C ABI exactly as include/czk.hpp's KZG10::commit does."""
+    deg, hid = 700, 3
+    _, pg = _bases(ctx, 1, deg + 1, 71)
+    _, pgg = _bases(ctx, 1, hid + 2, 72)
+    coeffs = orc.fr_from_repr(rand_fr_canonical(73, deg + 1))
+    blind = orc.fr_from_repr(rand_fr_canonical(74, hid + 2))
+    bg, bgg = ctx.register_bases(1, pg, None), ctx.register_bases(1, pgg, None)
+    c = ctx.msm(bg, coeffs, scalar_form=czk.CZK_SCALAR_MONTGOMERY)[0]
+    rc = ctx.msm(bgg, blind, scalar_form=czk.CZK_SCALAR_MONTGOMERY)[0]
+    rc_aff, rc_inf = ctx.jac_to_affine(1, rc)
+    got = ctx.jac_add_mixed(1, c, rc_aff[0], bool(rc_inf[0]))
+    z = np.zeros(deg + 1, dtype=np.uint8)
+    want_c = orc.multi_scalar_mul(1, pg, z, coeffs)
+    want_r, want_rinf = orc.jac_to_affine(1, orc.multi_scalar_mul(1, pgg, z[: hid + 2], blind))
+    want = orc.jac_add_mixed(1, want_c, want_r, want_rinf)
+    assert _same_point(ctx, orc, 1, got, want)
+    bg.release()
+    bgg.release()

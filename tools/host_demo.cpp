@@ -87,6 +87,18 @@ int main() {
     ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, both[0].x.l, 2, a2, i2));
     REQUIRE(memcmp(a2, a2 + 12, 96) == 0 && memcmp(a2, &pts[12 * n], 96) == 0);
 
+    // KZG10::commit: commitment to the all-ones polynomial with an all-ones blinding polynomial over the same powers
+    // = 2 * [n(n+1)/2] G
+    {
+        G1Projective cm = KZG10::commit(bases, ones, &bases, &ones);
+        std::vector<uint64_t> k2(4, 0);
+        k2[0] = n * (n + 1);
+        uint64_t want[12];
+        ctx.check(czk_fixed_base_points(ctx.raw(), CZK_G1, k2.data(), 1, want, CZK_MEM_HOST));
+        ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, cm.x.l, 1, aff, &inf));
+        REQUIRE(!inf && memcmp(aff, want, 96) == 0);
+    }
+
     // witness map of the 6-constraint squaring circuit (proof.rs:304-344): quotient is exact => h[D-1] == 0
     const size_t N = 6;
     auto d8 = Radix2EvaluationDomain::create(ctx, N + 2);
