@@ -142,7 +142,7 @@ __global__ __launch_bounds__(128) void k_batch_to_affine(const u64* jac, size_t 
 // ------------------------------------------------------------------------------------------------
 // digits[(lane*W + w)*size + i] = 0 (skip) or |d| | sign<<31, d in [-2^(c-1), 2^(c-1)].
 __global__ void k_digits(const u64* scalars, size_t n_scalars, size_t size, int montgomery, unsigned c, unsigned W,
-                         const uint8_t* inf, size_t n_bases, u32* digits, u32* counts, size_t B) {
+                         const uint8_t* inf, size_t n_bases, u32* digits, u32* ranks, u32* counts, size_t B) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= size) return;
     const unsigned lane = blockIdx.y;
@@ -170,11 +170,12 @@ __global__ void k_digits(const u64* scalars, size_t n_scalars, size_t size, int 
         if (inf[(size_t)w * n_bases + i]) code = 0;   // add_assign_mixed skips infinity (short_weierstrass_jacobian.rs:571-573)
         if ((code & 0x7fffffffu) == 0) code = 0;
         digits[((size_t)lane * W + w) * size + i] = code;
-        if (code) atomicAdd(&counts[(size_t)lane * B + (code & 0x7fffffffu) - 1], 1u);
+        // the histogram atomic also hands out the entry's rank inside its bucket, so the scatter needs no second atomic
+        if (code) ranks[((size_t)lane * W + w) * size + i] = atomicAdd(&counts[(size_t)lane * B + (code & 0x7fffffffu) - 1], 1u);
     }
 }
 
-// exclusive scan of counts[lane][0..B) -> offsets, and zero counts (reused as scatter cursors).  Three phases:
+// exclusive scan of counts[lane][0..B) -> offsets.  Three phases:
 // per-tile sums (tile = 2048 entries), scan of the tile sums (one block per lane), per-tile exclusive scan.
 constexpr unsigned SCAN_TILE = 2048;
 __global__ __launch_bounds__(256) void k_scan_tile_sums(const u32* counts, size_t B, u32* tile_sums, size_t n_tiles) {
@@ -243,16 +244,13 @@ __global__ __launch_bounds__(256) void k_scan_apply(u32* counts, u32* offsets, s
 #pragma unroll
     for (unsigned k = 0; k < PER; k++) {
         unsigned i = tid * PER + k;
-        if (i < lim) {
-            off[i] = run;
-            cnt[i] = 0;
-        }
+        if (i < lim) off[i] = run;
         run += v[k];
     }
 }
 
 // sorted[lane][offsets[b] + k] = (w * n_bases + i) | sign<<31
-__global__ void k_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* offsets, u32* cursors, size_t B,
+__global__ void k_scatter(const u32* digits, const u32* ranks, size_t size, unsigned W, size_t n_bases, const u32* offsets, size_t B,
                           u32* sorted) {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)W * size) return;
@@ -261,7 +259,7 @@ __global__ void k_scatter(const u32* digits, size_t size, unsigned W, size_t n_b
     if (!code) return;
     size_t w = e / size, i = e - w * size;
     size_t b = (code & 0x7fffffffu) - 1;
-    u32 pos = offsets[(size_t)lane * B + b] + atomicAdd(&cursors[(size_t)lane * B + b], 1u);
+    u32 pos = offsets[(size_t)lane * B + b] + ranks[(size_t)lane * W * size + e];
     sorted[(size_t)lane * W * size + pos] = (u32)(w * n_bases + i) | (code & 0x80000000u);
 }
 
@@ -411,7 +409,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
-    size_t need_sort = lanes * ((size_t)W * size * 4 * 2 + B * 4 * 4 + CNT_BINS * 4) + (1 << 16);
+    size_t need_sort = lanes * ((size_t)W * size * 4 * 3 + B * 4 * 4 + CNT_BINS * 4) + (1 << 16);
     size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B) + (1 << 17);
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
         CZK_TRY(msm_pipeline_sync(ctx));
@@ -421,6 +419,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     Bump bs{(char*)slot.ws_sort.p};
     u32* digits = bs.take<u32>(lanes * W * size);
     u32* sorted = bs.take<u32>(lanes * W * size);
+    u32* ranks = bs.take<u32>(lanes * W * size);
     u32* counts = bs.take<u32>(lanes * B);
     u32* offsets = bs.take<u32>(lanes * B);
     u32* perm = bs.take<u32>(lanes * B);
@@ -453,14 +452,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
         if (size) {
             hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
-                               form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, counts, B);
+                               form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, ranks, counts, B);
         }
         hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, B, tile_sums, n_tiles);
         hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)lanes), dim3(1024), 0, ss, tile_sums, n_tiles);
         hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, offsets, B, tile_sums, n_tiles);
         if (size) {
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, digits, size, W,
-                               b->n, offsets, counts, B, sorted);
+            hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, digits, ranks, size, W,
+                               b->n, offsets, B, sorted);
         }
         CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
         hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
