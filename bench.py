@@ -102,6 +102,8 @@ class Groth16Local:
         def lanes_buf():
             return torch.zeros((L, D, 4), dtype=torch.int64, device=dev)
         # a_i = b_i = w_i, c_i = w_{i+1} for i < N; a[N] = 1 (king only: Public lifted per SURVEY a18), a[N+1] = out
+        # (a0, b0, c0 are written out directly here as the EXPECTED constraint evaluations: step() computes them on the GPU
+        # from `full` with czk_r1cs_matvec; the parity test and the integrity check compare against these)
         self.a0, self.b0, self.c0 = lanes_buf(), lanes_buf(), lanes_buf()
         self.wit = torch.zeros((L, N, 4), dtype=torch.int64, device=dev)          # l-MSM scalars: witness
         self.asg = torch.zeros((L, N + 1, 4), dtype=torch.int64, device=dev)      # a/b-MSM scalars: [out, witness]
@@ -117,6 +119,22 @@ class Groth16Local:
                 self.wit[ln] = sh[p][:N]
                 self.asg[ln, 0] = sh[p][N]
                 self.asg[ln, 1:] = sh[p][:N]
+        # full assignment [1, out | w_0 .. w_{N-1}] per lane (r1cs_to_qap.rs:56-61); Public(1) lifted to the king's lanes
+        self.full = torch.zeros((L, N + 2, 4), dtype=torch.int64, device=dev)
+        for p in range(parties):
+            for m in range(2):
+                ln = 2 * p + m
+                if p == 0:
+                    self.full[ln, 0] = one_t
+                self.full[ln, 1] = sh[p][N]
+                self.full[ln, 2:] = sh[p][:N]
+        # the squaring circuit's matrices (proof.rs:304-344): a_i = b_i = w_i, c_i = w_{i+1} (c_{N-1} = out), all coefficients 1
+        ones = np.tile(one, (N + 2, 1))
+        rp = np.arange(N + 3, dtype=np.uint64)
+        wcols = np.arange(2, N + 2, dtype=np.uint32)
+        self.mat_a = ctx.r1cs_matrix_register(rp, np.concatenate([wcols, np.array([0, 1], dtype=np.uint32)]), ones, N + 2)
+        self.mat_b = ctx.r1cs_matrix_register(rp[: N + 1], wcols, ones[:N], N + 2)
+        self.mat_c = ctx.r1cs_matrix_register(rp[: N + 1], np.concatenate([wcols[1:], np.array([1], dtype=np.uint32)]), ones[:N], N + 2)
         # dummy Beaver triples (wire/field.rs:41-60): king holds (1,1,1), everyone else (0,0,0)
         self.tx, self.ty, self.tz = lanes_buf(), lanes_buf(), lanes_buf()
         for t in (self.tx, self.ty, self.tz):
@@ -163,9 +181,14 @@ class Groth16Local:
         ctx.msm_async(self.l_query, self.wit.data_ptr(), N, L, MONT, r["l"], stable=True)
         ctx.msm_async(self.a_query, self.asg.data_ptr(), N + 1, L, MONT, r["a"], stable=True)
         ctx.msm_async(self.b_g1_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g1"], stable=True)
-        self.a.copy_(self.a0); self.b.copy_(self.b0); self.c.copy_(self.c0)   # fresh inputs (in-place transforms)
         # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
-        ctx.witness_map_pre(self.a.data_ptr(), self.b.data_ptr(), ld, L)       # ifft, ifft, coset_fft, coset_fft
+        # constraint evaluation <A_i, z>, <B_i, z>, <C_i, z> over the share lanes of the full assignment (r1cs_to_qap.rs:
+        # 67-83, 95-100); A carries the two instance-copy rows (:79-83).  Rows beyond each matrix are zero padding that the
+        # first NTT pass supplies itself, so nothing is cleared or copied.
+        ctx.r1cs_matvec(self.mat_a, self.full.data_ptr(), lanes=L, out=self.a.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.r1cs_matvec(self.mat_b, self.full.data_ptr(), lanes=L, out=self.b.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.r1cs_matvec(self.mat_c, self.full.data_ptr(), lanes=L, out=self.c.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.witness_map_pre(self.a.data_ptr(), self.b.data_ptr(), ld, L, a_len=N + 2, b_len=N)   # ifft, ifft, coset_fft, coset_fft
         # batch_product_in_place -> S::batch_mul (share/field.rs:97-127): (s + x), (o + y), two opens, combine
         ctx.fr_vec_op(ADD, self.a.data_ptr(), self.tx.data_ptr(), out=self.a.data_ptr(), n=L * D, mem=M)
         ctx.fr_vec_op(ADD, self.b.data_ptr(), self.ty.data_ptr(), out=self.b.data_ptr(), n=L * D, mem=M)
@@ -174,7 +197,7 @@ class Groth16Local:
         for ln in range(L):
             ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
                                   self.oy.data_ptr(), ln < 2, out=self.ab[ln].data_ptr(), n=D, mem=M)
-        ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L)     # h = ab
+        ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L, c_len=N)     # h = ab
         # --- the h MSM (prover.rs:104) needs the witness map's output; NOT flagged stable: the next proof's witness
         # map overwrites `ab`, so the context's stream waits for this MSM's digit extraction (library-side ordering)
         ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"])

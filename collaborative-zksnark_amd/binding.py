@@ -240,6 +240,41 @@ class Context:
         self._ck(lib().czk_fr_spdz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(out_value_ptr), C.byref(bad)))
         return bad.value
 
+    def r1cs_matrix_register(self, row_ptr, col_idx, coeff, n_vars: int, mem=CZK_MEM_HOST, m=None, nnz=None) -> "R1csMatrix":
+        """One of ConstraintMatrices::{a, b, c} in CSR form (host numpy arrays, or device pointers with m / nnz given)."""
+        if mem == CZK_MEM_HOST:
+            row_ptr = np.ascontiguousarray(row_ptr, np.uint64)
+            col_idx = np.ascontiguousarray(col_idx, np.uint32)
+            coeff = np.ascontiguousarray(coeff, np.uint64)
+            m, nnz = row_ptr.size - 1, col_idx.size
+        h = C.c_void_p(0)
+        self._ck(lib().czk_r1cs_matrix_register(self._h, _ptr(row_ptr), _ptr(col_idx), _ptr(coeff), C.c_size_t(m), C.c_size_t(nnz),
+                                                C.c_size_t(n_vars), C.c_int(mem), C.byref(h)))
+        return R1csMatrix(self, h, m, n_vars)
+
+    def r1cs_matvec(self, mat: "R1csMatrix", z, lanes: int = 1, out=None, z_stride=None, out_stride=None, mem=CZK_MEM_HOST):
+        """evaluate_constraint over every row and lane; host mode returns (lanes, m, 4)."""
+        if mem == CZK_MEM_HOST:
+            z = np.ascontiguousarray(z, np.uint64).reshape(lanes, -1, 4)
+            z_stride = z.shape[1]
+            out_stride = mat.m
+            out = np.zeros((lanes, mat.m, 4), dtype=np.uint64)
+        self._ck(lib().czk_r1cs_matvec(self._h, mat._h, _ptr(z), C.c_size_t(z_stride), C.c_size_t(lanes), _ptr(out), C.c_size_t(out_stride), C.c_int(mem)))
+        return out
+
+    def poly_div_linear(self, coeffs, z, lanes: int = 1, n=None, quotient=None, remainder=None, mem=CZK_MEM_HOST):
+        """coeffs / (X - z) per lane; host mode returns (quotient (lanes, n-1, 4), remainder (lanes, 4))."""
+        z = np.ascontiguousarray(z, np.uint64).reshape(4)
+        if mem == CZK_MEM_HOST:
+            coeffs = np.ascontiguousarray(coeffs, np.uint64).reshape(lanes, -1, 4)
+            n = coeffs.shape[1]
+            quotient = np.zeros((lanes, max(n - 1, 0), 4), dtype=np.uint64)
+            remainder = np.zeros((lanes, 4), dtype=np.uint64)
+        qp = quotient if not (isinstance(quotient, np.ndarray) and quotient.size == 0) else None
+        cp = coeffs if not (isinstance(coeffs, np.ndarray) and coeffs.size == 0) else None
+        self._ck(lib().czk_poly_div_linear(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(qp), _ptr(remainder), C.c_int(mem)))
+        return quotient, remainder
+
     def fixed_base_points(self, group, k, out=None, n=None, mem=CZK_MEM_HOST):
         aw = 12 if group == CZK_G1 else 24
         if mem == CZK_MEM_HOST:
@@ -262,11 +297,33 @@ class Context:
         return ms.value, n.value
 
     # ---- Groth16 witness map (device buffers) ------------------------------------------------------
-    def witness_map_pre(self, a_ptr, b_ptr, log_d, lanes):
-        self._ck(lib().czk_witness_map_pre(self._h, _ptr(a_ptr), _ptr(b_ptr), C.c_uint(log_d), C.c_size_t(lanes)))
+    def witness_map_pre(self, a_ptr, b_ptr, log_d, lanes, a_len=None, b_len=None):
+        """a_len / b_len: evaluations present in each lane (default D); the rest of the domain counts as zero."""
+        d = 1 << log_d
+        self._ck(lib().czk_witness_map_pre(self._h, _ptr(a_ptr), C.c_size_t(d if a_len is None else a_len), _ptr(b_ptr),
+                                           C.c_size_t(d if b_len is None else b_len), C.c_uint(log_d), C.c_size_t(lanes)))
 
-    def witness_map_post(self, ab_ptr, c_ptr, log_d, lanes):
-        self._ck(lib().czk_witness_map_post(self._h, _ptr(ab_ptr), _ptr(c_ptr), C.c_uint(log_d), C.c_size_t(lanes)))
+    def witness_map_post(self, ab_ptr, c_ptr, log_d, lanes, c_len=None):
+        self._ck(lib().czk_witness_map_post(self._h, _ptr(ab_ptr), _ptr(c_ptr), C.c_size_t((1 << log_d) if c_len is None else c_len),
+                                            C.c_uint(log_d), C.c_size_t(lanes)))
+
+
+class R1csMatrix:
+    """czk_r1cs_matrix: a public constraint matrix pinned in HBM (CSR)."""
+
+    def __init__(self, ctx: "Context", handle, m: int, n_vars: int):
+        self.ctx, self._h, self.m, self.n_vars = ctx, handle, m, n_vars
+
+    def release(self):
+        if self._h:
+            lib().czk_r1cs_matrix_release(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
 
 class Bases:

@@ -200,6 +200,7 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
         if (d.coset_inv) (void)hipFree(d.coset_inv);
     }
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
+    if (ctx->poly_scratch.p) (void)hipFree(ctx->poly_scratch.p);
     msm_pipeline_destroy(ctx);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -79,6 +79,7 @@ struct czk_ctx {
     std::string err;
     std::map<unsigned, czk::DomainTables> domains;
     czk::DeviceBuf ntt_scratch;   // one lane-batch for the out-of-place NTT passes
+    czk::DeviceBuf poly_scratch;  // segment sums of czk_poly_div_linear (poly.hip)
     int num_cu = 256;
 };
 

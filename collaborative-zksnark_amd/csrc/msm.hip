@@ -336,6 +336,10 @@ static unsigned num_windows(unsigned c) { return (254 + c - 1) / c; }
 
 // window width for n bases: minimise W(c) * n mixed adds + ~3 * 2^(c-1) reduction adds
 static unsigned choose_c(size_t n) {
+    if (const char* e = getenv("CZK_MSM_C")) {   // tuning override
+        int v = atoi(e);
+        if (v >= 2 && v <= 22) return (unsigned)v;
+    }
     unsigned best = 2;
     double best_cost = 1e300;
     for (unsigned c = 2; c <= 22; c++) {

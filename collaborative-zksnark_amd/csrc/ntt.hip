@@ -564,24 +564,27 @@ static int repr_common(czk_ctx* ctx, int to_mont, const uint64_t* a, uint64_t* o
 extern "C" int czk_fr_into_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem) { return repr_common(ctx, 0, a, out, n, mem); }
 extern "C" int czk_fr_from_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem) { return repr_common(ctx, 1, a, out, n, mem); }
 
-extern "C" int czk_witness_map_pre(czk_ctx* ctx, uint64_t* a, uint64_t* b, unsigned log_d, size_t lanes) {
+extern "C" int czk_witness_map_pre(czk_ctx* ctx, uint64_t* a, size_t a_len, uint64_t* b, size_t b_len, unsigned log_d, size_t lanes) {
     if (!ctx || !a || !b) return ctx ? set_err(ctx, CZK_ERR_ARG, "null witness_map argument") : CZK_ERR_ARG;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t D = (size_t)1 << log_d;
-    CZK_TRY(ntt_device(ctx, a, log_d, lanes, CZK_IFFT, D));
-    CZK_TRY(ntt_device(ctx, b, log_d, lanes, CZK_IFFT, D));
+    if (a_len > D || b_len > D) return set_err(ctx, CZK_ERR_SIZE, "witness_map: more evaluations than the domain holds");
+    // elements [len, D) are the `vec![zero; domain_size]` padding (r1cs_to_qap.rs:66-67): the first pass zero-extends
+    CZK_TRY(ntt_device(ctx, a, log_d, lanes, CZK_IFFT, a_len));
+    CZK_TRY(ntt_device(ctx, b, log_d, lanes, CZK_IFFT, b_len));
     CZK_TRY(ntt_device(ctx, a, log_d, lanes, CZK_COSET_FFT, D));
     CZK_TRY(ntt_device(ctx, b, log_d, lanes, CZK_COSET_FFT, D));
     return CZK_OK;
 }
 
-extern "C" int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, unsigned log_d, size_t lanes) {
+extern "C" int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, size_t c_len, unsigned log_d, size_t lanes) {
     if (!ctx || !ab || !c) return ctx ? set_err(ctx, CZK_ERR_ARG, "null witness_map argument") : CZK_ERR_ARG;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t D = (size_t)1 << log_d;
+    if (c_len > D) return set_err(ctx, CZK_ERR_SIZE, "witness_map: more evaluations than the domain holds");
     DomainTables* d = nullptr;
     CZK_TRY(get_domain(ctx, log_d, &d));
-    CZK_TRY(ntt_device(ctx, c, log_d, lanes, CZK_IFFT, D));
+    CZK_TRY(ntt_device(ctx, c, log_d, lanes, CZK_IFFT, c_len));
     CZK_TRY(ntt_device(ctx, c, log_d, lanes, CZK_COSET_FFT, D));
     size_t n = lanes * D;
     hipLaunchKernelGGL(k_sub_scale, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (const u64*)ab, (const u64*)c, d->vanishing_inv, (u64*)ab, n);

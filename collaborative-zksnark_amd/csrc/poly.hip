@@ -1,0 +1,279 @@
+// poly.hip -- the share-local callers on either side of the NTT / MSM hot path ("next" rows of the scope table):
+//   * R1CS constraint evaluation  a_i = <A_i, z>   (mpc-snarks/src/groth/r1cs_to_qap.rs:12-42, 67-83, 95-100)
+//   * division of a coefficient vector by (X - z)  (KZG10::compute_witness_polynomial, poly-commit/src/kzg10/mod.rs:200-224;
+//     on shares: mpc-algebra/src/share/add.rs:148-156 -- the divisor is public, so the division is lane-wise)
+// Both are one- or two-sweep HBM-bound Fr kernels; share lanes ride on gridDim.y.
+#include "czk_internal.h"
+
+#include <string.h>
+
+namespace czk {
+
+__device__ __forceinline__ Fr pfr_load(const u64* base, size_t idx) { return fp_load<FrParams>(base + 4 * idx); }
+__device__ __forceinline__ void pfr_store(u64* base, size_t idx, const Fr& v) { fp_store<FrParams>(base + 4 * idx, v); }
+
+// ------------------------------------------------------------------------------------------------
+// R1CS matrices in CSR.  col[t] bit 31 marks a coefficient equal to one: evaluate_constraint adds the variable
+// without multiplying (r1cs_to_qap.rs:28-32) and the kernel then skips the 32-byte coefficient read as well.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_r1cs_prepare(const u64* row_ptr, u32* col, const u64* coeff, size_t m, size_t nnz, size_t n_vars, u32* row_ptr32, u32* bad) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= m) {
+        u64 r = row_ptr[t];
+        if (r > nnz || (t && row_ptr[t - 1] > r) || (t == 0 && r != 0) || (t == m && r != nnz)) atomicOr(bad, 1u);
+        row_ptr32[t] = (u32)r;
+    }
+    if (t < nnz) {
+        u32 c = col[t];
+        if (c >= n_vars || c >= 0x80000000u) {
+            atomicOr(bad, 2u);
+            return;
+        }
+        Fr k = pfr_load(coeff, t);
+        const Fr one = Fr::one();
+        bool is_one = true;
+#pragma unroll
+        for (int i = 0; i < 8; i++) is_one = is_one && (k.l[i] == one.l[i]);
+        if (is_one) col[t] = c | 0x80000000u;
+    }
+}
+
+// out[lane][i] = sum_t coeff[t] * z[lane][col[t]] over row i; one thread per row
+__global__ __launch_bounds__(256) void k_r1cs_matvec(const u32* row_ptr, const u32* col, const u64* coeff, size_t m, const u64* z, size_t z_stride,
+                                                      u64* out, size_t out_stride) {
+    const unsigned lane = blockIdx.y;
+    const u64* zl = z + 4 * (size_t)lane * z_stride;
+    u64* ol = out + 4 * (size_t)lane * out_stride;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += (size_t)gridDim.x * blockDim.x) {
+        u32 t0 = row_ptr[i], t1 = row_ptr[i + 1];
+        Fr acc = Fr::zero();
+        for (u32 t = t0; t < t1; t++) {
+            u32 c = col[t];
+            Fr v = pfr_load(zl, c & 0x7fffffffu);
+            if (!(c & 0x80000000u)) v = fp_mul(v, pfr_load(coeff, t));
+            acc = fp_add(acc, v);
+        }
+        pfr_store(ol, i, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Suffix Horner sums R_i = sum_{j >= i} p_j x^(j - i) (so R_i = p_i + x R_{i+1}): the quotient of p / (X - x) is
+// q_k = R_{k+1} and the remainder R_0 = p(x).  Segments of SEG coefficients: (1) per-segment Horner value H_t;
+// (2) the H_t are themselves a coefficient vector whose suffix Horner sums at x^SEG are the carries into the
+// segments -- the same problem, SEG times smaller (recursion, <= 3 levels up to 2^21); (3) per-segment fill.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned SEG = 128;
+
+__global__ __launch_bounds__(256) void k_seg_horner(const u64* in, size_t in_stride, size_t n, Fr x, u64* H, size_t n_seg) {
+    const unsigned lane = blockIdx.y;
+    const u64* p = in + 4 * (size_t)lane * in_stride;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg) return;
+    size_t a = t * SEG, b = a + SEG < n ? a + SEG : n;
+    Fr r = Fr::zero();
+    for (size_t i = b; i-- > a;) r = fp_add(fp_mul(r, x), pfr_load(p, i));
+    pfr_store(H + 4 * (size_t)lane * n_seg, t, r);
+}
+// out[i - shift] = R_i for i >= shift (shift = 1 writes the quotient); R_0 goes to rem when shift == 1.
+// carry[t] = suffix sum entering segment t from above = R at index (t + 1) * SEG, i.e. element t + 1 of the next level.
+__global__ __launch_bounds__(256) void k_seg_fill(const u64* in, size_t in_stride, size_t n, Fr x, const u64* carry, size_t n_seg, u64* out,
+                                                  size_t out_stride, unsigned shift, u64* rem) {
+    const unsigned lane = blockIdx.y;
+    const u64* p = in + 4 * (size_t)lane * in_stride;
+    u64* o = out + 4 * (size_t)lane * out_stride;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg) return;
+    size_t a = t * SEG, b = a + SEG < n ? a + SEG : n;
+    Fr r = (carry && t + 1 < n_seg) ? pfr_load(carry + 4 * (size_t)lane * n_seg, t + 1) : Fr::zero();
+    for (size_t i = b; i-- > a;) {
+        r = fp_add(fp_mul(r, x), pfr_load(p, i));
+        if (i >= shift) pfr_store(o, i - shift, r);
+        else if (rem) pfr_store(rem, lane, r);
+    }
+}
+
+static Fr host_pow(Fr x, unsigned e) {
+    Fr r = Fr::one();
+    for (; e; e >>= 1) {
+        if (e & 1) r = fp_mul(r, x);
+        x = fp_mul(x, x);
+    }
+    return r;
+}
+
+// suffix Horner sums of `in` (lanes x n, stride in_stride) at x, written to out[i - shift]; `ws` is a bump pointer into
+// ctx->poly_scratch (suffix_horner_scratch bytes)
+static size_t suffix_horner_scratch(size_t n, size_t lanes) {
+    size_t tot = 0;
+    for (size_t n_seg = (n + SEG - 1) / SEG; n_seg > 1; n_seg = (n_seg + SEG - 1) / SEG) tot += 2 * lanes * n_seg * 32;
+    return tot;
+}
+static int suffix_horner(czk_ctx* ctx, const u64* in, size_t in_stride, size_t n, size_t lanes, Fr x, u64* out, size_t out_stride, unsigned shift,
+                         u64* rem, char*& ws) {
+    const size_t n_seg = (n + SEG - 1) / SEG;
+    u64* carry = nullptr;
+    if (n_seg > 1) {
+        u64* H = (u64*)ws;
+        ws += lanes * n_seg * 32;
+        u64* R = (u64*)ws;
+        ws += lanes * n_seg * 32;
+        hipLaunchKernelGGL(k_seg_horner, dim3((unsigned)((n_seg + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, in, in_stride, n, x, H, n_seg);
+        CZK_TRY(suffix_horner(ctx, H, n_seg, n_seg, lanes, host_pow(x, SEG), R, n_seg, 0, nullptr, ws));
+        carry = R;
+    }
+    hipLaunchKernelGGL(k_seg_fill, dim3((unsigned)((n_seg + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, in, in_stride, n, x, carry, n_seg, out,
+                       out_stride, shift, rem);
+    CZK_HIP(ctx, hipGetLastError());
+    return CZK_OK;
+}
+
+}  // namespace czk
+
+using namespace czk;
+
+struct czk_r1cs_matrix {
+    czk_ctx* ctx = nullptr;
+    size_t m = 0, nnz = 0, n_vars = 0;
+    u32 *row_ptr = nullptr, *col = nullptr;
+    u64* coeff = nullptr;
+};
+
+extern "C" void czk_r1cs_matrix_release(czk_r1cs_matrix* a) {
+    if (!a) return;
+    if (a->ctx) (void)hipSetDevice(a->ctx->device);
+    if (a->row_ptr) (void)hipFree(a->row_ptr);
+    if (a->col) (void)hipFree(a->col);
+    if (a->coeff) (void)hipFree(a->coeff);
+    delete a;
+}
+
+extern "C" int czk_r1cs_matrix_register(czk_ctx* ctx, const uint64_t* row_ptr, const uint32_t* col_idx, const uint64_t* coeff, size_t m, size_t nnz,
+                                        size_t n_vars, int mem, czk_r1cs_matrix** out) {
+    if (!ctx || !out || !row_ptr || (nnz && (!col_idx || !coeff))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null r1cs matrix argument") : CZK_ERR_ARG;
+    *out = nullptr;
+    if (nnz >= ((size_t)1 << 32) || n_vars >= ((size_t)1 << 31) || m >= ((size_t)1 << 32))
+        return set_err(ctx, CZK_ERR_SIZE, "r1cs matrix too large for 32-bit indices");
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    czk_r1cs_matrix* a = new czk_r1cs_matrix();
+    a->ctx = ctx;
+    a->m = m;
+    a->nnz = nnz;
+    a->n_vars = n_vars;
+    u64* rp64 = nullptr;
+    u32* bad = nullptr;
+    int rc = CZK_OK;
+    auto fail = [&](int code, const std::string& msg) {
+        rc = set_err(ctx, code, msg);
+    };
+    const hipMemcpyKind kind = mem == CZK_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    if (hipMalloc(&a->row_ptr, (m + 1) * 4) != hipSuccess || hipMalloc(&a->col, (nnz ? nnz : 1) * 4) != hipSuccess ||
+        hipMalloc(&a->coeff, (nnz ? nnz : 1) * 32) != hipSuccess || hipMalloc(&rp64, (m + 1) * 8) != hipSuccess || hipMalloc(&bad, 4) != hipSuccess)
+        fail(CZK_ERR_NOMEM, "hipMalloc r1cs matrix");
+    if (rc == CZK_OK && (hipMemcpyAsync(rp64, row_ptr, (m + 1) * 8, kind, ctx->stream) != hipSuccess ||
+                         (nnz && hipMemcpyAsync(a->col, col_idx, nnz * 4, kind, ctx->stream) != hipSuccess) ||
+                         (nnz && hipMemcpyAsync(a->coeff, coeff, nnz * 32, kind, ctx->stream) != hipSuccess) ||
+                         hipMemsetAsync(bad, 0, 4, ctx->stream) != hipSuccess))
+        fail(CZK_ERR_HIP, "copy r1cs matrix");
+    if (rc == CZK_OK) {
+        size_t work = nnz > m + 1 ? nnz : m + 1;
+        hipLaunchKernelGGL(k_r1cs_prepare, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, ctx->stream, rp64, a->col, a->coeff, m, nnz, n_vars,
+                           a->row_ptr, bad);
+        u32 hb = 0;
+        if (hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            fail(CZK_ERR_HIP, "r1cs matrix validation");
+        else if (hb & 1) fail(CZK_ERR_ARG, "r1cs matrix: row_ptr is not a monotone CSR offset array ending at nnz");
+        else if (hb & 2) fail(CZK_ERR_ARG, "r1cs matrix: variable index out of range (the reference would panic on assignment[index])");
+    }
+    if (rp64) (void)hipFree(rp64);
+    if (bad) (void)hipFree(bad);
+    if (rc != CZK_OK) {
+        czk_r1cs_matrix_release(a);
+        return rc;
+    }
+    *out = a;
+    return CZK_OK;
+}
+
+namespace {
+struct StagedP {   // host <-> device staging for CZK_MEM_HOST callers
+    czk_ctx* ctx;
+    void* dev = nullptr;
+    bool owned = false;
+    int to_device(const void* host, size_t bytes, int mem) {
+        if (mem == CZK_MEM_DEVICE) {
+            dev = const_cast<void*>(host);
+            return CZK_OK;
+        }
+        CZK_HIP(ctx, hipMalloc(&dev, bytes ? bytes : 1));
+        owned = true;
+        if (host) CZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return CZK_OK;
+    }
+    int to_host(void* host, size_t bytes) {
+        if (!owned) return CZK_OK;
+        CZK_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return CZK_OK;
+    }
+    ~StagedP() {
+        if (owned && dev) (void)hipFree(dev);
+    }
+};
+}  // namespace
+
+extern "C" int czk_r1cs_matvec(czk_ctx* ctx, const czk_r1cs_matrix* a, const uint64_t* z, size_t z_stride, size_t lanes, uint64_t* out,
+                               size_t out_stride, int mem) {
+    if (!ctx || !a || (lanes && (!z || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null r1cs_matvec argument") : CZK_ERR_ARG;
+    if (z_stride < a->n_vars || out_stride < a->m) return set_err(ctx, CZK_ERR_SIZE, "r1cs_matvec: assignment shorter than n_vars or output shorter than m");
+    if (!lanes || !a->m) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    StagedP sz{ctx}, so{ctx};
+    CZK_TRY(sz.to_device(z, lanes * z_stride * 32, mem));
+    CZK_TRY(so.to_device(mem == CZK_MEM_HOST ? nullptr : out, lanes * out_stride * 32, mem));
+    if (so.owned) CZK_HIP(ctx, hipMemsetAsync(so.dev, 0, lanes * out_stride * 32, ctx->stream));
+    size_t blocks = (a->m + 255) / 256, cap = (size_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    {
+        ProfScope ps(ctx, "r1cs_matvec");
+        hipLaunchKernelGGL(k_r1cs_matvec, dim3((unsigned)blocks, (unsigned)lanes), dim3(256), 0, ctx->stream, a->row_ptr, a->col, a->coeff, a->m,
+                           (const u64*)sz.dev, z_stride, (u64*)so.dev, out_stride);
+    }
+    CZK_HIP(ctx, hipGetLastError());
+    if (so.owned) {
+        // only rows [0, m) of each lane are defined by this call: copy those back
+        for (size_t l = 0; l < lanes; l++)
+            CZK_HIP(ctx, hipMemcpyAsync(out + 4 * l * out_stride, (const u64*)so.dev + 4 * l * out_stride, a->m * 32, hipMemcpyDeviceToHost, ctx->stream));
+        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CZK_OK;
+}
+
+extern "C" int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* quotient,
+                                   uint64_t* remainder, int mem) {
+    if (!ctx || !z || (lanes && n && !coeffs) || (lanes && n > 1 && !quotient)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null poly_div argument") : CZK_ERR_ARG;
+    if (!lanes) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) {   // zero polynomial: zero quotient, zero remainder
+        if (remainder) {
+            if (mem == CZK_MEM_HOST) memset(remainder, 0, lanes * 32);
+            else CZK_HIP(ctx, hipMemsetAsync(remainder, 0, lanes * 32, ctx->stream));
+        }
+        return CZK_OK;
+    }
+    Fr x = fp_load<FrParams>(z);
+    const size_t qn = n - 1;
+    StagedP sp{ctx}, sq{ctx}, sr{ctx};
+    CZK_TRY(sp.to_device(coeffs, lanes * n * 32, mem));
+    CZK_TRY(sq.to_device(mem == CZK_MEM_HOST ? nullptr : quotient, lanes * qn * 32, mem));
+    CZK_TRY(sr.to_device(mem == CZK_MEM_HOST ? nullptr : remainder, lanes * 32, remainder ? mem : CZK_MEM_HOST));
+    CZK_TRY(ensure_buf(ctx, ctx->poly_scratch, suffix_horner_scratch(n, lanes) + 256));
+    char* ws = (char*)ctx->poly_scratch.p;
+    {
+        ProfScope ps(ctx, "poly_div_linear");
+        CZK_TRY(suffix_horner(ctx, (const u64*)sp.dev, n, n, lanes, x, (u64*)sq.dev, qn, 1, (u64*)sr.dev, ws));
+    }
+    CZK_TRY(sq.to_host(quotient, lanes * qn * 32));
+    if (remainder) CZK_TRY(sr.to_host(remainder, lanes * 32));
+    return CZK_OK;
+}

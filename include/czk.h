@@ -107,6 +107,29 @@ int czk_fr_beaver_combine(czk_ctx* ctx, const uint64_t* x, const uint64_t* y, co
  * *out_bad (host) receives the number of i with check[i] != 0 (the reference asserts it is 0). */
 int czk_fr_spdz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t n, uint64_t* out_value, uint64_t* out_bad);
 
+/* ---- callers either side of the NTT: constraint evaluation and division by (X - z) ------------------ */
+/* R1CS matrix (one of ConstraintMatrices::{a, b, c}, Vec<Vec<(F, usize)>>) in CSR form, pinned on the GPU once per
+ * circuit: row_ptr m+1 offsets (row_ptr[0] = 0, row_ptr[m] = nnz), col_idx nnz variable indices into the full
+ * assignment [instance | witness] (r1cs_to_qap.rs:56-61), coeff nnz Montgomery Fr.  CZK_ERR_ARG for a malformed
+ * row_ptr or an index >= n_vars (the reference panics on assignment[index]). */
+typedef struct czk_r1cs_matrix czk_r1cs_matrix;
+int czk_r1cs_matrix_register(czk_ctx* ctx, const uint64_t* row_ptr, const uint32_t* col_idx, const uint64_t* coeff, size_t m,
+                             size_t nnz, size_t n_vars, int mem, czk_r1cs_matrix** out);
+void czk_r1cs_matrix_release(czk_r1cs_matrix* a);
+/* evaluate_constraint over every row (mpc-snarks/src/groth/r1cs_to_qap.rs:12-42, called at :70-77 and :95-100):
+ *   out[lane][i] = sum_t coeff[t] * z[lane][col_idx[t]],  i < m
+ * z: lanes x z_stride Fr (z_stride >= n_vars), the share lanes of the full assignment with Public entries lifted as for
+ * the NTT (wire/field.rs Public * coeff stays public; lifting commutes with the sum); out: lanes x out_stride Fr
+ * (out_stride >= m; elements [m, out_stride) are not written, so the caller's zero padding to the domain size stays). */
+int czk_r1cs_matvec(czk_ctx* ctx, const czk_r1cs_matrix* a, const uint64_t* z, size_t z_stride, size_t lanes, uint64_t* out,
+                    size_t out_stride, int mem);
+/* DensePolynomial / (X - z): KZG10::compute_witness_polynomial (poly-commit/src/kzg10/mod.rs:200-224; shares divide
+ * lane-wise because the divisor is public, mpc-algebra/src/share/add.rs:148-156).  coeffs: lanes x n Fr, low degree
+ * first; quotient: lanes x (n-1) Fr; remainder (may be NULL): lanes Fr = p(z), which is also
+ * Polynomial::evaluate (kzg10/mod.rs:247).  z: one Montgomery Fr in HOST memory. */
+int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* quotient,
+                        uint64_t* remainder, int mem);
+
 /* Fr::into_repr / from_repr over a vector (fields/arithmetic.rs:59-81, macros.rs:443-454) -- also the wire format. */
 int czk_fr_into_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
 int czk_fr_from_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
@@ -164,9 +187,11 @@ int czk_fixed_base_points(czk_ctx* ctx, int group, const uint64_t* k, size_t n, 
  *   czk_witness_map_pre : a <- coset_fft(ifft(a)), b <- coset_fft(ifft(b))                       (:85-89)
  *   [caller: ab = batch_product(a, b) -- Beaver opens for shares, czk_fr_vec_op(MUL) for a single prover] (:92)
  *   czk_witness_map_post: c <- coset_fft(ifft(c)); ab <- coset_ifft((ab - c) * Z(g)^-1)          (:102-110)
- * h = ab on return. */
-int czk_witness_map_pre(czk_ctx* ctx, uint64_t* a, uint64_t* b, unsigned log_d, size_t lanes);
-int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, unsigned log_d, size_t lanes);
+ * h = ab on return.  a_len / b_len / c_len <= D: evaluations present in each lane (num_constraints + num_inputs for a,
+ * num_constraints for b and c); elements beyond them are the reference's `vec![zero; domain_size]` padding (:66-67, :94)
+ * and are never read -- the first NTT pass zero-extends. */
+int czk_witness_map_pre(czk_ctx* ctx, uint64_t* a, size_t a_len, uint64_t* b, size_t b_len, unsigned log_d, size_t lanes);
+int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, size_t c_len, unsigned log_d, size_t lanes);
 
 /* ---- measurement hooks --------------------------------------------------------------------------- */
 /* When enabled, the library brackets its kernel launches with HIP events on the context's stream (the stream the

@@ -508,3 +508,56 @@ void orc_witness_map_plain(uint64_t *a, uint64_t *b, uint64_t *c, unsigned log_d
     for (size_t i = 0; i < n; i++) fr_mul(&fa[i], &fa[i], &fb[i]);
     orc_witness_map_post_lane(fa, (fr_t *)c, log_d);
 }
+
+/* ---- callers either side of the NTT ("next" rows; test infrastructure like everything in this file) ------------- */
+/* evaluate_constraint over every row of one R1CS matrix (mpc-snarks/src/groth/r1cs_to_qap.rs:12-42, 70-77, 95-100):
+ * sum += (coeff == 1) ? val : val * coeff, in term order. */
+void orc_r1cs_matvec(const uint64_t *row_ptr, const uint32_t *col, const uint64_t *coeff, size_t m, const uint64_t *z, uint64_t *out) {
+    fr_t one;
+    fr_one(&one);
+    for (size_t i = 0; i < m; i++) {
+        fr_t sum;
+        memset(&sum, 0, sizeof sum);
+        for (uint64_t t = row_ptr[i]; t < row_ptr[i + 1]; t++) {
+            const fr_t *val = (const fr_t *)(z + 4 * (size_t)col[t]);
+            const fr_t *k = (const fr_t *)(coeff + 4 * t);
+            if (memcmp(k, &one, sizeof one) == 0) {
+                fr_add(&sum, &sum, val);
+            } else {
+                fr_t prod;
+                fr_mul(&prod, val, k);
+                fr_add(&sum, &sum, &prod);
+            }
+        }
+        memcpy(out + 4 * i, &sum, 32);
+    }
+}
+
+/* DensePolynomial::divide_with_q_and_r (algebra/poly/src/polynomial/univariate/mod.rs:133-174) for the divisor
+ * (X - z) = [-z, 1] that KZG10::compute_witness_polynomial builds (poly-commit/src/kzg10/mod.rs:205-209): schoolbook
+ * long division from the top coefficient.  quotient: n-1 coefficients (zero-padded where the reference's vector is
+ * shorter because of leading zeros), remainder: 1 coefficient. */
+void orc_poly_div_linear(const uint64_t *coeffs, size_t n, const uint64_t *z, uint64_t *quotient, uint64_t *remainder) {
+    fr_t negz, zero;
+    memset(&zero, 0, sizeof zero);
+    fr_neg(&negz, (const fr_t *)z);
+    if (n > 1) memset(quotient, 0, (n - 1) * 32);
+    memset(remainder, 0, 32);
+    if (n == 0) return;
+    fr_t *rem = malloc(n * sizeof(fr_t));
+    memcpy(rem, coeffs, n * 32);
+    size_t len = n;
+    while (len && memcmp(&rem[len - 1], &zero, 32) == 0) len--;          /* from_coefficients_vec truncates */
+    while (len >= 2) {                                                     /* degree >= divisor degree (1) */
+        fr_t q = rem[len - 1];                                             /* * divisor_leading_inv (= 1) */
+        size_t qdeg = len - 2;
+        memcpy(quotient + 4 * qdeg, &q, 32);
+        fr_t t;
+        fr_mul(&t, &q, &negz);
+        fr_sub(&rem[qdeg], &rem[qdeg], &t);                                /* i = 0: -= q * (-z) */
+        fr_sub(&rem[qdeg + 1], &rem[qdeg + 1], &q);                        /* i = 1: -= q * 1    */
+        while (len && memcmp(&rem[len - 1], &zero, 32) == 0) len--;
+    }
+    if (len == 1) memcpy(remainder, &rem[0], 32);
+    free(rem);
+}

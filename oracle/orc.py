@@ -246,3 +246,28 @@ def witness_map_post(ab, c, log_d):
     ab, c = (np.array(_u64(x).reshape(-1, 4)) for x in (ab, c))
     lib().orc_witness_map_post(_p(ab), _p(c), C.c_uint(log_d))
     return ab
+
+
+# ----------------------------------------------------------------------------- callers either side of the NTT
+def r1cs_matvec(row_ptr, col, coeff, z):
+    """evaluate_constraint over every row: row_ptr (m+1,) u64, col (nnz,) u32, coeff (nnz,4), z (n_vars,4) -> (m,4)."""
+    row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+    col = np.ascontiguousarray(col, dtype=np.uint32)
+    coeff = np.ascontiguousarray(_u64(coeff).reshape(-1, 4))
+    z = np.ascontiguousarray(_u64(z).reshape(-1, 4))
+    m = len(row_ptr) - 1
+    out = np.zeros((m, 4), dtype=np.uint64)
+    lib().orc_r1cs_matvec(_p(row_ptr), col.ctypes.data_as(C.c_void_p), _p(coeff), C.c_size_t(m), _p(z), _p(out))
+    return out
+
+
+def poly_div_linear(coeffs, z):
+    """coeffs (n,4) / (X - z) -> (quotient (n-1,4), remainder (4,))."""
+    coeffs = np.ascontiguousarray(_u64(coeffs).reshape(-1, 4))
+    z = np.ascontiguousarray(_u64(z).reshape(4))
+    n = len(coeffs)
+    q = np.zeros((max(n - 1, 0), 4), dtype=np.uint64)
+    r = np.zeros(4, dtype=np.uint64)
+    qbuf = q if len(q) else np.zeros((1, 4), dtype=np.uint64)
+    lib().orc_poly_div_linear(_p(coeffs) if n else None, C.c_size_t(n), _p(z), _p(qbuf), _p(r))
+    return q, r

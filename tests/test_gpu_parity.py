@@ -375,9 +375,11 @@ def test_spdz_open_with_mac_check(ctx, czk, orc):
     lanes = np.stack([np.stack([s_, s_]) for s_ in sh])          # mac share = sh * mac(), mac() = 1 (spdz.rs:41-47)
     t = torch.from_numpy(lanes.view(np.int64).copy()).cuda()
     out = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()                                       # torch's stream is not the context's
     assert ctx.fr_spdz_open(t.data_ptr(), parties, n, out.data_ptr()) == 0
     assert np.array_equal(out.cpu().numpy().view(np.uint64), secret)
     t[1, 1, 17, 0] += 1                                           # party 1 tampers with one MAC share
+    torch.cuda.synchronize()
     assert ctx.fr_spdz_open(t.data_ptr(), parties, n, out.data_ptr()) == 1
 
 
@@ -401,3 +403,112 @@ def test_kzg10_commit_matches_reference_composition(ctx, czk, orc):
     assert _same_point(ctx, orc, 1, got, want)
     bg.release()
     bgg.release()
+
+
+# ---- "next" rows: constraint evaluation and division by (X - z) -----------------------------------------------
+def _random_csr_limbs(orc, seed, m, n_vars, max_terms=6):
+    rng = np.random.default_rng(seed)
+    counts = rng.integers(0, max_terms + 1, size=m)
+    counts[3::7] = 0                                              # empty constraints
+    row_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    nnz = int(row_ptr[-1])
+    col = rng.integers(0, n_vars, size=nnz).astype(np.uint32)
+    coeff = orc.fr_from_repr(rand_fr_canonical(seed + 1, nnz))
+    one = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+    coeff[rng.random(nnz) < 0.5] = one                            # is_one() fast path (r1cs_to_qap.rs:28-32)
+    return row_ptr, col, coeff
+
+
+@pytest.mark.parametrize("m,n_vars,lanes", [(1, 1, 1), (1000, 300, 2), (70001, 50000, 4)])
+def test_r1cs_matvec_matches_oracle(ctx, czk, orc, m, n_vars, lanes):
+    row_ptr, col, coeff = _random_csr_limbs(orc, 90 + m, m, n_vars)
+    z = orc.fr_from_repr(rand_fr_canonical(91 + m, lanes * n_vars)).reshape(lanes, n_vars, 4)
+    mat = ctx.r1cs_matrix_register(row_ptr, col, coeff, n_vars)
+    got = ctx.r1cs_matvec(mat, z, lanes=lanes)
+    for ln in range(lanes):
+        assert np.array_equal(got[ln], orc.r1cs_matvec(row_ptr, col, coeff, z[ln])), ln
+    mat.release()
+
+
+def test_r1cs_squaring_circuit_feeds_witness_map(ctx, czk, orc):
+    """The matrices of the reference's benchmark circuit (proof.rs:304-344: w_{i+1} = w_i^2) evaluated on device lanes
+    with padding stride D, then the device witness map; compared with the oracle run on the oracle's own matvec."""
+    import torch
+    log_d, N = 10, 1000
+    D, n_vars = 1 << log_d, N + 2                                  # assignment = [1, out | w_0 .. w_{N-1}]
+    one = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    w = [orc.fr_from_repr(rand_fr_canonical(5, 1))]
+    for _ in range(N):
+        w.append(orc.fr_mul(w[-1], w[-1]))
+    z = np.concatenate([one, w[N]] + w[:N]).astype(np.uint64)     # instance (1, out) then witness
+    ident = lambda cols: (np.arange(len(cols) + 1, dtype=np.uint64), np.array(cols, dtype=np.uint32), np.tile(one, (len(cols), 1)))
+    A = ident([2 + i for i in range(N)] + [0, 1])                  # a_i = w_i, then the instance copy rows (:79-83)
+    Bm = ident([2 + i for i in range(N)])
+    Cm = ident([2 + i + 1 for i in range(N - 1)] + [1])            # c_i = w_{i+1}, last = out
+    dev = {}
+    zt = torch.from_numpy(z.view(np.int64).copy()).cuda()
+    for name, (rp, col, cf) in (("a", A), ("b", Bm), ("c", Cm)):
+        mat = ctx.r1cs_matrix_register(rp, col, cf, n_vars)
+        out = torch.zeros((D, 4), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()                                   # torch's stream is not the context's
+        ctx.r1cs_matvec(mat, zt.data_ptr(), lanes=1, out=out.data_ptr(), z_stride=n_vars, out_stride=D, mem=czk.CZK_MEM_DEVICE)
+        dev[name] = out
+        ctx.sync()
+        want = np.zeros((D, 4), dtype=np.uint64)
+        want[: len(rp) - 1] = orc.r1cs_matvec(rp, col, cf, z)
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want), name
+        mat.release()
+    a, b, c = (dev[k].cpu().numpy().view(np.uint64).copy() for k in "abc")
+    ctx.witness_map_pre(dev["a"].data_ptr(), dev["b"].data_ptr(), log_d, 1)
+    ctx.fr_vec_op(2, dev["a"].data_ptr(), dev["b"].data_ptr(), out=dev["a"].data_ptr(), n=D, mem=czk.CZK_MEM_DEVICE)
+    ctx.witness_map_post(dev["a"].data_ptr(), dev["c"].data_ptr(), log_d, 1)
+    ctx.sync()
+    assert np.array_equal(dev["a"].cpu().numpy().view(np.uint64), orc.witness_map_plain(a, b, c, log_d))
+
+
+def test_r1cs_matrix_rejects_malformed_input(ctx, czk, orc):
+    one = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    good_rp = np.array([0, 1, 2], dtype=np.uint64)
+    with pytest.raises(czk.CzkError):                              # index out of range: reference panics on assignment[index]
+        ctx.r1cs_matrix_register(good_rp, np.array([0, 5], dtype=np.uint32), np.tile(one, (2, 1)), 5)
+    with pytest.raises(czk.CzkError):                              # row_ptr not monotone
+        ctx.r1cs_matrix_register(np.array([0, 2, 1, 2], dtype=np.uint64), np.array([0, 1], dtype=np.uint32), np.tile(one, (2, 1)), 5)
+    mat = ctx.r1cs_matrix_register(good_rp, np.array([0, 4], dtype=np.uint32), np.tile(one, (2, 1)), 5)
+    with pytest.raises(czk.CzkError):                              # assignment shorter than n_vars
+        ctx.r1cs_matvec(mat, np.zeros((1, 4, 4), dtype=np.uint64), lanes=1)
+    mat.release()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 127, 128, 129, 128 * 128 + 5, (1 << 17) + 3])
+def test_poly_div_linear_matches_oracle(ctx, czk, orc, n):
+    lanes = 2
+    p = orc.fr_from_repr(rand_fr_canonical(300 + n, lanes * max(n, 1)))[: lanes * n].reshape(lanes, n, 4)
+    if n > 4:
+        p[1, n - 2:] = 0                                           # leading zeros: DensePolynomial truncates them
+    z = orc.fr_from_repr(rand_fr_canonical(301, 1))[0]
+    q, r = ctx.poly_div_linear(p, z, lanes=lanes)
+    for ln in range(lanes):
+        qw, rw = orc.poly_div_linear(p[ln], z)
+        assert np.array_equal(q[ln], qw) and np.array_equal(r[ln], rw), (n, ln)
+
+
+def test_poly_div_linear_full_size_identity(ctx, czk, orc):
+    """2^21 coefficients x 2 lanes on device: remainder == p(z) (oracle Horner) and p(x) == q(x) (x - z) + r at a random x."""
+    import torch
+    n, lanes = 1 << 21, 2
+    p = orc.fr_from_repr(rand_fr_canonical(310, 4096))
+    pt = torch.from_numpy(p.view(np.int64).copy()).cuda().repeat(lanes * n // 4096, 1).contiguous()
+    pt[n + 7, 0] += 1                                              # make the two lanes differ
+    z = orc.fr_from_repr(rand_fr_canonical(311, 1))[0]
+    x = orc.fr_from_repr(rand_fr_canonical(312, 1))[0]
+    q = torch.zeros((lanes, n - 1, 4), dtype=torch.int64, device="cuda")
+    r = torch.zeros((lanes, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()                                       # torch's stream is not the context's
+    ctx.poly_div_linear(pt.data_ptr(), z, lanes=lanes, n=n, quotient=q.data_ptr(), remainder=r.data_ptr(), mem=czk.CZK_MEM_DEVICE)
+    ctx.sync()
+    ph, qh, rh = pt.cpu().numpy().view(np.uint64).reshape(lanes, n, 4), q.cpu().numpy().view(np.uint64), r.cpu().numpy().view(np.uint64)
+    for ln in range(lanes):
+        assert np.array_equal(rh[ln], orc.fr_horner(ph[ln], z))
+        lhs = orc.fr_horner(ph[ln], x)
+        rhs = orc.fr_add(orc.fr_mul(orc.fr_horner(qh[ln], x), orc.fr_sub(x, z)), rh[ln])
+        assert np.array_equal(lhs, rhs)

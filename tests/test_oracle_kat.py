@@ -222,3 +222,56 @@ def test_window_rule():
         return 3 if size < 32 else lg * 69 // 100 + 2
     assert c_of((1 << 20) + 1) == 16 and c_of((1 << 21) - 1) == 16 and c_of(1 << 20) == 15
     assert c_of((1 << 22) + 1) == 17 and c_of(1 << 18) == 14 and c_of(1 << 17) == 13 and c_of(11) == 3
+
+
+def _random_csr(rng, m, n_vars, max_terms=5):
+    row_ptr, col, coeff = [0], [], []
+    for i in range(m):
+        k = 0 if i % 7 == 3 else rng.randrange(1, max_terms + 1)   # some empty rows
+        for _ in range(k):
+            col.append(rng.randrange(n_vars))
+            c = rng.choice([1, 1, P.R_MOD - 1, rng.randrange(P.R_MOD)])
+            coeff.append(c)
+        row_ptr.append(len(col))
+    return row_ptr, col, coeff
+
+
+def test_c_oracle_r1cs_matvec_vs_bigint(orc):
+    """orc_r1cs_matvec (evaluate_constraint, r1cs_to_qap.rs:12-42) against plain modular arithmetic."""
+    rng = random.Random(11)
+    m, n_vars = 200, 64
+    row_ptr, col, coeff = _random_csr(rng, m, n_vars)
+    z = _rand_fr(rng, n_vars)
+    want = [sum(coeff[t] * z[col[t]] for t in range(row_ptr[i], row_ptr[i + 1])) % P.R_MOD for i in range(m)]
+    mont = lambda xs: orc.ints_to_limbs([x * P.FR_MONT_R % P.R_MOD for x in xs], 4)
+    got = orc.r1cs_matvec(np.array(row_ptr, dtype=np.uint64), np.array(col, dtype=np.uint32), mont(coeff), mont(z))
+    assert orc.limbs_to_ints(orc.fr_into_repr(got)) == want
+
+
+def test_c_oracle_poly_div_linear_vs_bigint(orc):
+    """orc_poly_div_linear (divide_with_q_and_r with divisor X - z) against Horner's rule on integers; also the
+    defining identity p = q (X - z) + r and the leading-zero cases DensePolynomial truncates."""
+    rng = random.Random(12)
+    mont = lambda xs: orc.ints_to_limbs([x * P.FR_MONT_R % P.R_MOD for x in xs], 4)
+    for n, tail_zeros in ((0, 0), (1, 0), (2, 0), (9, 0), (130, 0), (40, 3), (5, 5)):
+        p = _rand_fr(rng, n)
+        for k in range(tail_zeros):
+            p[n - 1 - k] = 0
+        z = rng.randrange(P.R_MOD)
+        q_want = [0] * max(n - 1, 0)
+        run = 0
+        for i in range(n - 1, 0, -1):
+            run = (p[i] + z * run) % P.R_MOD
+            q_want[i - 1] = run
+        r_want = (p[0] + z * run) % P.R_MOD if n else 0
+        q, r = orc.poly_div_linear(mont(p) if n else np.zeros((0, 4), dtype=np.uint64), mont([z])[0])
+        assert orc.limbs_to_ints(orc.fr_into_repr(q)) == q_want if n > 1 else len(q) == 0
+        assert orc.limbs_to_ints(orc.fr_into_repr(r.reshape(1, 4))) == [r_want]
+        # p == q * (X - z) + r coefficient-wise
+        rec = [0] * n
+        for i, c in enumerate(q_want):
+            rec[i] = (rec[i] - z * c) % P.R_MOD
+            rec[i + 1] = (rec[i + 1] + c) % P.R_MOD
+        if n:
+            rec[0] = (rec[0] + r_want) % P.R_MOD
+        assert rec == p
