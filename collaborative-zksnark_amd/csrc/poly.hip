@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void k_r1cs_matvec(const u32* row_ptr, const u
 // (2) the H_t are themselves a coefficient vector whose suffix Horner sums at x^SEG are the carries into the
 // segments -- the same problem, SEG times smaller (recursion, <= 3 levels up to 2^21); (3) per-segment fill.
 // ------------------------------------------------------------------------------------------------
-constexpr unsigned SEG = 128;
+constexpr unsigned SEG = 32;
 
 __global__ __launch_bounds__(256) void k_seg_horner(const u64* in, size_t in_stride, size_t n, Fr x, u64* H, size_t n_seg) {
     const unsigned lane = blockIdx.y;

@@ -67,5 +67,42 @@ for g, sizes in ((czk.CZK_G1, (17, 20, 21, 22)), (czk.CZK_G2, (17, 20))):
             print(f"| MSM G{g} (blocking czk_msm) | 2^{log_n} | {lanes} | {dt*1e3:.2f} | {gb:.1f} | {gb/8000:.5f} | {lanes*n/dt:.3g} pts/s |")
             del s
         b.release()
+# ---- callers either side of the NTT: constraint evaluation and division by (X - z) ------------------------------------
+for log_m in (20, 22):
+    m, lanes = 1 << log_m, 4
+    one = np.array([9015221291577245683, 8239323489949974514, 1646089257421115374, 958099254763297437], dtype=np.uint64)   # R mod r
+    for kind in ("unit", "dense3"):
+        if kind == "unit":            # the squaring circuit's shape: one term per row, coefficient 1
+            rp = np.arange(m + 1, dtype=np.uint64)
+            col = np.arange(m, dtype=np.uint32)
+            cf = np.tile(one, (m, 1))
+        else:                          # 3 terms per row, general coefficients, random columns
+            rp = (3 * np.arange(m + 1)).astype(np.uint64)
+            col = np.random.default_rng(1).integers(0, m, size=3 * m).astype(np.uint32)
+            cf = rand_fr_canonical(5, 4096)[np.arange(3 * m) % 4096]
+        mat = ctx.r1cs_matrix_register(rp, col, cf, m)
+        z = torch.from_numpy(rand_fr_canonical(7, 4096).view(np.int64)).cuda().repeat(lanes * m // 4096, 1).contiguous()
+        out = torch.empty((lanes, m, 4), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        dt = timed(lambda: ctx.r1cs_matvec(mat, z.data_ptr(), lanes=lanes, out=out.data_ptr(), z_stride=m, out_stride=m, mem=czk.CZK_MEM_DEVICE), 5)
+        nnz = col.size
+        alg = m * 4 + nnz * 4 + (0 if kind == "unit" else nnz * 32) + lanes * (nnz * 32 + m * 32)   # row_ptr + col (+ coeff) + gathers + outputs
+        rows.append({"kernel": f"r1cs_matvec_{kind}", "log_size": log_m, "lanes": lanes, "ms": dt * 1e3, "alg_gbs": alg / dt / 1e9, "frac": alg / dt / 8e12})
+        print(f"| R1CS mat-vec ({kind}) | 2^{log_m} rows | {lanes} | {dt*1e3:.3f} | {alg/dt/1e9:.0f} | {alg/dt/8e12:.3f} | |")
+        mat.release()
+        del z, out
+for log_n in (20, 21, 23):
+    n, lanes = 1 << log_n, 2
+    p = torch.from_numpy(rand_fr_canonical(9, 4096).view(np.int64)).cuda().repeat(lanes * n // 4096, 1).contiguous()
+    q = torch.empty((lanes, n - 1, 4), dtype=torch.int64, device="cuda")
+    r = torch.empty((lanes, 4), dtype=torch.int64, device="cuda")
+    zpt = rand_fr_canonical(10, 1)[0]
+    torch.cuda.synchronize()
+    dt = timed(lambda: ctx.poly_div_linear(p.data_ptr(), zpt, lanes=lanes, n=n, quotient=q.data_ptr(), remainder=r.data_ptr(), mem=czk.CZK_MEM_DEVICE), 5)
+    alg = lanes * 2 * n * 32                                      # read the coefficients once, write the quotient once
+    rows.append({"kernel": "poly_div_linear", "log_size": log_n, "lanes": lanes, "ms": dt * 1e3, "alg_gbs": alg / dt / 1e9, "frac": alg / dt / 8e12,
+                 "mul_per_s": lanes * 2 * n / dt})
+    print(f"| poly / (X - z) | 2^{log_n} | {lanes} | {dt*1e3:.3f} | {alg/dt/1e9:.0f} | {alg/dt/8e12:.3f} | {lanes*2*n/dt:.3g} Fr |")
+    del p, q, r
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], "w"), indent=1)
