@@ -27,6 +27,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "czk.h"
@@ -249,6 +250,69 @@ struct KZG10 {
             ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, commitment.x.l, aff, inf, commitment.x.l));  // add_assign_mixed
         }
         return commitment;
+    }
+
+    // KZG10::compute_witness_polynomial (kzg10/mod.rs:200-224): p / (X - point); the remainder p(point) is dropped
+    // there and returned here because open() also needs Polynomial::evaluate (:247).
+    static std::vector<Fr> compute_witness_polynomial(const Context& ctx, const std::vector<Fr>& p, const Fr& point, Fr* evaluation = nullptr) {
+        std::vector<Fr> w(p.size() > 1 ? p.size() - 1 : 0);
+        Fr rem{{0, 0, 0, 0}};
+        ctx.check(czk_poly_div_linear(ctx.raw(), p.empty() ? nullptr : p[0].l, p.size(), 1, point.l, w.empty() ? nullptr : w[0].l, rem.l, CZK_MEM_HOST));
+        if (evaluation) *evaluation = rem;
+        return w;
+    }
+    // KZG10::open_with_witness_polynomial (kzg10/mod.rs:225-265): proof.w before into_affine; with hiding the second MSM
+    // runs over powers_of_gamma_g and random_v = blinding_p(point).
+    struct Proof {
+        G1Projective w;
+        std::optional<Fr> random_v;
+    };
+    static Proof open(const G1Bases& powers_of_g, const std::vector<Fr>& p, const Fr& point, const G1Bases* powers_of_gamma_g = nullptr,
+                      const std::vector<Fr>* blinding_p = nullptr) {
+        const Context& ctx = powers_of_g.ctx();
+        std::vector<Fr> witness = compute_witness_polynomial(ctx, p, point);
+        if (witness.size() > powers_of_g.len()) throw Panic(CZK_ERR_SIZE, "TooManyCoefficients (check_degree_is_too_large)");
+        Proof proof{G1Affine::multi_scalar_mul(powers_of_g, witness), std::nullopt};
+        if (powers_of_gamma_g && blinding_p) {
+            Fr v{{0, 0, 0, 0}};
+            std::vector<Fr> hiding = compute_witness_polynomial(ctx, *blinding_p, point, &v);
+            G1Projective hw = G1Affine::multi_scalar_mul(*powers_of_gamma_g, hiding);
+            ctx.check(czk_jac_add(ctx.raw(), CZK_G1, proof.w.x.l, hw.x.l, proof.w.x.l));       // w += ...
+            proof.random_v = v;
+        }
+        return proof;
+    }
+};
+
+// One of ConstraintMatrices::{a, b, c} (Vec<Vec<(F, usize)>>, ark-relations) pinned on the GPU in CSR form, and
+// evaluate_constraint over all of its rows (mpc-snarks/src/groth/r1cs_to_qap.rs:12-42, :70-77, :95-100).
+struct ConstraintMatrix {
+    const Context* ctx_;
+    czk_r1cs_matrix* h_ = nullptr;
+    size_t rows_ = 0;
+    ConstraintMatrix(const Context& ctx, const std::vector<std::vector<std::pair<Fr, size_t>>>& rows, size_t n_vars) : ctx_(&ctx), rows_(rows.size()) {
+        std::vector<uint64_t> row_ptr(rows.size() + 1, 0);
+        std::vector<uint32_t> col;
+        std::vector<Fr> coeff;
+        for (size_t i = 0; i < rows.size(); i++) {
+            for (const auto& term : rows[i]) {
+                coeff.push_back(term.first);
+                col.push_back((uint32_t)term.second);
+            }
+            row_ptr[i + 1] = col.size();
+        }
+        ctx.check(czk_r1cs_matrix_register(ctx.raw(), row_ptr.data(), col.data(), coeff.empty() ? nullptr : coeff[0].l, rows.size(), col.size(), n_vars,
+                                           CZK_MEM_HOST, &h_));
+    }
+    ConstraintMatrix(const ConstraintMatrix&) = delete;
+    ConstraintMatrix& operator=(const ConstraintMatrix&) = delete;
+    ~ConstraintMatrix() { czk_r1cs_matrix_release(h_); }
+    // rows x full_assignment; the result has `out_len` >= rows elements, the tail zero (`vec![zero; domain_size]`, :66-67)
+    std::vector<Fr> evaluate(const std::vector<Fr>& full_assignment, size_t out_len) const {
+        std::vector<Fr> out(out_len < rows_ ? rows_ : out_len, Fr{{0, 0, 0, 0}});
+        ctx_->check(czk_r1cs_matvec(ctx_->raw(), h_, full_assignment.empty() ? nullptr : full_assignment[0].l, full_assignment.size(), 1,
+                                    out[0].l, out.size(), CZK_MEM_HOST));
+        return out;
     }
 };
 

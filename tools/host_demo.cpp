@@ -99,6 +99,57 @@ int main() {
         REQUIRE(!inf && memcmp(aff, want, 96) == 0);
     }
 
+    // KZG10::open against the defining identity, in the exponent: with powers_of_g[i] = [tau^i] G,
+    //   commit(p) - [p(z)] G == [tau - z] * open(p, z).w          (e(C - vG, H) = e(w, (tau - z) H) without the pairing)
+    {
+        const uint64_t tau = 5, zpt = 2;
+        const size_t deg1 = 24;                                    // 5^23 < 2^64
+        std::vector<uint64_t> pw(4 * (deg1 + 1), 0);
+        uint64_t t = 1;
+        for (size_t i = 0; i < deg1; i++, t *= tau) pw[4 * i] = t;
+        pw[4 * deg1] = 1;                                          // G itself
+        std::vector<uint64_t> ppts(12 * (deg1 + 1));
+        ctx.check(czk_fixed_base_points(ctx.raw(), CZK_G1, pw.data(), deg1 + 1, ppts.data(), CZK_MEM_HOST));
+        G1Bases powers(ctx, ppts.data(), nullptr, deg1);
+        std::vector<uint64_t> craw;
+        for (size_t i = 0; i < deg1; i++) craw.push_back(1000003 * i + 17);
+        std::vector<Fr> poly = fr_from_u64(ctx, craw);
+        Fr zf = fr_from_u64(ctx, {zpt})[0], value;
+        std::vector<Fr> wit = KZG10::compute_witness_polynomial(ctx, poly, zf, &value);
+        REQUIRE(wit.size() == deg1 - 1);
+        KZG10::Proof proof = KZG10::open(powers, poly, zf);
+        REQUIRE(!proof.random_v.has_value());
+        G1Projective cm = KZG10::commit(powers, poly);
+        // lhs = cm + [-value] G : one-point MSM with the negated Montgomery scalar
+        Fr zero{{0, 0, 0, 0}}, negv;
+        ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_SUB, zero.l, value.l, negv.l, 1, CZK_MEM_HOST));
+        uint8_t no_inf = 0;
+        G1Projective vg;
+        ctx.check(czk_msm_g1(ctx.raw(), &ppts[12 * deg1], &no_inf, negv.l, 1, 1, CZK_SCALAR_MONTGOMERY, vg.x.l));
+        G1Projective lhs;
+        ctx.check(czk_jac_add(ctx.raw(), CZK_G1, cm.x.l, vg.x.l, lhs.x.l));
+        // rhs = [tau - z] w
+        uint64_t waff[12], laff[12], raff[12];
+        uint8_t winf = 0, linf = 0, rinf = 0;
+        ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, proof.w.x.l, 1, waff, &winf));
+        REQUIRE(!winf);
+        uint64_t kk[4] = {tau - zpt, 0, 0, 0};
+        G1Projective rhs;
+        ctx.check(czk_msm_g1(ctx.raw(), waff, &no_inf, kk, 1, 1, CZK_SCALAR_CANONICAL, rhs.x.l));
+        ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, lhs.x.l, 1, laff, &linf));
+        ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, rhs.x.l, 1, raff, &rinf));
+        REQUIRE(!linf && !rinf && memcmp(laff, raff, 96) == 0);
+    }
+
+    // ConstraintMatrix::evaluate: rows {z0 + 3 z2, (empty), z1} on z = (2, 5, 7)
+    {
+        std::vector<Fr> c = fr_from_u64(ctx, {1, 3, 2, 5, 7, 23});
+        std::vector<std::vector<std::pair<Fr, size_t>>> rows = {{{c[0], 0}, {c[1], 2}}, {}, {{c[0], 1}}};
+        ConstraintMatrix mat(ctx, rows, 3);
+        std::vector<Fr> ev = mat.evaluate({c[2], c[3], c[4]}, 4);
+        REQUIRE(ev.size() == 4 && eq(ev[0], c[5]) && eq(ev[1], Fr{{0, 0, 0, 0}}) && eq(ev[2], c[3]) && eq(ev[3], Fr{{0, 0, 0, 0}}));
+    }
+
     // witness map of the 6-constraint squaring circuit (proof.rs:304-344): quotient is exact => h[D-1] == 0
     const size_t N = 6;
     auto d8 = Radix2EvaluationDomain::create(ctx, N + 2);
