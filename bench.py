@@ -33,6 +33,7 @@ import torch
 R_MOD = 8444461749428370424248824938781546531375899335154063827935233455917409239041
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 REF_PROOFS_PER_S = 3.0 / (328.957 + 317.213 + 320.422)   # reference's published 2^20 SPDZ-2pc timings
+MADS_PER_MIXED_ADD = 7 * 378 + 2 * 287 + (2 * 196 + 182)   # 7 multiplies, 2 squarings, 1 fused two-product multiply (fqu.h)
 MAD_PEAK_GOPS = 27000.0  # measured v_mad_u64_u32 lane-ops/s on MI355X (tools/microbench.hip), G lane-ops/s
 
 
@@ -46,12 +47,17 @@ def to_mont_limbs(vals):
 class Groth16Local:
     """Device-resident state + the per-step pipeline (mpc-snarks/src/groth/{r1cs_to_qap.rs:47-113, prover.rs:66-178})."""
 
-    def __init__(self, czk, ctx, log_n: int, parties: int, seed: int = 0xC0FFEE):
+    def __init__(self, czk, ctx, log_n: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None):
+        """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
+        configs[1]); with a strict subset, `exchange` (parallel.all_gather_shares) plays mpc-net's broadcast in the two
+        opens of the witness map."""
         from util import rand_fr_canonical
         self.czk, self.ctx = czk, ctx
         self.N = 1 << log_n
         self.P = parties
-        self.lanes = 2 * parties                      # SPDZ: sh + mac per party (share/spdz.rs:50-53)
+        self.local = list(range(parties)) if local_parties is None else list(local_parties)
+        self.exchange = exchange
+        self.lanes = 2 * len(self.local)              # SPDZ: sh + mac per party (share/spdz.rs:50-53)
         self.log_d = (self.N + 2 - 1).bit_length()    # D = next_pow2(N + num_instance) (r1cs_to_qap.rs:63-65)
         self.D = 1 << self.log_d
         N, D, L = self.N, self.D, self.lanes
@@ -107,9 +113,9 @@ class Groth16Local:
         self.a0, self.b0, self.c0 = lanes_buf(), lanes_buf(), lanes_buf()
         self.wit = torch.zeros((L, N, 4), dtype=torch.int64, device=dev)          # l-MSM scalars: witness
         self.asg = torch.zeros((L, N + 1, 4), dtype=torch.int64, device=dev)      # a/b-MSM scalars: [out, witness]
-        for p in range(parties):
+        for j, p in enumerate(self.local):
             for m in range(2):                                     # mac lane = sh * mac(), mac() = 1 (spdz.rs:41-47)
-                ln = 2 * p + m
+                ln = 2 * j + m
                 self.a0[ln, :N] = sh[p][:N]
                 self.b0[ln, :N] = sh[p][:N]
                 self.c0[ln, :N] = sh[p][1:N + 1]
@@ -121,9 +127,9 @@ class Groth16Local:
                 self.asg[ln, 1:] = sh[p][:N]
         # full assignment [1, out | w_0 .. w_{N-1}] per lane (r1cs_to_qap.rs:56-61); Public(1) lifted to the king's lanes
         self.full = torch.zeros((L, N + 2, 4), dtype=torch.int64, device=dev)
-        for p in range(parties):
+        for j, p in enumerate(self.local):
             for m in range(2):
-                ln = 2 * p + m
+                ln = 2 * j + m
                 if p == 0:
                     self.full[ln, 0] = one_t
                 self.full[ln, 1] = sh[p][N]
@@ -137,9 +143,10 @@ class Groth16Local:
         self.mat_c = ctx.r1cs_matrix_register(rp[: N + 1], np.concatenate([wcols[1:], np.array([1], dtype=np.uint32)]), ones[:N], N + 2)
         # dummy Beaver triples (wire/field.rs:41-60): king holds (1,1,1), everyone else (0,0,0)
         self.tx, self.ty, self.tz = lanes_buf(), lanes_buf(), lanes_buf()
+        self.king_lanes = [2 * j + m for j, p in enumerate(self.local) if p == 0 for m in range(2)]
         for t in (self.tx, self.ty, self.tz):
-            t[0, :] = one_t
-            t[1, :] = one_t
+            for ln in self.king_lanes:
+                t[ln, :] = one_t
         self.a, self.b, self.c = lanes_buf(), lanes_buf(), lanes_buf()
         self.sx, self.oy = (torch.zeros((D, 4), dtype=torch.int64, device=dev) for _ in range(2))
         self.chk = torch.zeros((2, D, 4), dtype=torch.int64, device=dev)
@@ -147,11 +154,19 @@ class Groth16Local:
         self.results = {}
         self.all_results = []
 
-    # one open of a 4-lane share vector: value = sum of sh lanes; MAC check vector = mac_share*value - sum(mac lanes)
+    # one open of a share vector: value = sum of sh lanes; MAC check vector = mac_share*value - sum(mac lanes)
     def _open(self, shares, out, chk):
         czk, ctx, D = self.czk, self.ctx, self.D
         ADD, SUB = 0, 1
         M = czk.CZK_MEM_DEVICE
+        if len(self.local) < self.P:
+            # party-per-GPU layout: mpc-net's broadcast (multi.rs:145-173) is an all-gather of every party's (sh, mac)
+            # lanes over RCCL; the sums and the MAC comparison of batch_open (spdz.rs:166-185) are one fused kernel
+            assert len(self.local) == 1
+            gathered = self.exchange(shares)                       # (P, 2, D, 4), rank order == party order
+            bad = ctx.fr_spdz_open(gathered.data_ptr(), self.P, D, out.data_ptr())
+            assert bad == 0, "SPDZ MAC check failed"
+            return
         ctx.fr_vec_op(ADD, shares[0].data_ptr(), shares[2].data_ptr(), out=out.data_ptr(), n=D, mem=M)
         for p in range(2, self.P):
             ctx.fr_vec_op(ADD, out.data_ptr(), shares[2 * p].data_ptr(), out=out.data_ptr(), n=D, mem=M)
@@ -196,7 +211,7 @@ class Groth16Local:
         self._open(self.b, self.oy, self.chk[1])
         for ln in range(L):
             ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
-                                  self.oy.data_ptr(), ln < 2, out=self.ab[ln].data_ptr(), n=D, mem=M)
+                                  self.oy.data_ptr(), ln in self.king_lanes, out=self.ab[ln].data_ptr(), n=D, mem=M)
         ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L, c_len=N)     # h = ab
         # --- the h MSM (prover.rs:104) needs the witness map's output; NOT flagged stable: the next proof's witness
         # map overwrites `ab`, so the context's stream waits for this MSM's digit extraction (library-side ordering)
@@ -287,6 +302,11 @@ def main():
     ap.add_argument("--parties", type=int, default=2)
     ap.add_argument("--cpu-sample-log-n", type=int, default=14)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", choices=("replica", "party"), default="replica",
+                    help="replica (default, BASELINE configs[1]): every GPU proves independently with all parties' lanes on it; "
+                         "party: ONE proof, party p's lanes on rank p (WORLD_SIZE == --parties), opens all-gathered over RCCL")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rigs with fewer GPUs than ranks)")
+    ap.add_argument("--device", type=int, default=None, help="GPU index for this rank (default LOCAL_RANK)")
     args = ap.parse_args()
 
     import czk_amd as czk
@@ -294,15 +314,22 @@ def main():
     rank, world, local_rank = parallel.env_rank_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    parallel.init("nccl")          # RCCL; only the timing reduction uses it (units are independent)
+    device = local_rank if args.device is None else args.device
+    torch.cuda.set_device(device)
+    parallel.init(args.backend)    # RCCL; replica layout: only the timing reduction uses it (units are independent)
+    party_layout = args.layout == "party"
+    if party_layout and world != args.parties:
+        raise SystemExit(f"--layout party needs one rank per party: WORLD_SIZE={world}, --parties {args.parties}")
     # torch's default stream has handle 0, which the C ABI reads as "make a private stream": use an explicit torch
     # stream so that torch's copies and the library's kernels are ordered on ONE stream.
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
-    ctx = czk.Context(local_rank, tstream.cuda_stream)
+    ctx = czk.Context(device, tstream.cuda_stream)
     assert tstream.cuda_stream != 0
-    prover = Groth16Local(czk, ctx, args.log_n, args.parties)
+    if party_layout:
+        prover = Groth16Local(czk, ctx, args.log_n, args.parties, local_parties=[rank], exchange=parallel.all_gather_shares)
+    else:
+        prover = Groth16Local(czk, ctx, args.log_n, args.parties)
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)
@@ -326,7 +353,8 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     assert len(prover.all_results) == args.steps and all(r["h"].any() and r["b_g2"].any() for r in prover.all_results)
-    dt = parallel.max_over_ranks(dt, device="cuda")
+    dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
+    proofs = args.steps if party_layout else world * args.steps      # party layout: all ranks work on the same proof
 
     # every pipelined proof works on the same inputs, so all of them must yield the same group elements (compared in
     # affine: summation order inside buckets is not deterministic, Jacobian triples differ) -- guards the pipelining
@@ -340,6 +368,17 @@ def main():
                 assert np.array_equal(aff[k][0], ref_aff[k][0]) and np.array_equal(aff[k][1], ref_aff[k][1]), f"pipelined proofs disagree on {k}"
     # MAC-check vectors of the two opens must be all zero (share/spdz.rs:176-183)
     assert not bool(prover.chk.any().item()), "SPDZ MAC check failed"
+    # digest of the proof's group elements (affine, key order, party order, sh then mac): equal across layouts
+    import hashlib
+    mine = b"".join(ref_aff[k][0][ln].tobytes() + bytes([int(ref_aff[k][1][ln])]) for k in ("h", "l", "a", "b_g1", "b_g2")
+                    for ln in range(prover.lanes)) if not party_layout else None
+    if party_layout:
+        per_key = {k: b"".join(ref_aff[k][0][ln].tobytes() + bytes([int(ref_aff[k][1][ln])]) for ln in range(prover.lanes))
+                   for k in ("h", "l", "a", "b_g1", "b_g2")}
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, per_key)
+        mine = b"".join(g[k] for k in ("h", "l", "a", "b_g1", "b_g2") for g in gathered)
+    digest = hashlib.sha256(mine).hexdigest()
 
     acc_ms, acc_n = ctx.profile_read("msm_accumulate_g1")
     breakdown = {k: ctx.profile_read(k)[0] / max(1, args.steps) for k in
@@ -358,7 +397,7 @@ def main():
 
     out = {
         "metric": "collaborative Groth16 proofs/sec (BLS12-377, 2^20 constraints, SPDZ N=2)",
-        "value": world * args.steps / dt,
+        "value": proofs / dt,
         "unit": "proofs/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -369,15 +408,18 @@ def main():
         "scaling": "weak",
         # Groth16 SPDZ 2 parties 2^20 on 2x GCP n2-standard-2 (1 core each): 328.957 / 317.213 /
         # 320.422 s per proof (mpc-snarks/analysis/data/weak_1_20.csv:21-23) -> 1 / mean = 0.003104 proofs/s
-        "vs_baseline": (world * args.steps / dt) / REF_PROOFS_PER_S if args.log_n == 20 and args.parties == 2 else None,
+        "vs_baseline": (proofs / dt) / REF_PROOFS_PER_S if args.log_n == 20 and args.parties == 2 else None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": f"Groth16 SPDZ {args.parties} parties, BLS12-377, 2^{args.log_n} constraints (squaring circuit), both parties' "
-                               f"share-local NTT+MSM on one GPU: {7 * 2 * args.parties} Fr NTT lanes of 2^{prover.log_d} + 5 MSMs x "
-                               f"{2 * args.parties} share lanes",
+        "config": {"workload": f"Groth16 SPDZ {args.parties} parties, BLS12-377, 2^{args.log_n} constraints (squaring circuit), "
+                               + ("both parties' share-local NTT+MSM on one GPU" if not party_layout else "one party per GPU") +
+                               f": {7 * prover.lanes} Fr NTT lanes of 2^{prover.log_d} + 5 MSMs x {prover.lanes} share lanes per GPU",
                    "constraints": 1 << args.log_n, "domain": prover.D, "parties": args.parties, "share_lanes": prover.lanes,
-                   "parallelism": f"{world} independent proofs (one per GPU), no data-path collective; consecutive proofs on a GPU are "
-                                  "pipelined (ms_per_step = throughput; latency_ms_single_proof = one proof alone)"},
+                   "parallelism": (f"{world} independent proofs (one per GPU), no data-path collective; consecutive proofs on a GPU are "
+                                   "pipelined (ms_per_step = throughput; latency_ms_single_proof = one proof alone)") if not party_layout else
+                                  (f"ONE proof over {world} GPUs, party p's two share lanes on rank p; the two opens of the witness map are "
+                                   f"all-gathers over {args.backend} (mpc-net broadcast) followed by the fused sum + MAC-check kernel"),
+                   "layout": args.layout, "results_sha256": digest},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
@@ -385,10 +427,11 @@ def main():
                      "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md",
                      "valu": {"mixed_adds_per_s": madds / (acc_ms / 1e3) if acc_ms > 0 else 0.0,
                               "fq_mul_equiv_per_s": 10 * madds / (acc_ms / 1e3) if acc_ms > 0 else 0.0,
-                              "mad_u64_u32_gops": 10 * 378 * madds / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0,
+                              "mad_u64_u32_gops": MADS_PER_MIXED_ADD * madds / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0,
                               "mad_u64_u32_peak_gops": MAD_PEAK_GOPS,
-                              "comment": "XYZZ mixed add = 8M+2S = 10 Montgomery multiplies; unsaturated 14x28-bit limbs: "
-                                         "378 v_mad_u64_u32 per multiply and no carry instructions (csrc/fqu.h)"}},
+                              "comment": "XYZZ mixed add = 8M+2S = 10 Montgomery multiplies; unsaturated 14x28-bit limbs: 378 v_mad_u64_u32 "
+                                         "per multiply, 287 per squaring, one reduction shared by the two products of Y3 -> 3416 per "
+                                         "mixed addition, no carry instructions (csrc/fqu.h)"}},
         "breakdown_ms_per_step": breakdown,
         "setup_key_s": prover.setup_key_s,
     }

@@ -71,6 +71,14 @@ def all_gather_shares(share: torch.Tensor) -> torch.Tensor:
     (share/spdz.rs:166-185) is then a local, share-linear pointwise step."""
     if not dist.is_initialized():
         return share.unsqueeze(0)
-    out = [torch.empty_like(share) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, share.contiguous())
-    return torch.stack(out)
+    world = dist.get_world_size()
+    if dist.get_backend() == "gloo":
+        # CPU tests, and rigs without one GPU per party (several ranks on one device): stage through the host
+        host = share.contiguous().cpu()
+        out = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(out, host)
+        return torch.stack(out).to(share.device)
+    # RCCL: one all-gather straight into the (world, ...) result
+    out = torch.empty((world,) + tuple(share.shape), dtype=share.dtype, device=share.device)
+    dist.all_gather_into_tensor(out, share.contiguous())
+    return out
