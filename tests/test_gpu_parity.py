@@ -210,7 +210,7 @@ def test_msm_empty_and_all_zero(ctx, czk, orc):
     b0.release()
 
 
-@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (2, (1 << 17) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7)])
+@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (2, (1 << 17) + 1), (2, (1 << 20) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7)])
 def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, n):
     """Size-independent check at BASELINE scale: bases P_i = [k_i] G, so MSM(P, s) must equal
     [sum k_i s_i mod r] G; plus linearity between the two lanes.  Sizes: the Groth16 a/b queries at 2^20
@@ -479,7 +479,7 @@ def test_r1cs_matrix_rejects_malformed_input(ctx, czk, orc):
     mat.release()
 
 
-@pytest.mark.parametrize("n", [0, 1, 2, 127, 128, 129, 128 * 128 + 5, (1 << 17) + 3])
+@pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 127, 129, 32 * 32 + 5, 32 * 32 * 32 + 7, (1 << 17) + 3])   # around the 32-coefficient segment levels
 def test_poly_div_linear_matches_oracle(ctx, czk, orc, n):
     lanes = 2
     p = orc.fr_from_repr(rand_fr_canonical(300 + n, lanes * max(n, 1)))[: lanes * n].reshape(lanes, n, 4)
