@@ -275,6 +275,15 @@ class Context:
         self._ck(lib().czk_poly_div_linear(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(qp), _ptr(remainder), C.c_int(mem)))
         return quotient, remainder
 
+    def fr_prefix_product(self, x, out=None, n=None, mem=CZK_MEM_HOST):
+        """Running products of a public Fr vector (partial_products' local loop)."""
+        if mem == CZK_MEM_HOST:
+            x = np.ascontiguousarray(x, np.uint64).reshape(-1, 4)
+            n = x.shape[0]
+            out = np.zeros_like(x)
+        self._ck(lib().czk_fr_prefix_product(self._h, _ptr(x if n else None), C.c_size_t(n), _ptr(out if n else None), C.c_int(mem)))
+        return out
+
     def fixed_base_points(self, group, k, out=None, n=None, mem=CZK_MEM_HOST):
         aw = 12 if group == CZK_G1 else 24
         if mem == CZK_MEM_HOST:

@@ -128,6 +128,49 @@ static int suffix_horner(czk_ctx* ctx, const u64* in, size_t in_stride, size_t n
     return CZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Running products out[i] = x_0 * ... * x_i of a public vector: the local loop of partial_products between its open and
+// the final scale (mpc-algebra/src/share/field.rs:169-172; Plonk's grand product).  Same three-phase segment scheme as
+// the suffix Horner sums, with multiplication as the operator.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seg_product(const u64* in, size_t n, u64* S, size_t n_seg) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg) return;
+    size_t a = t * SEG, b = a + SEG < n ? a + SEG : n;
+    Fr r = pfr_load(in, a);
+    for (size_t i = a + 1; i < b; i++) r = fp_mul(r, pfr_load(in, i));
+    pfr_store(S, t, r);
+}
+// carry[t - 1] = product of everything before segment t (inclusive scan of the segment products)
+__global__ __launch_bounds__(256) void k_seg_product_fill(const u64* in, size_t n, const u64* carry, size_t n_seg, u64* out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg) return;
+    size_t a = t * SEG, b = a + SEG < n ? a + SEG : n;
+    Fr r = pfr_load(in, a);
+    if (carry && t) r = fp_mul(pfr_load(carry, t - 1), r);
+    pfr_store(out, a, r);
+    for (size_t i = a + 1; i < b; i++) {
+        r = fp_mul(r, pfr_load(in, i));
+        pfr_store(out, i, r);
+    }
+}
+static int prefix_product(czk_ctx* ctx, const u64* in, size_t n, u64* out, char*& ws) {
+    const size_t n_seg = (n + SEG - 1) / SEG;
+    u64* carry = nullptr;
+    if (n_seg > 1) {
+        u64* S = (u64*)ws;
+        ws += n_seg * 32;
+        u64* C = (u64*)ws;
+        ws += n_seg * 32;
+        hipLaunchKernelGGL(k_seg_product, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, ctx->stream, in, n, S, n_seg);
+        CZK_TRY(prefix_product(ctx, S, n_seg, C, ws));
+        carry = C;
+    }
+    hipLaunchKernelGGL(k_seg_product_fill, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, ctx->stream, in, n, carry, n_seg, out);
+    CZK_HIP(ctx, hipGetLastError());
+    return CZK_OK;
+}
+
 }  // namespace czk
 
 using namespace czk;
@@ -276,4 +319,20 @@ extern "C" int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t 
     CZK_TRY(sq.to_host(quotient, lanes * qn * 32));
     if (remainder) CZK_TRY(sr.to_host(remainder, lanes * 32));
     return CZK_OK;
+}
+
+extern "C" int czk_fr_prefix_product(czk_ctx* ctx, const uint64_t* x, size_t n, uint64_t* out, int mem) {
+    if (!ctx || (n && (!x || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null prefix_product argument") : CZK_ERR_ARG;
+    if (!n) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    StagedP sx{ctx}, so{ctx};
+    CZK_TRY(sx.to_device(x, n * 32, mem));
+    CZK_TRY(so.to_device(mem == CZK_MEM_HOST ? nullptr : out, n * 32, mem));
+    CZK_TRY(ensure_buf(ctx, ctx->poly_scratch, suffix_horner_scratch(n, 1) + 256));
+    char* ws = (char*)ctx->poly_scratch.p;
+    {
+        ProfScope ps(ctx, "fr_prefix_product");
+        CZK_TRY(prefix_product(ctx, (const u64*)sx.dev, n, (u64*)so.dev, ws));
+    }
+    return so.to_host(out, n * 32);
 }

@@ -130,6 +130,11 @@ int czk_r1cs_matvec(czk_ctx* ctx, const czk_r1cs_matrix* a, const uint64_t* z, s
 int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* quotient,
                         uint64_t* remainder, int mem);
 
+/* out[i] = x[0] * x[1] * ... * x[i] over a PUBLIC vector: the sequential loop of partial_products between its
+ * batch_open and the final scale (mpc-algebra/src/share/field.rs:169-172; Plonk's grand product).  The share-side
+ * scale that follows (:177-179) is czk_fr_vec_op(CZK_OP_MUL) per lane.  out may alias x only in HOST mode. */
+int czk_fr_prefix_product(czk_ctx* ctx, const uint64_t* x, size_t n, uint64_t* out, int mem);
+
 /* Fr::into_repr / from_repr over a vector (fields/arithmetic.rs:59-81, macros.rs:443-454) -- also the wire format. */
 int czk_fr_into_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
 int czk_fr_from_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);

@@ -561,3 +561,15 @@ void orc_poly_div_linear(const uint64_t *coeffs, size_t n, const uint64_t *z, ui
     if (len == 1) memcpy(remainder, &rem[0], 32);
     free(rem);
 }
+
+/* the public running-product loop of partial_products (mpc-algebra/src/share/field.rs:169-172) */
+void orc_fr_prefix_product(const uint64_t *x, size_t n, uint64_t *out) {
+    fr_t last;
+    for (size_t i = 0; i < n; i++) {
+        fr_t v;
+        memcpy(&v, x + 4 * i, 32);
+        if (i) fr_mul(&v, &v, &last);
+        last = v;
+        memcpy(out + 4 * i, &v, 32);
+    }
+}

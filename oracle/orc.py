@@ -271,3 +271,11 @@ def poly_div_linear(coeffs, z):
     qbuf = q if len(q) else np.zeros((1, 4), dtype=np.uint64)
     lib().orc_poly_div_linear(_p(coeffs) if n else None, C.c_size_t(n), _p(z), _p(qbuf), _p(r))
     return q, r
+
+
+def fr_prefix_product(x):
+    x = np.ascontiguousarray(_u64(x).reshape(-1, 4))
+    out = np.zeros_like(x)
+    if len(x):
+        lib().orc_fr_prefix_product(_p(x), C.c_size_t(len(x)), _p(out))
+    return out

@@ -540,3 +540,13 @@ def test_party_per_rank_layout_matches_single_gpu_layout():
     d2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert d2["n_gpus"] == 2 and d2["config"]["layout"] == "party"
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 31, 32, 33, 1029, 32 * 32 * 32 + 7, (1 << 18) + 1])
+def test_fr_prefix_product_matches_oracle(ctx, czk, orc, n):
+    """czk_fr_prefix_product vs the sequential loop of partial_products (share/field.rs:169-172)."""
+    x = orc.fr_from_repr(rand_fr_canonical(400 + n, max(n, 1)))[:n]
+    if n > 40:
+        x[37] = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+    got = ctx.fr_prefix_product(x)
+    assert np.array_equal(got, orc.fr_prefix_product(x))

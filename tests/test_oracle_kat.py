@@ -275,3 +275,14 @@ def test_c_oracle_poly_div_linear_vs_bigint(orc):
         if n:
             rec[0] = (rec[0] + r_want) % P.R_MOD
         assert rec == p
+
+
+def test_c_oracle_prefix_product_vs_bigint(orc):
+    rng = random.Random(13)
+    xs = _rand_fr(rng, 50)
+    want, run = [], 1
+    for v in xs:
+        run = run * v % P.R_MOD
+        want.append(run)
+    got = orc.fr_prefix_product(orc.ints_to_limbs([x * P.FR_MONT_R % P.R_MOD for x in xs], 4))
+    assert orc.limbs_to_ints(orc.fr_into_repr(got)) == want
