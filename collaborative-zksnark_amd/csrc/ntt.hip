@@ -149,9 +149,10 @@ __global__ __launch_bounds__(256) void k_ntt_final(PassArgs a) {
             unsigned l0 = ((rr >> q) << (q + 1)) | llow;
             unsigned l1 = l0 | (1u << q);
             Fr lo = lds_get(smem, t * RS + l0), hi = lds_get(smem, t * RS + l1);
-            Fr w = lds_get(tw_lds, ((1u << q) - 1u) + llow);
             lds_put(smem, t * RS + l0, fp_add(lo, hi));
-            lds_put(smem, t * RS + l1, fp_mul(fp_sub(lo, hi), w));
+            // the last stage's only twiddle is w^0 = 1 (the reference multiplies by roots[0] = 1, fft.rs:167-180: same value)
+            Fr d = fp_sub(lo, hi);
+            lds_put(smem, t * RS + l1, q == 0 ? d : fp_mul(d, lds_get(tw_lds, ((1u << q) - 1u) + llow)));
         }
         __syncthreads();
     }
