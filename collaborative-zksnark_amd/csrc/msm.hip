@@ -336,10 +336,6 @@ static unsigned num_windows(unsigned c) { return (254 + c - 1) / c; }
 
 // window width for n bases: minimise W(c) * n mixed adds + ~3 * 2^(c-1) reduction adds
 static unsigned choose_c(size_t n) {
-    if (const char* e = getenv("CZK_MSM_C")) {   // tuning override
-        int v = atoi(e);
-        if (v >= 2 && v <= 22) return (unsigned)v;
-    }
     unsigned best = 2;
     double best_cost = 1e300;
     for (unsigned c = 2; c <= 22; c++) {
@@ -517,18 +513,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 
 int msm_pipeline_init(czk_ctx* ctx) {
     if (ctx->s_sort) return CZK_OK;
-    // the accumulate kernel saturates every SIMD for tens of ms; give the short sort / reduce stages priority so
-    // they are not starved behind it (they are on the critical path of the NEXT accumulate)
-    int prio_lo = 0, prio_hi = 0;
-    CZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lower = higher priority
-    if (!getenv("CZK_STREAM_PRIO")) prio_hi = prio_lo;   // measured: no gain from prioritising sort / reduce (default off)
+    // (stream priorities for the short sort / reduce stages were measured: no gain, so all three are equal)
     if (const char* e = getenv("CZK_MSM_SLOTS")) {
         int v = atoi(e);
         if (v >= 1 && v <= czk_ctx::MSM_SLOTS) ctx->msm_slots_in_use = v;
     }
-    CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_sort, hipStreamNonBlocking, prio_hi));
-    CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_acc, hipStreamNonBlocking, prio_lo));
-    CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_red, hipStreamNonBlocking, prio_hi));
+    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_sort, hipStreamNonBlocking));
+    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_acc, hipStreamNonBlocking));
+    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_red, hipStreamNonBlocking));
     CZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
     for (auto& s : ctx->msm_slots) {
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_sorted, hipEventDisableTiming));

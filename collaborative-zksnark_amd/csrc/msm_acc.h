@@ -282,24 +282,4 @@ __global__ void k_accumulate_u2_cleanup(const u64* pts, size_t B, u64* buckets, 
 
 #endif
 
-// G2 variant: one bucket per lane PAIR (fq2p.h).  Same algorithm, same memory formats.
-template <class FP>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_pair(
-    const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets) {
-    size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
-    if (t >= B) return;
-    const unsigned lane = blockIdx.y;
-    const size_t b = perm[(size_t)lane * B + t];
-    const u32* srt = sorted + (size_t)lane * sorted_stride;
-    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
-    XYZZ<FP> acc = XYZZ<FP>::zero();
-    for (u32 e = 0; e < cnt; e++) {
-        u32 code = srt[off + e];
-        Affine<FP> p = aff_load<FP>(pts + (size_t)24 * (code & 0x7fffffffu));
-        if (code & 0x80000000u) p.y = f_neg(p.y);
-        acc = xyzz_add_mixed(acc, p);
-    }
-    xyzz_store<FP>(buckets + (size_t)48 * ((size_t)lane * B + b), acc);
-}
-
 }  // namespace czk

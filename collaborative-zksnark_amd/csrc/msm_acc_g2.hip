@@ -9,12 +9,8 @@
 namespace czk {
 void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes) {
-    // one bucket per lane pair: 64 buckets per 128-thread workgroup
-    if (!getenv("CZK_G2_PAIR"))   // default: one bucket per lane; CZK_G2_PAIR=1 selects the lane-pair kernel (fq2p.h)
-        hipLaunchKernelGGL(k_accumulate<Fq2>, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                           sorted_stride, buckets);
-    else
-    hipLaunchKernelGGL(k_accumulate_pair<Fq2P>, dim3((unsigned)((B + 63) / 64), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
+    // saturated fallback (CZK_MSM_SAT_G2=1 at registration): one bucket per thread
+    hipLaunchKernelGGL(k_accumulate<Fq2>, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
                        sorted_stride, buckets);
 }
 void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,

@@ -323,15 +323,17 @@ def test_groth16_local_pipeline_config0_matches_reference(ctx, czk, orc):
     c2.close()
 
 
-def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch):
-    """CZK_MSM_SAT=1 selects the saturated G1 accumulate kernel (k_accumulate<Fq>); keep it covered."""
-    monkeypatch.setenv("CZK_MSM_SAT", "1")
+@pytest.mark.parametrize("g,env", [(1, "CZK_MSM_SAT"), (2, "CZK_MSM_SAT_G2")])
+def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch, g, env):
+    """CZK_MSM_SAT=1 / CZK_MSM_SAT_G2=1 select the saturated accumulate kernels (k_accumulate<Fq>, k_accumulate<Fq2>)
+    at registration; keep them covered."""
+    monkeypatch.setenv(env, "1")
     c2 = czk.Context(0)
-    _, bases = _bases(c2, 1, 500, 41)
+    _, bases = _bases(c2, g, 500, 41)
     sc = rand_fr_canonical(42, 500)
     inf = np.zeros(500, dtype=np.uint8)
-    b = c2.register_bases(1, bases, inf)
-    assert _same_point(c2, orc, 1, c2.msm(b, sc)[0], orc.msm(1, bases, inf, sc))
+    b = c2.register_bases(g, bases, inf)
+    assert _same_point(c2, orc, g, c2.msm(b, sc)[0], orc.msm(g, bases, inf, sc))
     b.release()
     c2.close()
 
