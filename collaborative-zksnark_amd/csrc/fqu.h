@@ -434,6 +434,67 @@ __device__ __forceinline__ FqU fqu_mul_add(const FqU& a, const FqU& b, const FqU
     return r;
 }
 
+// (a b + c d + e f + g h) / R' mod p with ONE Montgomery reduction.  Column capacity: every limb product < 2^58
+// (at most one lazy factor, < 2^30, per product), so a column holds < 56 * 2^58 + 13 * 2^56 < 2^64.
+__device__ __forceinline__ FqU fqu_mul_add4(const FqU& a, const FqU& b, const FqU& c, const FqU& d, const FqU& e, const FqU& f, const FqU& g,
+                                            const FqU& h) {
+    constexpr int N = 14;
+    u32 m[N];
+    FqU r;
+    u64 acc = 0;
+    static_for<0, 2 * N - 1>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        constexpr int i0 = k < N ? 0 : k - N + 1;
+        constexpr int cab = (k < N ? k : N - 1) - i0 + 1;
+        {
+            u32 xs[cab], ys[cab];
+#pragma unroll
+            for (int t = 0; t < cab; t++) {
+                xs[t] = a.l[i0 + t];
+                ys[t] = b.l[k - i0 - t];
+            }
+            MadU<cab>::run(acc, xs, ys);
+#pragma unroll
+            for (int t = 0; t < cab; t++) {
+                xs[t] = c.l[i0 + t];
+                ys[t] = d.l[k - i0 - t];
+            }
+            MadU<cab>::run(acc, xs, ys);
+#pragma unroll
+            for (int t = 0; t < cab; t++) {
+                xs[t] = e.l[i0 + t];
+                ys[t] = f.l[k - i0 - t];
+            }
+            MadU<cab>::run(acc, xs, ys);
+#pragma unroll
+            for (int t = 0; t < cab; t++) {
+                xs[t] = g.l[i0 + t];
+                ys[t] = h.l[k - i0 - t];
+            }
+            MadU<cab>::run(acc, xs, ys);
+        }
+        constexpr int cmp = (k < N ? k - 1 : N - 1) - i0 + 1;
+        if constexpr (cmp > 0) {
+            u32 xs[cmp], ys[cmp];
+#pragma unroll
+            for (int t = 0; t < cmp; t++) {
+                xs[t] = m[i0 + t];
+                ys[t] = fqu_p(k - i0 - t);
+            }
+            MadU<cmp>::run(acc, xs, ys);
+        }
+        if constexpr (k < N) {
+            m[k] = (0u - (u32)acc) & FQU_MASK;
+            acc += m[k];
+        } else {
+            r.l[k - N] = (u32)acc & FQU_MASK;
+        }
+        acc >>= 28;
+    });
+    r.l[N - 1] = (u32)acc;
+    return r;
+}
+
 // carry-propagate: limbs < 2^28 afterwards (top limb takes the rest)
 __device__ __forceinline__ FqU fqu_normalize(const FqU& a) {
     FqU r;
@@ -629,21 +690,49 @@ __device__ __forceinline__ Fq2U fq2u_sqr(const Fq2U& a) {
     r.c1 = fqu_normalize(r.c1);
     return r;
 }
+__device__ __forceinline__ u32 fqu_512p_u5(int i) {   // 512 p, every limb but the top >= 5 * 2^28
+    constexpr u32 m[14] = {0x50000200u, 0x57fffffbu, 0x50010a0cu, 0x5885fffbu, 0x502e16b5u, 0x574128fbu, 0x5de6c45au,
+                           0x5ea271deu, 0x55b3e5fcu, 0x5927633fu, 0x5b80d93du, 0x5d58c75bu, 0x5c2f8a1cu, 0x0035c743u};
+    return m[i];
+}
+// K p - 5 a, normalised (K = 16: a < 3.2 p; K = 512: a < 102 p): the beta * a1 operand of the schoolbook product below
+template <bool BIG>
+__device__ __forceinline__ FqU fqu_neg5(const FqU& a) {
+    FqU r;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.l[i] = (BIG ? fqu_512p_u5(i) : fqu_16p_u5(i)) - 5u * a.l[i];
+    return fqu_normalize(r);
+}
+// (a0 + a1 u)(b0 + b1 u) with u^2 = -5, schoolbook with ONE Montgomery reduction per component:
+//   c0 = a0 b0 + a1 (-5 b1),  c1 = a0 b1 + a1 b0          (4 x 196 + 2 x 182 = 1148 multiply-adds)
+// Karatsuba (fq2u_mul) needs 1134 but pays ~190 more instructions re-normalising the combinations of its three products;
+// n5b1 = fqu_neg5(b.c1) is shared by every product with the same b.  All operands normalised (limb products < 2^57);
+// results are multiply outputs (< 1.01 p + (a0 b0 + a1 n5b1) / 2^392, i.e. < 3 p for the operand values below).
+__device__ __forceinline__ Fq2U fq2u_mul_n5(const Fq2U& a, const Fq2U& b, const FqU& n5b1) {
+    Fq2U r;
+    r.c0 = fqu_mul_add(a.c0, b.c0, a.c1, n5b1);
+    r.c1 = fqu_mul_add(a.c0, b.c1, a.c1, b.c0);
+    return r;
+}
 __device__ __forceinline__ bool fqu_low_in(const FqU& a, u32 lo, u32 hi) { return (a.l[0] - lo) <= (hi - lo); }
 
 // In-place XYZZ mixed addition over Fq2U.  Returns false when H == 0 mod p is possible (both components of
 // H = U2 - X1 + 128 p equal j p for some j in (43, 145): low normalised limb == j).
 __device__ __forceinline__ bool fq2u_xyzz_acc_mixed(Fq2U& ax, Fq2U& ay, Fq2U& azz, Fq2U& azzz, const Fq2U& qx, const Fq2U& qy) {
-    Fq2U u2 = fq2u_mul(qx, azz);
+    // value bounds (units of p): table coordinates < 4, multiply outputs < 3, X < 85, Y < 36, H in (43, 131), r < 67
+    const FqU n5zz = fqu_neg5<false>(azz.c1);
+    Fq2U u2 = fq2u_mul_n5(qx, azz, n5zz);
     Fq2U pp{fqu_subn_128(u2.c0, ax.c0), fqu_subn_128(u2.c1, ax.c1)};
     if (fqu_low_in(pp.c0, 40, 150) && fqu_low_in(pp.c1, 40, 150)) return false;
-    Fq2U s2 = fq2u_mul(qy, azzz);
+    const FqU n5zzz = fqu_neg5<false>(azzz.c1);
+    Fq2U s2 = fq2u_mul_n5(qy, azzz, n5zzz);
     Fq2U r{fqu_subn_64(s2.c0, ay.c0), fqu_subn_64(s2.c1, ay.c1)};
-    Fq2U p2 = fq2u_sqr(pp);
-    azz = fq2u_mul(azz, p2);
-    Fq2U p3 = fq2u_mul(pp, p2);
-    azzz = fq2u_mul(azzz, p3);
-    Fq2U qv = fq2u_mul(ax, p2);
+    Fq2U p2 = fq2u_sqr(pp);                              // c1 = 2 v2 < 3 p
+    const FqU n5p2 = fqu_neg5<false>(p2.c1);
+    azz = fq2u_mul_n5(p2, azz, n5zz);
+    Fq2U p3 = fq2u_mul_n5(pp, p2, n5p2);
+    azzz = fq2u_mul_n5(p3, azzz, n5zzz);
+    Fq2U qv = fq2u_mul_n5(ax, p2, n5p2);
     Fq2U t = fq2u_sqr(r);
 #pragma unroll
     for (int i = 0; i < 14; i++) {                                        // X3 = t - p3 - 2 qv + 64 p
@@ -653,10 +742,17 @@ __device__ __forceinline__ bool fq2u_xyzz_acc_mixed(Fq2U& ax, Fq2U& ay, Fq2U& az
     ax.c0 = fqu_normalize(ax.c0);
     ax.c1 = fqu_normalize(ax.c1);
     Fq2U d{fqu_subn_128(qv.c0, ax.c0), fqu_subn_128(qv.c1, ax.c1)};
-    Fq2U e = fq2u_mul(r, d);
-    Fq2U f = fq2u_mul(ay, p3);
-    ay.c0 = fqu_subn_32(e.c0, f.c0);
-    ay.c1 = fqu_subn_32(e.c1, f.c1);
+    // Y3 = d r - Y1 PPP, each component four products under one reduction (operands: d, r, p3 normalised; -Y1 lazy)
+    const FqU n5r = fqu_neg5<true>(r.c1);
+    const FqU n5p3 = fqu_neg5<false>(p3.c1);
+    FqU nay0, nay1;                                      // 64 p - Y1 (Y1 < 36 p)
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        nay0.l[i] = fqu_64p(i) - ay.c0.l[i];
+        nay1.l[i] = fqu_64p(i) - ay.c1.l[i];
+    }
+    ay.c0 = fqu_mul_add4(d.c0, r.c0, d.c1, n5r, nay0, p3.c0, nay1, n5p3);
+    ay.c1 = fqu_mul_add4(d.c0, r.c1, d.c1, r.c0, nay0, p3.c1, nay1, p3.c0);
     return true;
 }
 
