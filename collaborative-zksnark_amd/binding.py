@@ -284,6 +284,17 @@ class Context:
         self._ck(lib().czk_fr_prefix_product(self._h, _ptr(x if n else None), C.c_size_t(n), _ptr(out if n else None), C.c_int(mem)))
         return out
 
+    def fr_batch_inverse(self, v, coeff=None, out=None, n=None, mem=CZK_MEM_HOST):
+        """batch_inversion_and_mul: out[i] = coeff / v[i] (zeros stay zero)."""
+        if mem == CZK_MEM_HOST:
+            v = np.ascontiguousarray(v, np.uint64).reshape(-1, 4)
+            n = v.shape[0]
+            out = np.zeros_like(v)
+        if coeff is not None:
+            coeff = np.ascontiguousarray(coeff, np.uint64).reshape(4)
+        self._ck(lib().czk_fr_batch_inverse(self._h, _ptr(v if n else None), C.c_size_t(n), _ptr(coeff), _ptr(out if n else None), C.c_int(mem)))
+        return out
+
     def fixed_base_points(self, group, k, out=None, n=None, mem=CZK_MEM_HOST):
         aw = 12 if group == CZK_G1 else 24
         if mem == CZK_MEM_HOST:

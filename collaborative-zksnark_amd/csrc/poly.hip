@@ -171,6 +171,37 @@ static int prefix_product(czk_ctx* ctx, const u64* in, size_t n, u64* out, char*
     return CZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// batch_inversion_and_mul (algebra/ff/src/fields/mod.rs:616-677): out[i] = coeff / v[i], zeros stay zero.  Montgomery's
+// trick per 64-element segment (the reference's `parallel` build chunks the vector the same way, :632-640): running
+// products into `out`, one Fermat inversion per segment, backward sweep.  Field inverses are unique, so the limbs equal
+// the reference's whatever the chunking.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned INV_SEG = 64;
+__global__ __launch_bounds__(128) void k_batch_inverse(const u64* v, size_t n, Fr coeff, u64* out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t a = t * INV_SEG;
+    if (a >= n) return;
+    size_t b = a + INV_SEG < n ? a + INV_SEG : n;
+    Fr run = Fr::one();
+    for (size_t i = a; i < b; i++) {
+        Fr x = pfr_load(v, i);
+        if (!x.is_zero()) run = fp_mul(run, x);
+        pfr_store(out, i, run);
+    }
+    Fr tmp = fp_mul(fp_inv(run), coeff);   // run != 0: a product of nonzero elements (or one)
+    for (size_t i = b; i-- > a;) {
+        Fr x = pfr_load(v, i);
+        if (x.is_zero()) {
+            pfr_store(out, i, Fr::zero());
+            continue;
+        }
+        Fr s = i > a ? pfr_load(out, i - 1) : Fr::one();
+        pfr_store(out, i, fp_mul(tmp, s));
+        tmp = fp_mul(tmp, x);
+    }
+}
+
 }  // namespace czk
 
 using namespace czk;
@@ -334,5 +365,23 @@ extern "C" int czk_fr_prefix_product(czk_ctx* ctx, const uint64_t* x, size_t n, 
         ProfScope ps(ctx, "fr_prefix_product");
         CZK_TRY(prefix_product(ctx, (const u64*)sx.dev, n, (u64*)so.dev, ws));
     }
+    return so.to_host(out, n * 32);
+}
+
+extern "C" int czk_fr_batch_inverse(czk_ctx* ctx, const uint64_t* v, size_t n, const uint64_t* coeff, uint64_t* out, int mem) {
+    if (!ctx || (n && (!v || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null batch_inverse argument") : CZK_ERR_ARG;
+    if (mem == CZK_MEM_DEVICE && v == out) return set_err(ctx, CZK_ERR_ARG, "batch_inverse: out must not alias v in device memory");
+    if (!n) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    Fr k = coeff ? fp_load<FrParams>(coeff) : Fr::one();
+    StagedP sv{ctx}, so{ctx};
+    CZK_TRY(sv.to_device(v, n * 32, mem));
+    CZK_TRY(so.to_device(mem == CZK_MEM_HOST ? nullptr : out, n * 32, mem));
+    const size_t segs = (n + INV_SEG - 1) / INV_SEG;
+    {
+        ProfScope ps(ctx, "fr_batch_inverse");
+        hipLaunchKernelGGL(k_batch_inverse, dim3((unsigned)((segs + 127) / 128)), dim3(128), 0, ctx->stream, (const u64*)sv.dev, n, k, (u64*)so.dev);
+    }
+    CZK_HIP(ctx, hipGetLastError());
     return so.to_host(out, n * 32);
 }

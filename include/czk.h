@@ -135,6 +135,11 @@ int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t l
  * scale that follows (:177-179) is czk_fr_vec_op(CZK_OP_MUL) per lane.  out may alias x only in HOST mode. */
 int czk_fr_prefix_product(czk_ctx* ctx, const uint64_t* x, size_t n, uint64_t* out, int mem);
 
+/* batch_inversion_and_mul (algebra/ff/src/fields/mod.rs:616-677): out[i] = coeff * v[i]^-1, zero elements stay zero
+ * (the reference skips them, :651, :666).  coeff: one Montgomery Fr in HOST memory, NULL = one (batch_inversion, :616).
+ * In device memory out must not alias v. */
+int czk_fr_batch_inverse(czk_ctx* ctx, const uint64_t* v, size_t n, const uint64_t* coeff, uint64_t* out, int mem);
+
 /* Fr::into_repr / from_repr over a vector (fields/arithmetic.rs:59-81, macros.rs:443-454) -- also the wire format. */
 int czk_fr_into_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);
 int czk_fr_from_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem);

@@ -573,3 +573,30 @@ void orc_fr_prefix_product(const uint64_t *x, size_t n, uint64_t *out) {
         memcpy(out + 4 * i, &v, 32);
     }
 }
+
+/* serial_batch_inversion_and_mul (algebra/ff/src/fields/mod.rs:642-677): v[i] <- coeff / v[i], zero elements skipped */
+void orc_fr_batch_inverse(uint64_t *v, size_t n, const uint64_t *coeff) {
+    fr_t *x = (fr_t *)v, zero, tmp, one;
+    memset(&zero, 0, sizeof zero);
+    fr_one(&one);
+    fr_t *prod = malloc((n ? n : 1) * sizeof(fr_t));
+    size_t np = 0;
+    tmp = one;
+    for (size_t i = 0; i < n; i++) {                                  /* first pass: [a, ab, abc, ...] over the non-zero elements */
+        if (memcmp(&x[i], &zero, 32) == 0) continue;
+        fr_mul(&tmp, &tmp, &x[i]);
+        prod[np++] = tmp;
+    }
+    fr_inv(&tmp, &tmp);                                               /* guaranteed non-zero */
+    fr_mul(&tmp, &tmp, (const fr_t *)coeff);
+    size_t k = np;                                                    /* prod.rev().skip(1).chain(one) */
+    for (size_t i = n; i-- > 0;) {
+        if (memcmp(&x[i], &zero, 32) == 0) continue;
+        fr_t s = k >= 2 ? prod[k - 2] : one, new_tmp;
+        k--;
+        fr_mul(&new_tmp, &tmp, &x[i]);
+        fr_mul(&x[i], &tmp, &s);
+        tmp = new_tmp;
+    }
+    free(prod);
+}

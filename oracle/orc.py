@@ -279,3 +279,11 @@ def fr_prefix_product(x):
     if len(x):
         lib().orc_fr_prefix_product(_p(x), C.c_size_t(len(x)), _p(out))
     return out
+
+
+def fr_batch_inverse(v, coeff):
+    v = np.array(_u64(v).reshape(-1, 4))
+    coeff = np.ascontiguousarray(_u64(coeff).reshape(4))
+    if len(v):
+        lib().orc_fr_batch_inverse(_p(v), C.c_size_t(len(v)), _p(coeff))
+    return v

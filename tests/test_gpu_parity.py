@@ -552,3 +552,16 @@ def test_fr_prefix_product_matches_oracle(ctx, czk, orc, n):
         x[37] = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
     got = ctx.fr_prefix_product(x)
     assert np.array_equal(got, orc.fr_prefix_product(x))
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 1000, (1 << 17) + 5])
+def test_fr_batch_inverse_matches_oracle(ctx, czk, orc, n):
+    """czk_fr_batch_inverse vs serial_batch_inversion_and_mul (fields/mod.rs:642-677), zeros included."""
+    v = orc.fr_from_repr(rand_fr_canonical(500 + n, max(n, 1)))[:n]
+    if n > 70:
+        v[[0, 5, 63, 64, 69]] = 0
+        v[128:192] = 0                                             # an all-zero segment
+    coeff = orc.fr_from_repr(rand_fr_canonical(501, 1))[0]
+    assert np.array_equal(ctx.fr_batch_inverse(v, coeff), orc.fr_batch_inverse(v, coeff))
+    one = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+    assert np.array_equal(ctx.fr_batch_inverse(v), orc.fr_batch_inverse(v, one))

@@ -286,3 +286,16 @@ def test_c_oracle_prefix_product_vs_bigint(orc):
         want.append(run)
     got = orc.fr_prefix_product(orc.ints_to_limbs([x * P.FR_MONT_R % P.R_MOD for x in xs], 4))
     assert orc.limbs_to_ints(orc.fr_into_repr(got)) == want
+
+
+def test_c_oracle_batch_inverse_vs_bigint(orc):
+    """orc_fr_batch_inverse (serial_batch_inversion_and_mul, fields/mod.rs:642-677; the reference's own test is
+    fields/mod.rs:704-727) against pow(x, -1, r), zeros skipped."""
+    rng = random.Random(14)
+    xs = _rand_fr(rng, 40)
+    for i in (0, 7, 8, 39):
+        xs[i] = 0
+    coeff = rng.randrange(1, P.R_MOD)
+    mont = lambda v: orc.ints_to_limbs([x * P.FR_MONT_R % P.R_MOD for x in v], 4)
+    got = orc.fr_batch_inverse(mont(xs), mont([coeff])[0])
+    assert orc.limbs_to_ints(orc.fr_into_repr(got)) == [coeff * pow(x, -1, P.R_MOD) % P.R_MOD if x else 0 for x in xs]
