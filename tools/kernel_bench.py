@@ -104,5 +104,33 @@ for log_n in (20, 21, 23):
                  "mul_per_s": lanes * 2 * n / dt})
     print(f"| poly / (X - z) | 2^{log_n} | {lanes} | {dt*1e3:.3f} | {alg/dt/1e9:.0f} | {alg/dt/8e12:.3f} | {lanes*2*n/dt:.3g} Fr |")
     del p, q, r
+for log_n in (20, 22):
+    n = 1 << log_n
+    x = torch.from_numpy(rand_fr_canonical(11, 4096).view(np.int64)).cuda().repeat(n // 4096, 1).contiguous()
+    x = torch.from_numpy(np.ascontiguousarray(x.cpu().numpy())).cuda()
+    o = torch.empty_like(x)
+    torch.cuda.synchronize()
+    xm = torch.empty_like(x)
+    ctx.fr_from_repr(x.data_ptr(), out=xm.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+    ctx.sync()
+    for name, fn, muls in (("fr_prefix_product", lambda: ctx.fr_prefix_product(xm.data_ptr(), out=o.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE), 2),
+                           ("fr_batch_inverse", lambda: ctx.fr_batch_inverse(xm.data_ptr(), out=o.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE), 3 + 380 / 64)):
+        dt = timed(fn, 5)
+        alg = 2 * n * 32
+        rows.append({"kernel": name, "log_size": log_n, "lanes": 1, "ms": dt * 1e3, "alg_gbs": alg / dt / 1e9, "frac": alg / dt / 8e12, "mul_per_s": muls * n / dt})
+        print(f"| {name} | 2^{log_n} | 1 | {dt*1e3:.3f} | {alg/dt/1e9:.0f} | {alg/dt/8e12:.3f} | {muls*n/dt:.3g} Fr |")
+    del x, o, xm
+for log_n in (21,):   # pointwise steps of the witness map
+    n, lanes = 1 << log_n, 4
+    a = torch.from_numpy(rand_fr_canonical(12, 4096).view(np.int64)).cuda().repeat(lanes * n // 4096, 1).contiguous()
+    b = a.clone()
+    o = torch.empty_like(a)
+    torch.cuda.synchronize()
+    for name, fn, nbuf in (("fr_vec_op(MUL)", lambda: ctx.fr_vec_op(2, a.data_ptr(), b.data_ptr(), out=o.data_ptr(), n=lanes * n, mem=czk.CZK_MEM_DEVICE), 3),
+                           ("fr_vec_op(ADD)", lambda: ctx.fr_vec_op(0, a.data_ptr(), b.data_ptr(), out=o.data_ptr(), n=lanes * n, mem=czk.CZK_MEM_DEVICE), 3)):
+        dt = timed(fn, 10)
+        alg = nbuf * lanes * n * 32
+        rows.append({"kernel": name, "log_size": log_n, "lanes": lanes, "ms": dt * 1e3, "alg_gbs": alg / dt / 1e9, "frac": alg / dt / 8e12})
+        print(f"| {name} | 2^{log_n} | {lanes} | {dt*1e3:.3f} | {alg/dt/1e9:.0f} | {alg/dt/8e12:.3f} | |")
 if len(sys.argv) > 1:
     json.dump(rows, open(sys.argv[1], "w"), indent=1)
