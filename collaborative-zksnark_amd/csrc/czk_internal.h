@@ -49,7 +49,7 @@ struct DeviceBuf {
 };
 struct MsmSlot {
     DeviceBuf ws_sort, ws_red;
-    hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_red = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_fix = nullptr, ev_red = nullptr;
     bool used = false;
 };
 struct MsmPending {
@@ -141,6 +141,12 @@ void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u
 // implemented in msm_acc_g1.hip / msm_acc_g2.hip (hot kernels, built with the multiply inlined)
 void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);
+void launch_accumulate_g1_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, unsigned lanes);
+void launch_accumulate_g2_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, unsigned lanes);
+void launch_accumulate_g1_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                                  u64* buckets, unsigned lanes, uint8_t* dirty);
+void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                                  u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords);

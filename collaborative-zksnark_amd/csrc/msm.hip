@@ -446,7 +446,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     // inputs (scalars) are produced on the caller's stream
     CZK_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->stream));
     CZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_in, 0));
-    if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_acc, 0));   // slot's sort buffers are read by its accumulate
+    if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_fix, 0));   // slot's sort buffers are read by its accumulate and fix-up kernels
     {
         ProfScope ps(ctx, "msm_sort", ss);
         CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
@@ -465,6 +465,13 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
         hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
         hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
+        if (b->unsat) {
+            // clear the dirty flags / exception list here rather than on the accumulate stream (the critical one); they live
+            // in the slot's reduce workspace, which the slot's previous reduction may still be using
+            if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_red, 0));
+            if (GT<F>::AW == 12) launch_accumulate_g1_u_prepare(ss, dirty, B, (unsigned)lanes);
+            else launch_accumulate_g2_u_prepare(ss, dirty, B, (unsigned)lanes);
+        }
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_sorted, ss));
     // the caller's stream may overwrite the scalars once the digits are extracted
@@ -483,6 +490,12 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
     CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
+    if (b->unsat) {
+        // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
+        if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else launch_accumulate_g2_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+    }
+    CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
     {
         ProfScope ps(ctx, "msm_reduce", sr);
         const u64 *P = buckets, *E = nullptr;
@@ -525,6 +538,7 @@ int msm_pipeline_init(czk_ctx* ctx) {
     for (auto& s : ctx->msm_slots) {
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_sorted, hipEventDisableTiming));
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_acc, hipEventDisableTiming));
+        CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_fix, hipEventDisableTiming));
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_red, hipEventDisableTiming));
     }
     ctx->msm_pinned_bytes = 1 << 20;
@@ -552,6 +566,7 @@ void msm_pipeline_destroy(czk_ctx* ctx) {
         if (s.ws_red.p) (void)hipFree(s.ws_red.p);
         (void)hipEventDestroy(s.ev_sorted);
         (void)hipEventDestroy(s.ev_acc);
+        (void)hipEventDestroy(s.ev_fix);
         (void)hipEventDestroy(s.ev_red);
     }
     (void)hipEventDestroy(ctx->ev_in);

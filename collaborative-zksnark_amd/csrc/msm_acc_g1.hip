@@ -9,21 +9,30 @@ void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, con
     hipLaunchKernelGGL(k_accumulate<Fq>, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
                        sorted_stride, buckets);
 }
+// The unsaturated accumulation is issued in three pieces so that only the dominant kernel occupies the accumulate
+// stream: `prepare` (clear the dirty flags + exception list; sort stream), the kernel itself, `fixup` (recompute dirty
+// buckets, add deferred points; reduce stream, ahead of the bucket reduction).
+static constexpr u32 G1_EXC_CAP = 4096;
+void launch_accumulate_g1_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, unsigned lanes) {
+    size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
+    (void)hipMemsetAsync(dirty, 0, flags + 16, st);
+}
 void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty) {
     // workspace behind the dirty flags: [count][list of EXC_CAP x 3 u32]
-    constexpr u32 EXC_CAP = 4096;
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
-    (void)hipMemsetAsync(dirty, 0, flags + 16, st);
-    {
-        ProfScope ps(ctx, "msm_accumulate_g1", st);   // brackets the dominant kernel only
-        hipLaunchKernelGGL(k_accumulate_u, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                           sorted_stride, buckets, dirty, exc, exc + 4, EXC_CAP);
-    }
+    ProfScope ps(ctx, "msm_accumulate_g1", st);   // brackets the dominant kernel only
+    hipLaunchKernelGGL(k_accumulate_u, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
+                       sorted_stride, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
+}
+void launch_accumulate_g1_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                                  u64* buckets, unsigned lanes, uint8_t* dirty) {
+    size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
+    u32* exc = (u32*)(dirty + flags);
     hipLaunchKernelGGL(k_accumulate_u_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
                        sorted_stride, buckets, dirty);
-    hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, EXC_CAP);
+    hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
 }
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords) {
     hipLaunchKernelGGL(k_convert_to_u, dim3((unsigned)((n_coords + 255) / 256)), dim3(256), 0, st, pts, n_coords);

@@ -20,19 +20,25 @@ void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n
 void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out) {
     hipLaunchKernelGGL((k_finish<Fq2P, 48, 1>), dim3((unsigned)(((segs << 1) + 63) / 64)), dim3(64), 0, st, P, E, segs, out);
 }
+static constexpr u32 G2_EXC_CAP = 4096;
+void launch_accumulate_g2_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, unsigned lanes) {
+    size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
+    (void)hipMemsetAsync(dirty, 0, flags + 16, st);
+}
 void launch_accumulate_g2_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty) {
-    constexpr u32 EXC_CAP = 4096;
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
-    (void)hipMemsetAsync(dirty, 0, flags + 16, st);
-    {
-        ProfScope ps(ctx, "msm_accumulate_g2", st);   // brackets the dominant kernel only
-        hipLaunchKernelGGL(k_accumulate_u2, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                           sorted_stride, buckets, dirty, exc, exc + 4, EXC_CAP);
-    }
+    ProfScope ps(ctx, "msm_accumulate_g2", st);   // brackets the dominant kernel only
+    hipLaunchKernelGGL(k_accumulate_u2, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
+                       sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP);
+}
+void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                                  u64* buckets, unsigned lanes, uint8_t* dirty) {
+    size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
+    u32* exc = (u32*)(dirty + flags);
     hipLaunchKernelGGL(k_accumulate_u2_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
                        sorted_stride, buckets, dirty);
-    hipLaunchKernelGGL(k_accumulate_u2_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, EXC_CAP);
+    hipLaunchKernelGGL(k_accumulate_u2_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G2_EXC_CAP);
 }
 }  // namespace czk
