@@ -334,12 +334,18 @@ struct Bump {
 
 static unsigned num_windows(unsigned c) { return (254 + c - 1) / c; }
 
-// window width for n bases: minimise W(c) * n mixed adds + ~3 * 2^(c-1) reduction adds
+// window width for n bases: minimise W(c) * n mixed additions + ~3 * 2^(c-1) reduction additions.  (In instruction terms
+// a bucket costs ~6 mixed additions to reduce, but weighting it so -- c = 17 at n = 2^20 -- lengthens the accumulate kernels,
+// which are the critical stream of the pipeline: measured 98 -> 102 ms per proof.)  Widths whose TOP window is only a few
+// bits wide are skipped for large n: its digits pile n / 2^t points onto each of ~2^t buckets, and a bucket is one thread's
+// serial chain (c = 19: 7 top bits -> 37 buckets of 28 k points at n = 2^20).
 static unsigned choose_c(size_t n) {
     unsigned best = 2;
     double best_cost = 1e300;
     for (unsigned c = 2; c <= 22; c++) {
-        double cost = (double)num_windows(c) * (double)(n ? n : 1) + 3.0 * (double)((size_t)1 << (c - 1));
+        const unsigned W = num_windows(c), top_bits = 254 - (W - 1) * c;
+        if (n >= 16384 && top_bits < 10) continue;
+        double cost = (double)W * (double)(n ? n : 1) + 3.0 * (double)((size_t)1 << (c - 1));
         if (cost < best_cost) {
             best_cost = cost;
             best = c;
