@@ -210,11 +210,11 @@ def test_msm_empty_and_all_zero(ctx, czk, orc):
     b0.release()
 
 
-@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (2, (1 << 17) + 1), (2, (1 << 20) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7)])
+@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (1, (1 << 21) - 1), (2, (1 << 17) + 1), (2, (1 << 20) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7), (1, (1 << 22) + 1)])
 def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, n):
     """Size-independent check at BASELINE scale: bases P_i = [k_i] G, so MSM(P, s) must equal
-    [sum k_i s_i mod r] G; plus linearity between the two lanes.  Sizes: the Groth16 a/b queries at 2^20
-    constraints (configs[1]), a G2 query, a KZG commit of a 2^18-coefficient polynomial (Plonk, configs[2]) and a
+    [sum k_i s_i mod r] G; plus linearity between the two lanes.  Sizes: the Groth16 a/b queries and the h query at 2^20
+    constraints (configs[1]), G2 queries, the a/b query at 2^22 constraints (configs[4]), a KZG commit of a 2^18-coefficient polynomial (Plonk, configs[2]) and a
     non-power-of-two ~3N commit as Marlin's largest polynomials at 2^20 (configs[3]; poly-commit/src/kzg10/mod.rs:159-162)."""
     import torch
     k = rand_fr_canonical(0xBA5E5, n)
