@@ -94,11 +94,12 @@ def _fr_pow(orc, base, e):
     return acc
 
 
-def test_ntt_device_memory_and_full_size_properties(ctx, czk, orc):
-    """BASELINE size D = 2^21, device-resident, 2 lanes: round trips restore the input exactly; forward
-    transforms agree with Horner evaluation at w^i / 22 w^i (radix2/mod.rs:320-360) at sampled points."""
+@pytest.mark.parametrize("log_d,lanes", [(21, 2), (22, 2), (23, 2)])
+def test_ntt_device_memory_and_full_size_properties(ctx, czk, orc, log_d, lanes):
+    """BASELINE sizes D = 2^21 (configs[1]; three 7-stage passes), 2^22 and 2^23 (configs[4]; four passes), device-resident,
+    2 lanes: round trips restore the input exactly; forward transforms agree with Horner evaluation at w^i / 22 w^i
+    (radix2/mod.rs:320-360) at sampled points."""
     import torch
-    log_d, lanes = 21, 2
     d = 1 << log_d
     x = orc.fr_from_repr(rand_fr_canonical(777, lanes * d)).reshape(lanes, d, 4)
     t = torch.from_numpy(x.view(np.int64)).cuda()
