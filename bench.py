@@ -418,7 +418,8 @@ def main():
             traffic = None
 
     out = {
-        "metric": "collaborative Groth16 proofs/sec (BLS12-377, 2^20 constraints, SPDZ N=2)",
+        # BASELINE.json's metric string for the BASELINE configuration; other sizes / party counts say what they are
+        "metric": f"collaborative Groth16 proofs/sec (BLS12-377, 2^{args.log_n} constraints, SPDZ N={args.parties})",
         "value": proofs / dt,
         "unit": "proofs/s",
         "n_gpus": world,
