@@ -566,3 +566,23 @@ def test_fr_batch_inverse_matches_oracle(ctx, czk, orc, n):
     assert np.array_equal(ctx.fr_batch_inverse(v, coeff), orc.fr_batch_inverse(v, coeff))
     one = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
     assert np.array_equal(ctx.fr_batch_inverse(v), orc.fr_batch_inverse(v, one))
+
+
+def test_poly_and_scan_entry_points_reject_bad_arguments(ctx, czk, orc):
+    import ctypes as C
+    import torch
+    L = czk.lib()
+    h = ctx._h
+    ERR_ARG, OK = 3, 0                                             # include/czk.h: CZK_ERR_ARG, CZK_OK
+    one = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))
+    buf = torch.zeros((8, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    p = C.c_void_p(buf.data_ptr())
+    null = C.c_void_p(0)
+    z = one.ctypes.data_as(C.c_void_p)
+    assert L.czk_poly_div_linear(h, p, C.c_size_t(8), C.c_size_t(1), null, p, null, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG      # no point
+    assert L.czk_poly_div_linear(h, null, C.c_size_t(8), C.c_size_t(1), z, p, null, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG   # no coefficients
+    assert L.czk_fr_batch_inverse(h, p, C.c_size_t(8), null, p, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG                        # in-place on device
+    assert L.czk_fr_prefix_product(h, null, C.c_size_t(8), p, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG
+    assert L.czk_fr_prefix_product(h, null, C.c_size_t(0), null, C.c_int(czk.CZK_MEM_DEVICE)) == OK                            # empty vector
+    assert L.czk_r1cs_matvec(h, null, p, C.c_size_t(8), C.c_size_t(1), p, C.c_size_t(8), C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG   # no matrix
