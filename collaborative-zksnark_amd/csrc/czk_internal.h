@@ -137,6 +137,11 @@ void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n
 void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
                             unsigned lanes);
 void launch_finish_g1(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
+// tail of the G1 bucket reduction for n_in <= 1024 entries per lane; scratch: lanes * 12 * 512 points, sums: lanes * 12 points
+void launch_reduce_tail_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,
+                           unsigned lanes);
+void launch_reduce_tail_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,
+                           unsigned lanes);
 void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
 // implemented in msm_acc_g1.hip / msm_acc_g2.hip (hot kernels, built with the multiply inlined)
 void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,

@@ -416,7 +416,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
     size_t need_sort = lanes * ((size_t)W * size * 4 * 3 + B * 4 * 4 + CNT_BINS * 4) + (1 << 16);
-    size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B) + (1 << 17);
+    size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B + (size_t)12 * 513 * XW * 8) + (1 << 17);
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
         CZK_TRY(msm_pipeline_sync(ctx));
         CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
@@ -437,6 +437,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     u64* lv[4];
     for (int i = 0; i < 4; i++) lv[i] = br.take<u64>(lanes * lvl0 * XW);
     u64* result = br.take<u64>(lanes * JW);
+    u64* tail_scratch = br.take<u64>(lanes * 12 * 512 * XW);   // reduction tail (G1): tree-reduction scratch and the 12 sums
+    u64* tail_sums = br.take<u64>(lanes * 12 * XW);
     uint8_t* dirty = br.take<uint8_t>(lanes * B + 64 + 3 * 4096 * 4 + 64);   // unsaturated kernel: dirty flags + exception list
 
     // pinned staging for the result
@@ -508,7 +510,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         size_t n_in = B;
         unsigned level = 0;
         int flip = 0;
+        bool finished = false;
         while (n_in > 1) {
+            if (n_in <= 1024) {   // latency-bound from here: bit-sum tree reductions instead of more levels
+                if (GT<F>::AW == 12) launch_reduce_tail_g1(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
+                else launch_reduce_tail_g2(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
+                finished = true;
+                break;
+            }
             size_t n_out = (n_in + L - 1) / L;
             u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
             if (GT<F>::AW == 12) launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
@@ -519,7 +528,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             level++;
             flip ^= 1;
         }
-        if (GT<F>::AW == 12) launch_finish_g1(sr, P, E, lanes, result);
+        if (finished) {
+        } else if (GT<F>::AW == 12) launch_finish_g1(sr, P, E, lanes, result);
         else launch_finish_g2(sr, P, E, lanes, result);
     }
     CZK_HIP(ctx, hipGetLastError());

@@ -67,6 +67,51 @@ __global__ void k_finish(const u64* P, const u64* E, size_t segs, u64* out) {
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Tail of the bucket reduction, used once a level has n_in <= 1024 entries per lane.  The chunked levels below that
+// point are latency: a handful of threads each walking ~30 dependent point additions per level.  Here
+//   sum_j j P[j] = sum_b 2^b S_b,   S_b = sum_{j : bit b of j set} P[j]
+// so blocks 0..9 each form one S_b, block 10 sums E and block 11 sums P, all as depth-10 tree reductions in parallel;
+// k_reduce_tail_finish then runs the 10-step Horner recombination.  total = 2^scale * sum_j j P[j] + sum E + sum P.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned TAIL_MAX = 1024, TAIL_BLOCKS = 12, TAIL_THREADS = 128;   // 128-thread blocks: a 512-thread block needs a whole idle CU at ~250 VGPRs
+template <class F, int JW, int SHIFT>   // SHIFT = 1: one point per lane pair (F = Fq2P), as in k_reduce_level
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tail_sums(const u64* P_in, const u64* E_in, size_t n_in,
+                                                                                                      u64* scratch, u64* sums) {
+    const unsigned which = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x >> SHIFT;
+    constexpr unsigned NT = TAIL_THREADS >> SHIFT;   // points in flight per block
+    const u64* src = which == 10 ? E_in : P_in;
+    XYZZ<F> v = XYZZ<F>::zero();
+    if (src) {
+        src += (size_t)JW * seg * n_in;
+        for (size_t j = tid; j < n_in; j += NT)
+            if (which >= 10 || ((j >> which) & 1)) v = xyzz_add(v, xyzz_load<F>(src + JW * j));
+    }
+    u64* sc = scratch + (size_t)JW * ((size_t)(seg * TAIL_BLOCKS + which) * TAIL_THREADS);
+    xyzz_store<F>(sc + (size_t)JW * tid, v);
+    __syncthreads();
+    for (unsigned stride = NT / 2; stride > 0; stride >>= 1) {
+        if (tid < stride) {
+            v = xyzz_add(v, xyzz_load<F>(sc + (size_t)JW * (tid + stride)));
+            xyzz_store<F>(sc + (size_t)JW * tid, v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) xyzz_store<F>(sums + (size_t)JW * (seg * TAIL_BLOCKS + which), v);
+}
+template <class F, int JW, int SHIFT>
+__global__ void k_reduce_tail_finish(const u64* sums, unsigned scale_dbl, size_t segs, u64* out) {
+    size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> SHIFT;
+    if (s >= segs) return;
+    const u64* sm = sums + (size_t)JW * s * TAIL_BLOCKS;
+    XYZZ<F> acc = xyzz_load<F>(sm + JW * 9);
+    for (int b = 8; b >= 0; b--) acc = xyzz_add(xyzz_double(acc), xyzz_load<F>(sm + JW * b));
+    for (unsigned k = 0; k < scale_dbl; k++) acc = xyzz_double(acc);
+    acc = xyzz_add(acc, xyzz_load<F>(sm + JW * 10));
+    acc = xyzz_add(acc, xyzz_load<F>(sm + JW * 11));   // weights are b + 1 (see k_finish)
+    jac_store<F>(out + (size_t)(JW / 4 * 3) * s, xyzz_to_jac(acc));
+}
+
 #ifdef CZK_FQU_G1
 // G1 accumulation in the unsaturated residue system (fqu.h): `pts` holds x R' mod p, y R' mod p as canonical
 // 12 x u32 integers (converted at registration).  Buckets leave in the usual saturated XYZZ Montgomery form.

@@ -44,4 +44,9 @@ void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n
 void launch_finish_g1(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out) {
     hipLaunchKernelGGL((k_finish<Fq, 24, 0>), dim3((unsigned)(((segs << 0) + 63) / 64)), dim3(64), 0, st, P, E, segs, out);
 }
+void launch_reduce_tail_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,
+                           unsigned lanes) {
+    hipLaunchKernelGGL((k_reduce_tail_sums<Fq, 24, 0>), dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
+    hipLaunchKernelGGL((k_reduce_tail_finish<Fq, 24, 0>), dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
+}
 }  // namespace czk
