@@ -517,10 +517,11 @@ def test_poly_div_linear_full_size_identity(ctx, czk, orc):
         assert np.array_equal(lhs, rhs)
 
 
-def test_party_per_rank_layout_matches_single_gpu_layout():
+@pytest.mark.parametrize("parties", [2, 3])
+def test_party_per_rank_layout_matches_single_gpu_layout(parties):
     """bench.py --layout party (one MPC party per rank; the witness map's two opens are all-gathers + the fused
     open/MAC-check kernel) must produce the same proof elements as the default layout with both parties on one GPU.
-    Two ranks share this box's single GPU, so the exchange runs over gloo (RCCL needs one device per rank)."""
+    The ranks share this box's single GPU, so the exchange runs over gloo (RCCL needs one device per rank)."""
     import json
     import os
     import socket
@@ -531,17 +532,17 @@ def test_party_per_rank_layout_matches_single_gpu_layout():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    common = ["--log-n", "12", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    common = ["--log-n", "12" if parties == 2 else "10", "--parties", str(parties), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--layout", "party", "--backend", "gloo",
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(parties), "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo",
                           "--device", "0"] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     d2 = json.loads(two.stdout.strip().splitlines()[-1])
-    assert d2["n_gpus"] == 2 and d2["config"]["layout"] == "party"
+    assert d2["n_gpus"] == parties and d2["config"]["layout"] == "party"
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
 
 
