@@ -264,6 +264,157 @@ __global__ void k_scatter(const u32* digits, const u32* ranks, size_t size, unsi
 }
 
 // ------------------------------------------------------------------------------------------------
+// partitioned counting sort (default).  The one-pass sort above costs one global atomic and one random 4-byte store per
+// entry -- 54 M of each per 4-lane 2^20-point MSM -- and those are what slows the accumulate kernels of the neighbouring
+// MSMs in the pipeline (measured: every ms of k_scatter overlap inflates an accumulate kernel by ~0.6 ms).  Here the
+// buckets are grouped into partitions of 1024 (by the LOW bits of the bucket index, so the few thousand over-full buckets of
+// the 13-bit top window spread over all partitions; `sorted` is partition-major, which the accumulate kernel does not care about): (1) digits + per-block LDS histogram of partitions (global atomics: one per
+// block and partition); (2) scan of the partition sizes; (3) entries move into their partition's region -- per block, the
+// entries of one partition land in one contiguous run; (4) one workgroup per partition counts, scans and places its
+// entries with LDS atomics and writes the partition's slice of `sorted`, `offsets` and `counts`.
+// ------------------------------------------------------------------------------------------------
+constexpr unsigned PART_LOG = 10, PART_BUCKETS = 1u << PART_LOG, MAX_PARTS = 2048;
+
+__global__ __launch_bounds__(256) void k_digits_part(const u64* scalars, size_t n_scalars, size_t size, int montgomery, unsigned c, unsigned W,
+                                                     const uint8_t* inf, size_t n_bases, u32* digits, u32* part_counts, unsigned n_parts) {
+    __shared__ u32 h[MAX_PARTS];
+    for (unsigned t = threadIdx.x; t < n_parts; t += 256) h[t] = 0;
+    __syncthreads();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned lane = blockIdx.y;
+    if (i < size) {
+        Fr s = fp_load<FrParams>(scalars + 4 * ((size_t)lane * n_scalars + i));
+        if (montgomery) s = fp_into_repr(s);   // ec/src/lib.rs:305-307
+        u32 carry = 0;
+        const u32 half = 1u << (c - 1);
+        for (unsigned w = 0; w < W; w++) {
+            unsigned bit = w * c;
+            u32 v = 0;
+            if (bit < 256) {
+                unsigned limb = bit >> 5, off = bit & 31;
+                u64 two = (u64)s.l[limb] | ((limb + 1 < 8) ? ((u64)s.l[limb + 1] << 32) : 0);
+                v = (u32)(two >> off) & ((1u << c) - 1u);
+            }
+            v += carry;
+            u32 code;
+            if (v > half) {
+                code = ((1u << c) - v) | 0x80000000u;
+                carry = 1;
+            } else {
+                code = v;
+                carry = 0;
+            }
+            if (inf[(size_t)w * n_bases + i]) code = 0;   // add_assign_mixed skips infinity (short_weierstrass_jacobian.rs:571-573)
+            if ((code & 0x7fffffffu) == 0) code = 0;
+            digits[((size_t)lane * W + w) * size + i] = code;
+            if (code) atomicAdd(&h[((code & 0x7fffffffu) - 1) & (n_parts - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    for (unsigned t = threadIdx.x; t < n_parts; t += 256)
+        if (h[t]) atomicAdd(&part_counts[(size_t)lane * n_parts + t], h[t]);
+}
+// part_base[lane][0 .. n_parts] = exclusive scan of part_counts; cursors cleared.  One block per lane.
+__global__ __launch_bounds__(1024) void k_part_scan(const u32* part_counts, u32* part_base, u32* part_cursor, unsigned n_parts) {
+    __shared__ u32 part[1024];
+    const unsigned lane = blockIdx.x, tid = threadIdx.x;
+    const u32* cnt = part_counts + (size_t)lane * n_parts;
+    u32* base = part_base + (size_t)lane * (n_parts + 1);
+    const unsigned per = (n_parts + 1023) / 1024;
+    unsigned start = tid * per, end = start + per < n_parts ? start + per : n_parts;
+    u32 sum = 0;
+    for (unsigned i = start; i < end; i++) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (unsigned d = 1; d < 1024; d <<= 1) {
+        u32 v = tid >= d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (unsigned i = start; i < end; i++) {
+        base[i] = run;
+        part_cursor[(size_t)lane * n_parts + i] = 0;
+        run += cnt[i];
+    }
+    if (tid == 1023) base[n_parts] = part[1023];
+}
+// entries -> partition regions: part_idx[dst] = point code, part_lb[dst] = bucket index inside the partition
+constexpr unsigned PS_TILE = 16;   // entries per thread
+__global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* part_base, u32* part_cursor,
+                                                      unsigned n_parts, unsigned part_shift, u32* part_idx, uint16_t* part_lb) {
+    __shared__ u32 h[MAX_PARTS], base[MAX_PARTS];
+    for (unsigned t = threadIdx.x; t < n_parts; t += 256) h[t] = 0;
+    __syncthreads();
+    const unsigned lane = blockIdx.y;
+    const size_t total = (size_t)W * size, tile0 = (size_t)blockIdx.x * 256 * PS_TILE;
+    u32 code[PS_TILE], rank[PS_TILE];
+#pragma unroll
+    for (unsigned k = 0; k < PS_TILE; k++) {
+        size_t e = tile0 + (size_t)k * 256 + threadIdx.x;
+        code[k] = e < total ? digits[(size_t)lane * total + e] : 0u;
+        if (code[k]) rank[k] = atomicAdd(&h[((code[k] & 0x7fffffffu) - 1) & (n_parts - 1)], 1u);
+    }
+    __syncthreads();
+    for (unsigned t = threadIdx.x; t < n_parts; t += 256)
+        if (h[t]) base[t] = part_base[(size_t)lane * (n_parts + 1) + t] + atomicAdd(&part_cursor[(size_t)lane * n_parts + t], h[t]);
+    __syncthreads();
+#pragma unroll
+    for (unsigned k = 0; k < PS_TILE; k++) {
+        if (!code[k]) continue;
+        size_t e = tile0 + (size_t)k * 256 + threadIdx.x;
+        size_t w = e / size, i = e - w * size;
+        u32 b = (code[k] & 0x7fffffffu) - 1;
+        size_t dst = (size_t)lane * total + base[b & (n_parts - 1)] + rank[k];
+        part_idx[dst] = (u32)(w * n_bases + i) | (code[k] & 0x80000000u);
+        part_lb[dst] = (uint16_t)(b >> part_shift);
+    }
+}
+// one workgroup per (partition, lane): bucket counts, offsets and the final placement of the partition's entries
+__global__ __launch_bounds__(256) void k_part_sort(const u32* part_idx, const uint16_t* part_lb, const u32* part_base, unsigned n_parts, unsigned part_shift,
+                                                   size_t total, size_t B, u32* sorted, u32* offsets, u32* counts) {
+    __shared__ u32 cnt[PART_BUCKETS], cur[PART_BUCKETS], red[256];
+    const unsigned p = blockIdx.x, lane = blockIdx.y, tid = threadIdx.x;
+    const u32 r0 = part_base[(size_t)lane * (n_parts + 1) + p], r1 = part_base[(size_t)lane * (n_parts + 1) + p + 1];
+    for (unsigned t = tid; t < PART_BUCKETS; t += 256) cnt[t] = 0;
+    __syncthreads();
+    const uint16_t* lb = part_lb + (size_t)lane * total;
+    const u32* idx = part_idx + (size_t)lane * total;
+    for (u32 j = r0 + tid; j < r1; j += 256) atomicAdd(&cnt[lb[j]], 1u);
+    __syncthreads();
+    // exclusive scan of cnt[0..1024): 4 consecutive entries per thread
+    u32 v[4], s = 0;
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+        v[k] = cnt[tid * 4 + k];
+        s += v[k];
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (unsigned d = 1; d < 256; d <<= 1) {
+        u32 x = tid >= d ? red[tid - d] : 0;
+        __syncthreads();
+        red[tid] += x;
+        __syncthreads();
+    }
+    u32 run = r0 + (tid ? red[tid - 1] : 0);
+#pragma unroll
+    for (unsigned k = 0; k < 4; k++) {
+        size_t b = ((size_t)(tid * 4 + k) << part_shift) | p;   // bucket = (index inside the partition, partition)
+        cur[tid * 4 + k] = run;
+        if (b < B) {
+            offsets[(size_t)lane * B + b] = run;
+            counts[(size_t)lane * B + b] = v[k];
+        }
+        run += v[k];
+    }
+    __syncthreads();
+    u32* out = sorted + (size_t)lane * total;
+    for (u32 j = r0 + tid; j < r1; j += 256) out[atomicAdd(&cur[lb[j]], 1u)] = idx[j];
+}
+
+// ------------------------------------------------------------------------------------------------
 // load balancing: order the buckets by population (descending) so the 64 lanes of a wave fold the same number
 // of points (bucket sizes are ~Poisson: without this a wave waits for its fullest bucket, ~30% of the time)
 // ------------------------------------------------------------------------------------------------
@@ -415,7 +566,10 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
-    size_t need_sort = lanes * ((size_t)W * size * 4 * 3 + B * 4 * 4 + CNT_BINS * 4) + (1 << 16);
+    const unsigned n_parts = (unsigned)((B + PART_BUCKETS - 1) >> PART_LOG);   // B is a power of two
+    unsigned part_shift = 0;
+    while ((1u << part_shift) < n_parts) part_shift++;
+    size_t need_sort = lanes * ((size_t)W * size * (4 * 3 + 2) + B * 4 * 4 + CNT_BINS * 4 + (size_t)n_parts * 12 + 64) + (1 << 16);
     size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B + (size_t)12 * 513 * XW * 8) + (1 << 17);
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
         CZK_TRY(msm_pipeline_sync(ctx));
@@ -425,7 +579,11 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     Bump bs{(char*)slot.ws_sort.p};
     u32* digits = bs.take<u32>(lanes * W * size);
     u32* sorted = bs.take<u32>(lanes * W * size);
-    u32* ranks = bs.take<u32>(lanes * W * size);
+    u32* ranks = bs.take<u32>(lanes * W * size);            // one-pass sort: ranks; partitioned sort: entries grouped by partition
+    uint16_t* part_lb = bs.take<uint16_t>(lanes * W * size);
+    u32* part_counts = bs.take<u32>(lanes * n_parts);
+    u32* part_cursor = bs.take<u32>(lanes * n_parts);
+    u32* part_base = bs.take<u32>(lanes * (n_parts + 1));
     u32* counts = bs.take<u32>(lanes * B);
     u32* offsets = bs.take<u32>(lanes * B);
     u32* perm = bs.take<u32>(lanes * B);
@@ -457,17 +615,34 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_fix, 0));   // slot's sort buffers are read by its accumulate and fix-up kernels
     {
         ProfScope ps(ctx, "msm_sort", ss);
-        CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
-        if (size) {
-            hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
-                               form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, ranks, counts, B);
-        }
-        hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, B, tile_sums, n_tiles);
-        hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)lanes), dim3(1024), 0, ss, tile_sums, n_tiles);
-        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, offsets, B, tile_sums, n_tiles);
-        if (size) {
-            hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, digits, ranks, size, W,
-                               b->n, offsets, B, sorted);
+        const bool one_pass = getenv("CZK_SORT_ONEPASS") != nullptr || n_parts > MAX_PARTS;
+        if (one_pass) {
+            CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
+            if (size) {
+                hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
+                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, ranks, counts, B);
+            }
+            hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, B, tile_sums, n_tiles);
+            hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)lanes), dim3(1024), 0, ss, tile_sums, n_tiles);
+            hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, offsets, B, tile_sums, n_tiles);
+            if (size) {
+                hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, digits, ranks, size, W,
+                                   b->n, offsets, B, sorted);
+            }
+        } else {
+            const size_t total = (size_t)W * size;
+            CZK_HIP(ctx, hipMemsetAsync(part_counts, 0, lanes * n_parts * 4, ss));
+            if (size) {
+                hipLaunchKernelGGL(k_digits_part, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
+                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, part_counts, n_parts);
+            }
+            hipLaunchKernelGGL(k_part_scan, dim3((unsigned)lanes), dim3(1024), 0, ss, part_counts, part_base, part_cursor, n_parts);
+            if (size) {
+                hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((total + 256 * PS_TILE - 1) / (256 * PS_TILE)), (unsigned)lanes), dim3(256), 0, ss, digits,
+                                   size, W, b->n, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
+            }
+            hipLaunchKernelGGL(k_part_sort, dim3(n_parts, (unsigned)lanes), dim3(256), 0, ss, ranks, part_lb, part_base, n_parts, part_shift, total, B, sorted,
+                               offsets, counts);
         }
         CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
         hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);

@@ -339,6 +339,24 @@ def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch, g, env):
     c2.close()
 
 
+def test_msm_one_pass_sort_still_matches(czk, orc, monkeypatch):
+    """CZK_SORT_ONEPASS=1 selects the single-pass counting sort (one global atomic + one random store per entry), the
+    fallback for more than 2048 partitions; keep it covered."""
+    monkeypatch.setenv("CZK_SORT_ONEPASS", "1")
+    c2 = czk.Context(0)
+    n = 5000
+    _, bases = _bases(c2, 1, n, 43)
+    sc = rand_fr_canonical(44, 2 * n).reshape(2, n, 4)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[0, 17]] = 1
+    b = c2.register_bases(1, bases, inf)
+    got = c2.msm(b, sc, lanes=2)
+    for ln in range(2):
+        assert _same_point(c2, orc, 1, got[ln], orc.msm(1, bases, inf, sc[ln]))
+    b.release()
+    c2.close()
+
+
 @pytest.mark.parametrize("g", [1, 2])
 def test_msm_adversarial_equal_and_opposite_bases(ctx, czk, orc, g):
     """Worst case for the unsaturated accumulate kernels' exceptional-case hand-off: every base is +-P and the
