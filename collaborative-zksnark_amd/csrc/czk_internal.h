@@ -66,7 +66,7 @@ struct czk_ctx {
     static constexpr int MSM_SLOTS = 4;   // workspace ring: accumulate(k + MSM_SLOTS) waits for reduce(k)
     czk::MsmSlot msm_slots[MSM_SLOTS];
     int msm_next_slot = 0;
-    int msm_slots_in_use = 3;
+    int msm_slots_in_use = 4;
     char* msm_pinned = nullptr;
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
     std::vector<czk::MsmPending> msm_pending;
