@@ -138,6 +138,10 @@ void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n
                             unsigned lanes);
 void launch_finish_g1(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
 // tail of the G1 bucket reduction for n_in <= 1024 entries per lane; scratch: lanes * 12 * 512 points, sums: lanes * 12 points
+void launch_heavy_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                     u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat);
+void launch_heavy_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                     u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat);
 void launch_reduce_tail_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,
                            unsigned lanes);
 void launch_reduce_tail_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,

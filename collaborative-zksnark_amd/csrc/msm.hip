@@ -570,7 +570,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     unsigned part_shift = 0;
     while ((1u << part_shift) < n_parts) part_shift++;
     size_t need_sort = lanes * ((size_t)W * size * (4 * 3 + 2) + B * 4 * 4 + CNT_BINS * 4 + (size_t)n_parts * 12 + 64) + (1 << 16);
-    size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B + (size_t)12 * 513 * XW * 8) + (1 << 17);
+    const u32 heavy_cap = (u32)(lanes * (size_t)W * size / 256 + 64);   // >= number of 256-entry work items of over-full buckets (msm_acc.h HEAVY_SUB)
+    size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B + (size_t)12 * 513 * XW * 8) + (size_t)heavy_cap * (XW * 8 + 32) + (1 << 17);
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
         CZK_TRY(msm_pipeline_sync(ctx));
         CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
@@ -597,6 +598,10 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     u64* result = br.take<u64>(lanes * JW);
     u64* tail_scratch = br.take<u64>(lanes * 12 * 512 * XW);   // reduction tail (G1): tree-reduction scratch and the 12 sums
     u64* tail_sums = br.take<u64>(lanes * 12 * XW);
+    u64* heavy_partials = br.take<u64>((size_t)heavy_cap * XW);   // over-full buckets: per-chunk partial sums, item / bucket lists, header
+    u32* heavy_items = br.take<u32>((size_t)heavy_cap * 3);
+    u32* heavy_list = br.take<u32>((size_t)heavy_cap * 4);
+    u32* heavy_hdr = br.take<u32>(4);
     uint8_t* dirty = br.take<uint8_t>(lanes * B + 64 + 3 * 4096 * 4 + 64);   // unsaturated kernel: dirty flags + exception list
 
     // pinned staging for the result
@@ -673,6 +678,11 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
     CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
+    // work items beyond the first 1024 entries of over-full buckets (none with uniformly random scalars): reduce stream
+    if (GT<F>::AW == 12) launch_heavy_g1(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr,
+                                         heavy_items, heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
+    else launch_heavy_g2(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr, heavy_items,
+                         heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
     if (b->unsat) {
         // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
         if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);

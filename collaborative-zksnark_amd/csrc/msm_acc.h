@@ -9,6 +9,102 @@ namespace czk {
 // sorted[off .. off+cnt) lists this bucket's points as (w * n_bases + i) | sign<<31; pts holds the window
 // multiples 2^(c*w) * P_i in affine Montgomery form.  acc += (+/-) P in XYZZ coordinates (curve.h; same edge cases as
 // short_weierstrass_jacobian.rs:570-597).
+// ------------------------------------------------------------------------------------------------
+// Over-full buckets.  One thread folds one bucket, so a bucket with a million points would be a million dependent
+// additions (seconds) -- and real witnesses do that: boolean wires put half of the scalars on digit 1 of window 0 (the
+// reference special-cases scalar == 1 for the same reason, variable_base.rs:44-48).  The main kernels therefore stop after
+// HEAVY_CHUNK entries; every further chunk of HEAVY_SUB entries becomes a work item folded by its own thread into a
+// partial sum (saturated formulas: complete, no exception list), and k_heavy_combine tree-adds a bucket's partials to it.
+// With the benchmark's uniformly random scalars no bucket comes near the limit and the item list stays empty.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 HEAVY_CHUNK = 1024, HEAVY_SUB = 256;   // main kernels fold the first 1024 entries; the rest in 256-entry work items
+// items: (lane, bucket, chunk index j); heavy: (lane, bucket, first item, number of items); hdr[0] = #items, hdr[1] = #heavy buckets
+template <class F>   // (template only so that each translation unit gets its own instance)
+__global__ void k_heavy_list(const u32* counts, size_t B, u32* hdr, u32* items, u32* heavy, u32 cap) {
+    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const unsigned lane = blockIdx.y;
+    u32 cnt = counts[(size_t)lane * B + b];
+    if (cnt <= HEAVY_CHUNK) return;
+    u32 extra = (cnt - HEAVY_CHUNK + HEAVY_SUB - 1) / HEAVY_SUB;
+    u32 base = atomicAdd(&hdr[0], extra);
+    u32 slot = atomicAdd(&hdr[1], 1u);
+    if (base + extra > cap || slot >= cap) {             // cannot happen: cap >= total entries / HEAVY_SUB + 64; flagged anyway
+        atomicOr(&hdr[2], 1u);
+        return;
+    }
+    heavy[4 * slot] = lane;
+    heavy[4 * slot + 1] = (u32)b;
+    heavy[4 * slot + 2] = base;
+    heavy[4 * slot + 3] = extra;
+    for (u32 j = 0; j < extra; j++) {
+        items[3 * (base + j)] = lane;
+        items[3 * (base + j) + 1] = (u32)b;
+        items[3 * (base + j) + 2] = j;
+    }
+}
+template <class F>
+__device__ __forceinline__ F heavy_coord(const u64* p, bool unsat);   // table coordinate -> saturated Montgomery form
+template <>
+__device__ __forceinline__ Fq heavy_coord<Fq>(const u64* p, bool unsat) {
+    Fq v = fp_load<FqParams>(p);
+    return unsat ? fp_mul(v, fqu_k_from_u()) : v;
+}
+template <>
+__device__ __forceinline__ Fq2 heavy_coord<Fq2>(const u64* p, bool unsat) {
+    return Fq2{heavy_coord<Fq>(p, unsat), heavy_coord<Fq>(p + 6, unsat)};
+}
+template <class F>
+__global__ __launch_bounds__(128) void k_accumulate_heavy(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+                                                         size_t sorted_stride, const u32* hdr, const u32* items, u64* partials, u32 cap, int unsat) {
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 n_items = hdr[0] < cap ? hdr[0] : cap;
+    if (k >= n_items) return;
+    const u32 lane = items[3 * k], b = items[3 * k + 1], j = items[3 * k + 2];
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    const u32 first = HEAVY_CHUNK + j * HEAVY_SUB;
+    u32 off = offsets[(size_t)lane * B + b] + first, cnt = counts[(size_t)lane * B + b] - first;
+    if (cnt > HEAVY_SUB) cnt = HEAVY_SUB;
+    constexpr int FW = GT<F>::AW / 2;
+    F ax = F::one(), ay = F::one(), azz = F::zero(), azzz = F::zero();
+    for (u32 e = 0; e < cnt; e++) {
+        u32 code = srt[off + e];
+        const u64* pp = pts + (size_t)GT<F>::AW * (code & 0x7fffffffu);
+        F qx = heavy_coord<F>(pp, unsat != 0), qy = heavy_coord<F>(pp + FW, unsat != 0);
+        if (code & 0x80000000u) qy = f_neg(qy);
+        xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy);
+    }
+    xyzz_store<F>(partials + (size_t)GT<F>::XW * k, XYZZ<F>{ax, ay, azz, azzz});
+}
+// one 128-thread block per over-full bucket: strided sums of its partials, tree reduction (in place in `partials`), add to the bucket
+template <class F>
+__global__ __launch_bounds__(128) void k_heavy_combine(const u32* hdr, const u32* heavy, u64* partials, size_t B, u64* buckets, const uint8_t* dirty, u32 cap) {
+    const u32 k = blockIdx.x, tid = threadIdx.x;
+    u32 n_heavy = hdr[1] < cap ? hdr[1] : cap;
+    if (k >= n_heavy) return;
+    const u32 lane = heavy[4 * k], b = heavy[4 * k + 1], base = heavy[4 * k + 2], extra = heavy[4 * k + 3];
+    if (dirty && dirty[(size_t)lane * B + b]) return;   // k_accumulate_u*_fix recomputes a dirty bucket from ALL of its entries
+    constexpr int XW = GT<F>::XW;
+    u64* part = partials + (size_t)XW * base;
+    XYZZ<F> v = XYZZ<F>::zero();
+    for (u32 j = tid; j < extra; j += 128) v = xyzz_add(v, xyzz_load<F>(part + (size_t)XW * j));
+    __syncthreads();                                     // every partial has been read before slots 0..127 are reused
+    if (tid < extra) xyzz_store<F>(part + (size_t)XW * tid, v);
+    __syncthreads();
+    const u32 live = extra < 128 ? extra : 128;
+    for (u32 stride = 64; stride > 0; stride >>= 1) {
+        if (tid < stride && tid + stride < live) {
+            v = xyzz_add(v, xyzz_load<F>(part + (size_t)XW * (tid + stride)));
+            xyzz_store<F>(part + (size_t)XW * tid, v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        u64* slot = buckets + (size_t)XW * ((size_t)lane * B + b);
+        xyzz_store<F>(slot, xyzz_add(xyzz_load<F>(slot), v));
+    }
+}
+
 template <class F>
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts,
                                                    const u32* perm, size_t B, size_t sorted_stride, u64* buckets) {
@@ -19,6 +115,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const u32* srt = sorted + (size_t)lane * sorted_stride;
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     F ax = F::one(), ay = F::one(), azz = F::zero(), azzz = F::zero();   // XYZZ infinity
+    if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;   // the rest of an over-full bucket is folded by k_accumulate_heavy
     for (u32 e = 0; e < cnt; e++) {
         u32 code = srt[off + e];
         Affine<F> p = aff_load<F>(pts + (size_t)GT<F>::AW * (code & 0x7fffffffu));
@@ -126,6 +223,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     FqU ax, ay, azz, azzz;
     bool inf = true;
+    if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;   // the rest of an over-full bucket is folded by k_accumulate_heavy
     for (u32 e = 0; e < cnt; e++) {
         u32 code = srt[off + e];
         const u64* pp = pts + (size_t)12 * (code & 0x7fffffffu);
@@ -243,6 +341,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     Fq2U ax, ay, azz, azzz;
     bool inf = true;
+    if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;   // the rest of an over-full bucket is folded by k_accumulate_heavy
     for (u32 e = 0; e < cnt; e++) {
         u32 code = srt[off + e];
         const u64* pp = pts + (size_t)24 * (code & 0x7fffffffu);

@@ -605,3 +605,30 @@ def test_poly_and_scan_entry_points_reject_bad_arguments(ctx, czk, orc):
     assert L.czk_fr_prefix_product(h, null, C.c_size_t(8), p, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG
     assert L.czk_fr_prefix_product(h, null, C.c_size_t(0), null, C.c_int(czk.CZK_MEM_DEVICE)) == OK                            # empty vector
     assert L.czk_r1cs_matvec(h, null, p, C.c_size_t(8), C.c_size_t(1), p, C.c_size_t(8), C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG   # no matrix
+
+
+@pytest.mark.parametrize("g,n", [(1, 70000), (2, 9000)])
+def test_msm_over_full_buckets(ctx, czk, orc, g, n):
+    """Skewed scalars as boolean-heavy witnesses produce them: most scalars are 1 (one bucket of window 0 receives tens of
+    thousands of points), some are r - 1 (the negated digit), a few are random.  The over-full bucket is folded in
+    2048-entry chunks by k_accumulate_heavy / k_heavy_combine instead of one thread walking all of it; the reference
+    special-cases scalar == 1 (variable_base.rs:44-48).  Checked against [sum k_i s_i] G."""
+    import time
+    k = rand_fr_canonical(600 + g, n)
+    bases = ctx.fixed_base_points(g, k)
+    s = np.zeros((2, n, 4), dtype=np.uint64)
+    s[:, :, 0] = 1                                                 # scalar 1 everywhere
+    rm1 = ints_to_limbs([R_MOD - 1], 4)[0]
+    s[0, ::7] = rm1                                                # lane 0: every 7th scalar is -1
+    s[1, ::5] = rand_fr_canonical(601, len(s[1, ::5]))             # lane 1: every 5th is random
+    s[1, 3] = 0
+    b = ctx.register_bases(g, bases, None)
+    t0 = time.perf_counter()
+    out = ctx.msm(b, s, lanes=2)
+    dt = time.perf_counter() - t0
+    ki, gen = limbs_to_ints(k), ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
+    for ln in range(2):
+        e = sum(a * c for a, c in zip(ki, limbs_to_ints(s[ln]))) % R_MOD
+        assert _same_point(ctx, orc, g, out[ln], orc.scalar_mul(g, gen, False, ints_to_limbs([e], 4)[0])), (g, ln)
+    assert dt < 1.0, f"over-full bucket path took {dt:.2f} s"    # one thread per bucket would need seconds here
+    b.release()
