@@ -55,7 +55,9 @@ __device__ __forceinline__ Fq2 heavy_coord<Fq2>(const u64* p, bool unsat) {
     return Fq2{heavy_coord<Fq>(p, unsat), heavy_coord<Fq>(p + 6, unsat)};
 }
 template <class F>
-__global__ __launch_bounds__(128) void k_accumulate_heavy(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+// (<= 128 VGPRs, spilling: with no work items -- the normal case -- its blocks must slip into the register space the accumulate
+// kernels leave free; at 250 VGPRs each empty block waited for a drained SIMD and the empty launch took 7 ms in the pipeline)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_heavy(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                          size_t sorted_stride, const u32* hdr, const u32* items, u64* partials, u32 cap, int unsat) {
     u32 k = blockIdx.x * blockDim.x + threadIdx.x;
     u32 n_items = hdr[0] < cap ? hdr[0] : cap;
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(128) void k_accumulate_heavy(const u64* pts, const 
 }
 // one 128-thread block per over-full bucket: strided sums of its partials, tree reduction (in place in `partials`), add to the bucket
 template <class F>
-__global__ __launch_bounds__(128) void k_heavy_combine(const u32* hdr, const u32* heavy, u64* partials, size_t B, u64* buckets, const uint8_t* dirty, u32 cap) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_heavy_combine(const u32* hdr, const u32* heavy, u64* partials, size_t B, u64* buckets, const uint8_t* dirty, u32 cap) {
     const u32 k = blockIdx.x, tid = threadIdx.x;
     u32 n_heavy = hdr[1] < cap ? hdr[1] : cap;
     if (k >= n_heavy) return;
