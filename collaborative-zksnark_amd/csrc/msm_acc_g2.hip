@@ -13,18 +13,6 @@ void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, con
     hipLaunchKernelGGL(k_accumulate<Fq2>, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
                        sorted_stride, buckets);
 }
-void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
-                            unsigned lanes) {
-    hipLaunchKernelGGL((k_reduce_level<Fq2P, 48, 1>), dim3((unsigned)(((n_out << 1) + 127) / 128), lanes), dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
-}
-void launch_reduce_tail_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,
-                           unsigned lanes) {
-    hipLaunchKernelGGL((k_reduce_tail_sums<Fq2P, 48, 1>), dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
-    hipLaunchKernelGGL((k_reduce_tail_finish<Fq2P, 48, 1>), dim3((2 * lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
-}
-void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out) {
-    hipLaunchKernelGGL((k_finish<Fq2P, 48, 1>), dim3((unsigned)(((segs << 1) + 63) / 64)), dim3(64), 0, st, P, E, segs, out);
-}
 static constexpr u32 G2_EXC_CAP = 4096;
 void launch_accumulate_g2_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, unsigned lanes) {
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
@@ -45,14 +33,5 @@ void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sor
     hipLaunchKernelGGL(k_accumulate_u2_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
                        sorted_stride, buckets, dirty);
     hipLaunchKernelGGL(k_accumulate_u2_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G2_EXC_CAP);
-}
-// over-full buckets (see msm_acc.h): item list, per-item partial sums, combination into the buckets; all on `st`
-void launch_heavy_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
-                     u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat) {
-    (void)hipMemsetAsync(hdr, 0, 16, st);
-    hipLaunchKernelGGL(k_heavy_list<Fq2>, dim3((unsigned)((B + 255) / 256), lanes), dim3(256), 0, st, counts, B, hdr, items, heavy, cap);
-    hipLaunchKernelGGL(k_accumulate_heavy<Fq2>, dim3((cap + 127) / 128), dim3(128), 0, st, pts, sorted, offsets, counts, B, sorted_stride, hdr, items,
-                       partials, cap, unsat);
-    hipLaunchKernelGGL(k_heavy_combine<Fq2>, dim3(cap / 4 + 1), dim3(128), 0, st, hdr, heavy, partials, B, buckets, dirty, cap);   // a bucket is over-full above 1024 entries: at most total / 1024 of them
 }
 }  // namespace czk
