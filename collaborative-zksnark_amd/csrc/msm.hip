@@ -14,14 +14,16 @@
 //     digit then lands in ONE shared bucket set: a single bucket reduction per MSM and no window-combine
 //     doubling chain (256 dependent doublings in the reference) at all.
 //   * signed digits: 2^(c-1) buckets of weight 1..2^(c-1); a negative digit adds -P (y -> p - y).
-//   * digits are counting-sorted by bucket (histogram -> scan -> scatter), then one thread owns one bucket
-//     and folds its points with the mixed addition (same edge cases as short_weierstrass_jacobian.rs:570-597)
-//     -- no atomics or locks on group elements; buckets are visited in descending-population order so the 64
-//     lanes of a wave do equal work.
+//   * digits are counting-sorted by bucket (partitioned: per-block LDS histograms, 1024-bucket partitions, one
+//     workgroup per partition), then one thread owns one bucket and folds its points with the mixed addition (same
+//     edge cases as short_weierstrass_jacobian.rs:570-597) -- no atomics or locks on group elements; buckets are
+//     visited in descending-population order so the 64 lanes of a wave do equal work; a bucket with more than 1024
+//     entries is cut into work items (msm_acc.h, over-full buckets).
 //   * buckets live in XYZZ coordinates (curve.h): mixed addition 8M + 2S instead of 7M + 4S, addition 12M + 2S
 //     instead of 11M + 5S; one conversion back to the reference's Jacobian triple per result.
 //   * bucket reduction sum_b (b+1) * B_b: multi-level chunked running sums (the reference's :82-86 running
-//     sum, applied per chunk, with the chunk offsets folded in at the next level).
+//     sum, applied per chunk, with the chunk offsets folded in at the next level) down to 1024 entries per lane,
+//     then bit-sum tree reductions (msm_acc.h k_reduce_tail_*).
 //   * consecutive MSMs pipeline over three internal streams (msm_enqueue below).
 //   * `lanes` scalar vectors that share the bases (SPDZ sh / mac lanes) ride on gridDim.y.
 // All arithmetic is 32-bit-limb integer VALU (field.h); nothing here is MFMA-shaped.
@@ -545,9 +547,9 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
 }
 
 // Enqueue one MSM on the context's three-stage pipeline:
-//   s_sort : digits -> histogram -> offsets -> scatter -> population order          (memory / atomics bound)
-//   s_acc  : bucket accumulation                                                     (integer-VALU bound, fills the chip)
-//   s_red  : multi-level bucket reduction + result copy                              (latency bound, few waves)
+//   s_sort : digits -> partition -> per-partition sort -> population order; flag clearing  (memory bound)
+//   s_acc  : the bucket accumulation kernel, nothing else                            (integer-VALU bound, fills the chip)
+//   s_red  : over-full-bucket items, fix-up kernels, bucket reduction, result copy   (mostly latency bound)
 // Consecutive MSMs overlap stage-wise (sort of k+1 and reduce of k-1 hide under accumulate of k); a ring of
 // workspace slots is guarded by events.  Results land in a pinned staging area and are handed to the caller's
 // buffer by msm_collect() after the streams are synchronised.
