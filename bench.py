@@ -318,8 +318,8 @@ def _ref_work(log_n: int) -> float:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=20, help="log2(constraints); BASELINE config = 20")
     ap.add_argument("--parties", type=int, default=2)
     ap.add_argument("--cpu-sample-log-n", type=int, default=14)
