@@ -38,6 +38,26 @@ int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes) {
     return CZK_OK;
 }
 
+int Staged::to_device(const void* host, size_t bytes, int mem) {
+    if (mem == CZK_MEM_DEVICE) {
+        dev = const_cast<void*>(host);
+        return CZK_OK;
+    }
+    CZK_HIP(ctx, hipMalloc(&dev, bytes ? bytes : 1));
+    owned = true;
+    if (host) CZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return CZK_OK;
+}
+int Staged::to_host(void* host, size_t bytes) {
+    if (!owned) return CZK_OK;
+    CZK_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CZK_OK;
+}
+Staged::~Staged() {
+    if (owned && dev) (void)hipFree(dev);
+}
+
 static hipEvent_t take_event(czk_ctx* ctx) {
     if (!ctx->event_pool.empty()) {
         hipEvent_t e = ctx->event_pool.back();
@@ -201,6 +221,7 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     }
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
     if (ctx->poly_scratch.p) (void)hipFree(ctx->poly_scratch.p);
+    if (ctx->open_bad) (void)hipFree(ctx->open_bad);
     msm_pipeline_destroy(ctx);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -70,6 +70,8 @@ struct czk_ctx {
     char* msm_pinned = nullptr;
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
     std::vector<czk::MsmPending> msm_pending;
+    bool msm_sort_onepass = false;   // CZK_SORT_ONEPASS=1 at pipeline creation: the single-pass digit sort (kept as the > 2048-partition fallback)
+    unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
     bool profiling = false;
     std::map<std::string, czk::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
@@ -84,7 +86,7 @@ struct czk_ctx {
 };
 
 struct czk_bases {
-    czk_ctx* ctx = nullptr;
+    int device = 0;            // GPU ordinal the tables live on (the handle may outlive its context: no ctx pointer is kept)
     int group = 1;
     size_t n = 0;
     unsigned c = 0;            // signed-digit window width chosen at registration
@@ -97,6 +99,30 @@ struct czk_bases {
 namespace czk {
 
 int set_err(czk_ctx* ctx, int code, const std::string& msg);
+
+// every buffer argument is host or device memory; the STABLE bit is only meaningful for czk_msm_async
+inline bool valid_mem(int mem) { return mem == CZK_MEM_HOST || mem == CZK_MEM_DEVICE; }
+
+// One Fr handed over by HOST pointer (czk.h promises a plain `const uint64_t*`: 8-byte alignment only, e.g. a Rust
+// [u64; 4] or a C stack array), so it is read limb by limb -- fp_load's 16-byte vector loads are for device pointers.
+inline Fr host_fr(const uint64_t* p) {
+    Fr r;
+    for (int i = 0; i < 4; i++) {
+        r.l[2 * i] = (u32)p[i];
+        r.l[2 * i + 1] = (u32)(p[i] >> 32);
+    }
+    return r;
+}
+
+// host <-> device staging for CZK_MEM_HOST callers of the vector entry points
+struct Staged {
+    czk_ctx* ctx;
+    void* dev = nullptr;
+    bool owned = false;
+    int to_device(const void* host, size_t bytes, int mem);
+    int to_host(void* host, size_t bytes);
+    ~Staged();
+};
 int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes);
 int get_domain(czk_ctx* ctx, unsigned log_d, DomainTables** out);
 

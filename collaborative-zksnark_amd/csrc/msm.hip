@@ -622,7 +622,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_fix, 0));   // slot's sort buffers are read by its accumulate and fix-up kernels
     {
         ProfScope ps(ctx, "msm_sort", ss);
-        const bool one_pass = getenv("CZK_SORT_ONEPASS") != nullptr || n_parts > MAX_PARTS;
+        const bool one_pass = ctx->msm_sort_onepass || n_parts > MAX_PARTS;
         if (one_pass) {
             CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
             if (size) {
@@ -730,6 +730,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 int msm_pipeline_init(czk_ctx* ctx) {
     if (ctx->s_sort) return CZK_OK;
     // (stream priorities for the short sort / reduce stages were measured: no gain, so all three are equal)
+    ctx->msm_sort_onepass = getenv("CZK_SORT_ONEPASS") != nullptr;   // read once, not per enqueue
     if (const char* e = getenv("CZK_MSM_SLOTS")) {
         int v = atoi(e);
         if (v >= 1 && v <= czk_ctx::MSM_SLOTS) ctx->msm_slots_in_use = v;
@@ -763,7 +764,13 @@ int msm_pipeline_sync(czk_ctx* ctx) {
 
 void msm_pipeline_destroy(czk_ctx* ctx) {
     if (!ctx->s_sort) return;
-    (void)msm_pipeline_sync(ctx);
+    // drain the streams, but do NOT deliver pending czk_msm_async results: the caller's `out_jac` buffers may be gone by
+    // now (an exception between msm_async and sync, then garbage collection in any order); results are only ever
+    // delivered by an explicit czk_ctx_sync / czk_msm
+    (void)hipStreamSynchronize(ctx->s_sort);
+    (void)hipStreamSynchronize(ctx->s_acc);
+    (void)hipStreamSynchronize(ctx->s_red);
+    ctx->msm_pending.clear();
     for (auto& s : ctx->msm_slots) {
         if (s.ws_sort.p) (void)hipFree(s.ws_sort.p);
         if (s.ws_red.p) (void)hipFree(s.ws_red.p);
@@ -825,10 +832,11 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     *out = nullptr;
     if (group != CZK_G1 && group != CZK_G2) return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
     if (n && !bases) return set_err(ctx, CZK_ERR_ARG, "null bases");
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t aw = group == CZK_G1 ? 12 : 24;
     czk_bases* b = new czk_bases();
-    b->ctx = ctx;
+    b->device = ctx->device;
     b->group = group;
     b->n = n;
     b->c = choose_c(n);
@@ -863,7 +871,7 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
 
 extern "C" void czk_bases_release(czk_bases* b) {
     if (!b) return;
-    if (b->ctx) (void)hipSetDevice(b->ctx->device);
+    (void)hipSetDevice(b->device);
     if (b->pts) (void)hipFree(b->pts);
     if (b->inf) (void)hipFree(b->inf);
     delete b;
@@ -880,6 +888,8 @@ static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scal
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const bool stable = (mem & CZK_MEM_STABLE) != 0;
     mem &= ~CZK_MEM_STABLE;
+    if (!valid_mem(mem) || (stable && (blocking || mem != CZK_MEM_DEVICE)))
+        return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (CZK_MEM_STABLE: czk_msm_async with device scalars only)");
     const u64* sdev = scalars;
     void* tmp = nullptr;
     if (mem == CZK_MEM_HOST && n_scalars) {
@@ -926,6 +936,7 @@ extern "C" int czk_msm_g2(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t*
 extern "C" int czk_fixed_base_points(czk_ctx* ctx, int group, const uint64_t* k, size_t n, uint64_t* out, int mem) {
     if (!ctx || (n && (!k || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null fixed_base argument") : CZK_ERR_ARG;
     if (group != CZK_G1 && group != CZK_G2) return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t aw = group == CZK_G1 ? 12 : 24;

@@ -428,38 +428,11 @@ using namespace czk;
 // ------------------------------------------------------------------------------------------------
 // C ABI (NTT + pointwise part)
 // ------------------------------------------------------------------------------------------------
-namespace {
-struct Staged {
-    // brings a host buffer to the device (and back) for CZK_MEM_HOST callers
-    czk_ctx* ctx;
-    void* dev = nullptr;
-    bool owned = false;
-    int to_device(const void* host, size_t bytes, int mem) {
-        if (mem == CZK_MEM_DEVICE) {
-            dev = const_cast<void*>(host);
-            return CZK_OK;
-        }
-        CZK_HIP(ctx, hipMalloc(&dev, bytes ? bytes : 1));
-        owned = true;
-        if (host) CZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return CZK_OK;
-    }
-    int to_host(void* host, size_t bytes) {
-        if (!owned) return CZK_OK;
-        CZK_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return CZK_OK;
-    }
-    ~Staged() {
-        if (owned && dev) (void)hipFree(dev);
-    }
-};
-}  // namespace
-
 extern "C" int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int kind, size_t in_len, int mem) {
     if (!ctx) return CZK_ERR_ARG;
     if (!data && lanes) return set_err(ctx, CZK_ERR_ARG, "null data");
     if (log_d > 47) return set_err(ctx, CZK_ERR_SIZE, "domain larger than 2^TWO_ADICITY (radix2/mod.rs:61-63)");
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     size_t bytes = lanes * ((size_t)32 << log_d);
     Staged s{ctx};
@@ -480,6 +453,7 @@ extern "C" int czk_domain_constants(czk_ctx* ctx, unsigned log_d, uint64_t* out2
 
 extern "C" int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int mem) {
     if (!ctx || (n && (!a || !b || !out)) || op < 0 || op > 2) return ctx ? set_err(ctx, CZK_ERR_ARG, "bad vec_op argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     Staged sa{ctx}, sb{ctx}, so{ctx};
@@ -493,6 +467,7 @@ extern "C" int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint
 
 extern "C" int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n, int mem) {
     if (!ctx || !k || (n && (!a || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "bad vec_scale argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     u64 kh[4];
@@ -518,6 +493,7 @@ extern "C" int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t*
 extern "C" int czk_fr_beaver_combine(czk_ctx* ctx, const uint64_t* x, const uint64_t* y, const uint64_t* z, const uint64_t* sx,
                                      const uint64_t* oy, int add_open, uint64_t* out, size_t n, int mem) {
     if (!ctx || (n && (!x || !y || !z || !sx || !oy || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null beaver argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     Staged s0{ctx}, s1{ctx}, s2{ctx}, s3{ctx}, s4{ctx}, so{ctx};
@@ -538,21 +514,21 @@ extern "C" int czk_fr_spdz_open(czk_ctx* ctx, const uint64_t* shares, size_t par
     *out_bad = 0;
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
-    unsigned long long* bad = nullptr;
-    CZK_HIP(ctx, hipMalloc(&bad, 8));
+    if (!ctx->open_bad) CZK_HIP(ctx, hipMalloc(&ctx->open_bad, 8));
+    unsigned long long* bad = ctx->open_bad;
     CZK_HIP(ctx, hipMemsetAsync(bad, 0, 8, ctx->stream));
     hipLaunchKernelGGL(k_spdz_open, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (const u64*)shares, parties, n, (u64*)out_value, bad);
     CZK_HIP(ctx, hipGetLastError());
     unsigned long long hb = 0;
     CZK_HIP(ctx, hipMemcpyAsync(&hb, bad, 8, hipMemcpyDeviceToHost, ctx->stream));
-    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    CZK_HIP(ctx, hipFree(bad));
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the count is the call's result: the reference asserts on it right here
     *out_bad = hb;
     return CZK_OK;
 }
 
 static int repr_common(czk_ctx* ctx, int to_mont, const uint64_t* a, uint64_t* out, size_t n, int mem) {
     if (!ctx || (n && (!a || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null repr argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     Staged sa{ctx}, so{ctx};

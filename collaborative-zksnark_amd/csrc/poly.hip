@@ -207,7 +207,7 @@ __global__ __launch_bounds__(128) void k_batch_inverse(const u64* v, size_t n, F
 using namespace czk;
 
 struct czk_r1cs_matrix {
-    czk_ctx* ctx = nullptr;
+    int device = 0;   // GPU ordinal (the handle may outlive its context)
     size_t m = 0, nnz = 0, n_vars = 0;
     u32 *row_ptr = nullptr, *col = nullptr;
     u64* coeff = nullptr;
@@ -215,7 +215,7 @@ struct czk_r1cs_matrix {
 
 extern "C" void czk_r1cs_matrix_release(czk_r1cs_matrix* a) {
     if (!a) return;
-    if (a->ctx) (void)hipSetDevice(a->ctx->device);
+    (void)hipSetDevice(a->device);
     if (a->row_ptr) (void)hipFree(a->row_ptr);
     if (a->col) (void)hipFree(a->col);
     if (a->coeff) (void)hipFree(a->coeff);
@@ -226,11 +226,12 @@ extern "C" int czk_r1cs_matrix_register(czk_ctx* ctx, const uint64_t* row_ptr, c
                                         size_t n_vars, int mem, czk_r1cs_matrix** out) {
     if (!ctx || !out || !row_ptr || (nnz && (!col_idx || !coeff))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null r1cs matrix argument") : CZK_ERR_ARG;
     *out = nullptr;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (nnz >= ((size_t)1 << 32) || n_vars >= ((size_t)1 << 31) || m >= ((size_t)1 << 32))
         return set_err(ctx, CZK_ERR_SIZE, "r1cs matrix too large for 32-bit indices");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     czk_r1cs_matrix* a = new czk_r1cs_matrix();
-    a->ctx = ctx;
+    a->device = ctx->device;
     a->m = m;
     a->nnz = nnz;
     a->n_vars = n_vars;
@@ -269,40 +270,14 @@ extern "C" int czk_r1cs_matrix_register(czk_ctx* ctx, const uint64_t* row_ptr, c
     return CZK_OK;
 }
 
-namespace {
-struct StagedP {   // host <-> device staging for CZK_MEM_HOST callers
-    czk_ctx* ctx;
-    void* dev = nullptr;
-    bool owned = false;
-    int to_device(const void* host, size_t bytes, int mem) {
-        if (mem == CZK_MEM_DEVICE) {
-            dev = const_cast<void*>(host);
-            return CZK_OK;
-        }
-        CZK_HIP(ctx, hipMalloc(&dev, bytes ? bytes : 1));
-        owned = true;
-        if (host) CZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return CZK_OK;
-    }
-    int to_host(void* host, size_t bytes) {
-        if (!owned) return CZK_OK;
-        CZK_HIP(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return CZK_OK;
-    }
-    ~StagedP() {
-        if (owned && dev) (void)hipFree(dev);
-    }
-};
-}  // namespace
-
 extern "C" int czk_r1cs_matvec(czk_ctx* ctx, const czk_r1cs_matrix* a, const uint64_t* z, size_t z_stride, size_t lanes, uint64_t* out,
                                size_t out_stride, int mem) {
     if (!ctx || !a || (lanes && (!z || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null r1cs_matvec argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (z_stride < a->n_vars || out_stride < a->m) return set_err(ctx, CZK_ERR_SIZE, "r1cs_matvec: assignment shorter than n_vars or output shorter than m");
     if (!lanes || !a->m) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
-    StagedP sz{ctx}, so{ctx};
+    Staged sz{ctx}, so{ctx};
     CZK_TRY(sz.to_device(z, lanes * z_stride * 32, mem));
     CZK_TRY(so.to_device(mem == CZK_MEM_HOST ? nullptr : out, lanes * out_stride * 32, mem));
     if (so.owned) CZK_HIP(ctx, hipMemsetAsync(so.dev, 0, lanes * out_stride * 32, ctx->stream));
@@ -326,6 +301,7 @@ extern "C" int czk_r1cs_matvec(czk_ctx* ctx, const czk_r1cs_matrix* a, const uin
 extern "C" int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* quotient,
                                    uint64_t* remainder, int mem) {
     if (!ctx || !z || (lanes && n && !coeffs) || (lanes && n > 1 && !quotient)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null poly_div argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!lanes) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     if (n == 0) {   // zero polynomial: zero quotient, zero remainder
@@ -335,9 +311,9 @@ extern "C" int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t 
         }
         return CZK_OK;
     }
-    Fr x = fp_load<FrParams>(z);
+    const Fr x = host_fr(z);   // host pointer, 8-byte aligned only
     const size_t qn = n - 1;
-    StagedP sp{ctx}, sq{ctx}, sr{ctx};
+    Staged sp{ctx}, sq{ctx}, sr{ctx};
     CZK_TRY(sp.to_device(coeffs, lanes * n * 32, mem));
     CZK_TRY(sq.to_device(mem == CZK_MEM_HOST ? nullptr : quotient, lanes * qn * 32, mem));
     CZK_TRY(sr.to_device(mem == CZK_MEM_HOST ? nullptr : remainder, lanes * 32, remainder ? mem : CZK_MEM_HOST));
@@ -354,9 +330,10 @@ extern "C" int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t 
 
 extern "C" int czk_fr_prefix_product(czk_ctx* ctx, const uint64_t* x, size_t n, uint64_t* out, int mem) {
     if (!ctx || (n && (!x || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null prefix_product argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
-    StagedP sx{ctx}, so{ctx};
+    Staged sx{ctx}, so{ctx};
     CZK_TRY(sx.to_device(x, n * 32, mem));
     CZK_TRY(so.to_device(mem == CZK_MEM_HOST ? nullptr : out, n * 32, mem));
     CZK_TRY(ensure_buf(ctx, ctx->poly_scratch, suffix_horner_scratch(n, 1) + 256));
@@ -370,11 +347,12 @@ extern "C" int czk_fr_prefix_product(czk_ctx* ctx, const uint64_t* x, size_t n, 
 
 extern "C" int czk_fr_batch_inverse(czk_ctx* ctx, const uint64_t* v, size_t n, const uint64_t* coeff, uint64_t* out, int mem) {
     if (!ctx || (n && (!v || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null batch_inverse argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (mem == CZK_MEM_DEVICE && v == out) return set_err(ctx, CZK_ERR_ARG, "batch_inverse: out must not alias v in device memory");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
-    Fr k = coeff ? fp_load<FrParams>(coeff) : Fr::one();
-    StagedP sv{ctx}, so{ctx};
+    const Fr k = coeff ? host_fr(coeff) : Fr::one();   // host pointer, 8-byte aligned only
+    Staged sv{ctx}, so{ctx};
     CZK_TRY(sv.to_device(v, n * 32, mem));
     CZK_TRY(so.to_device(mem == CZK_MEM_HOST ? nullptr : out, n * 32, mem));
     const size_t segs = (n + INV_SEG - 1) / INV_SEG;

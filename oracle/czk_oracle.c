@@ -509,6 +509,144 @@ void orc_witness_map_plain(uint64_t *a, uint64_t *b, uint64_t *c, unsigned log_d
     orc_witness_map_post_lane(fa, (fr_t *)c, log_d);
 }
 
+/* ------------------------------------------------------------------ all-host-cores CPU baseline (bench.py only)
+ * Same values as the serial functions above; OpenMP tasks over independent pieces: the windows of an MSM (the
+ * reference's `parallel` feature, variable_base.rs:33-37), the butterflies of one NTT stage, the independent a / b / c
+ * chains and share lanes of the witness map, and the MSMs of a proof. */
+#include <omp.h>
+static void orc_io_helper_par(fr_t *x, size_t n, const fr_t *roots) {
+    for (size_t gap = n / 2; gap > 0; gap /= 2) {
+        const size_t stride = (n / 2) / gap;
+#pragma omp taskloop grainsize(16384)
+        for (size_t t = 0; t < n / 2; t++) {
+            size_t base = (t / gap) * 2 * gap, k = t % gap;
+            fr_t *lo = &x[base + k], *hi = &x[base + gap + k], neg;
+            fr_sub(&neg, lo, hi);
+            fr_add(lo, lo, hi);
+            fr_mul(hi, &neg, &roots[k * stride]);
+        }
+    }
+}
+static void orc_oi_helper_par(fr_t *x, size_t n, const fr_t *roots) {
+    for (size_t gap = 1; gap < n; gap *= 2) {
+        const size_t nchunks = n / (2 * gap);
+#pragma omp taskloop grainsize(16384)
+        for (size_t t = 0; t < n / 2; t++) {
+            size_t base = (t / gap) * 2 * gap, k = t % gap;
+            fr_t *lo = &x[base + k], *hi = &x[base + gap + k], neg;
+            fr_mul(hi, hi, &roots[nchunks * k]);
+            fr_sub(&neg, lo, hi);
+            fr_add(lo, lo, hi);
+            *hi = neg;
+        }
+    }
+}
+/* pw[i] = c * g^i, in chunks (each chunk starts from one fr_pow) */
+static void orc_scale_powers_par(fr_t *x, size_t n, const fr_t *g, const fr_t *c) {
+    const size_t CH = 16384;
+#pragma omp taskloop grainsize(1)
+    for (size_t s = 0; s < (n + CH - 1) / CH; s++) {
+        uint64_t e[1] = {(uint64_t)(s * CH)};
+        fr_t pw;
+        fr_pow(&pw, g, e, 1);
+        fr_mul(&pw, &pw, c);
+        size_t end = (s + 1) * CH < n ? (s + 1) * CH : n;
+        for (size_t i = s * CH; i < end; i++) { fr_mul(&x[i], &x[i], &pw); fr_mul(&pw, &pw, g); }
+    }
+}
+static void orc_ntt_fr_par(fr_t *x, unsigned log_d, int kind, const orc_domain_t *d, const fr_t *roots_fwd, const fr_t *roots_inv) {
+    size_t n = (size_t)1 << log_d;
+    fr_t one;
+    fr_one(&one);
+    if (kind == ORC_COSET_FFT) orc_scale_powers_par(x, n, &d->generator, &one);
+    if (kind == ORC_FFT || kind == ORC_COSET_FFT) {
+        orc_io_helper_par(x, n, roots_fwd);
+        orc_derange(x, n, log_d);
+    } else {
+        orc_derange(x, n, log_d);
+        orc_oi_helper_par(x, n, roots_inv);
+        if (kind == ORC_IFFT) orc_scale_powers_par(x, n, &one, &d->size_inv);
+        else orc_scale_powers_par(x, n, &d->generator_inv, &d->size_inv);
+    }
+}
+/* One proof's local compute for `lanes` share lanes on all host cores: witness map (the product a * b stands in for the
+ * Beaver local half: same multiplication count order) and the five MSMs per lane.  a, b, c: lanes x D evaluations (a ends
+ * as h); wit: lanes x N, asg: lanes x (N+1) Montgomery scalars; out: lanes x (4 x 18 + 36) u64 (h, l, a, b_g1, b_g2). */
+void orc_groth16_local_par(unsigned log_d, size_t N, size_t lanes, uint64_t *a, uint64_t *b, uint64_t *c, const uint64_t *wit,
+                           const uint64_t *asg, const uint64_t *h_q, const uint64_t *l_q, const uint64_t *a_q, const uint64_t *b1_q,
+                           const uint64_t *b2_q, const uint8_t *inf0, const uint8_t *inf_b, uint64_t *out, int threads) {
+    const size_t D = (size_t)1 << log_d;
+    orc_domain_t d;
+    orc_domain_new(&d, D);
+    uint64_t consts[24];
+    orc_domain_constants(log_d, consts);
+    fr_t zinv;
+    memcpy(zinv.l, consts + 20, 32);
+    fr_t *roots_fwd = orc_roots(D / 2, &d.group_gen), *roots_inv = orc_roots(D / 2, &d.group_gen_inv);
+    uint64_t *wit_r = (uint64_t *)malloc(lanes * N * 32), *asg_r = (uint64_t *)malloc(lanes * (N + 1) * 32);
+    uint64_t *h_r = (uint64_t *)malloc(lanes * D * 32);
+    if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#pragma omp single
+    {
+#pragma omp taskgroup
+        {
+            for (size_t ln = 0; ln < lanes; ln++) {
+                fr_t *la = (fr_t *)a + ln * D, *lb = (fr_t *)b + ln * D, *lc = (fr_t *)c + ln * D;
+                const size_t O = 4 * 18 + 36;
+                uint64_t *lo = out + ln * O;
+#pragma omp task
+                {   /* witness map -> h MSM (r1cs_to_qap.rs:85-110, prover.rs:104) */
+#pragma omp taskgroup
+                    {
+#pragma omp task
+                        { orc_ntt_fr_par(la, log_d, ORC_IFFT, &d, roots_fwd, roots_inv); orc_ntt_fr_par(la, log_d, ORC_COSET_FFT, &d, roots_fwd, roots_inv); }
+#pragma omp task
+                        { orc_ntt_fr_par(lb, log_d, ORC_IFFT, &d, roots_fwd, roots_inv); orc_ntt_fr_par(lb, log_d, ORC_COSET_FFT, &d, roots_fwd, roots_inv); }
+#pragma omp task
+                        { orc_ntt_fr_par(lc, log_d, ORC_IFFT, &d, roots_fwd, roots_inv); orc_ntt_fr_par(lc, log_d, ORC_COSET_FFT, &d, roots_fwd, roots_inv); }
+                    }
+#pragma omp taskloop grainsize(16384)
+                    for (size_t i = 0; i < D; i++) {
+                        fr_mul(&la[i], &la[i], &lb[i]);
+                        fr_sub(&la[i], &la[i], &lc[i]);
+                        fr_mul(&la[i], &la[i], &zinv);
+                    }
+                    orc_ntt_fr_par(la, log_d, ORC_COSET_IFFT, &d, roots_fwd, roots_inv);
+#pragma omp taskloop grainsize(16384)
+                    for (size_t i = 0; i < D; i++) fr_into_repr(h_r + 4 * (ln * D + i), &la[i]);
+                    g1_jac_t r;
+                    g1_msm_pippenger_par(&r, (const g1_aff_t *)h_q, inf0, h_r + 4 * ln * D, D - 1);
+                    memcpy(lo, &r, sizeof r);
+                }
+#pragma omp task
+                {   /* witness-only MSMs (prover.rs:108, 132-156) */
+#pragma omp taskloop grainsize(16384)
+                    for (size_t i = 0; i < N; i++) fr_into_repr(wit_r + 4 * (ln * N + i), (const fr_t *)(wit + 4 * (ln * N + i)));
+#pragma omp taskloop grainsize(16384)
+                    for (size_t i = 0; i < N + 1; i++) fr_into_repr(asg_r + 4 * (ln * (N + 1) + i), (const fr_t *)(asg + 4 * (ln * (N + 1) + i)));
+#pragma omp taskgroup
+                    {
+#pragma omp task
+                        { g2_jac_t r; g2_msm_pippenger_par(&r, (const g2_aff_t *)b2_q, inf_b, asg_r + 4 * ln * (N + 1), N + 1); memcpy(lo + 72, &r, sizeof r); }
+#pragma omp task
+                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)l_q, inf0, wit_r + 4 * ln * N, N); memcpy(lo + 18, &r, sizeof r); }
+#pragma omp task
+                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)a_q, inf0, asg_r + 4 * ln * (N + 1), N + 1); memcpy(lo + 36, &r, sizeof r); }
+#pragma omp task
+                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)b1_q, inf_b, asg_r + 4 * ln * (N + 1), N + 1); memcpy(lo + 54, &r, sizeof r); }
+                    }
+                }
+            }
+        }
+    }
+    free(roots_fwd); free(roots_inv); free(wit_r); free(asg_r); free(h_r);
+}
+int orc_max_threads(void) { return omp_get_max_threads(); }
+/* input generation for the CPU baseline: n distinct subgroup points (see ec_tmpl.h chain_points) */
+void orc_g1_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g1_chain_points((g1_aff_t *)out, n, (const g1_aff_t *)gen_aff); }
+void orc_g2_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g2_chain_points((g2_aff_t *)out, n, (const g2_aff_t *)gen_aff); }
+
 /* ---- callers either side of the NTT ("next" rows; test infrastructure like everything in this file) ------------- */
 /* evaluate_constraint over every row of one R1CS matrix (mpc-snarks/src/groth/r1cs_to_qap.rs:12-42, 70-77, 95-100):
  * sum += (coeff == 1) ? val : val * coeff, in term order. */

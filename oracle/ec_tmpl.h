@@ -177,3 +177,91 @@ static void EC(msm_pippenger)(EC(jac_t) *out, const EC(aff_t) *bases, const uint
     free(buckets);
     free(window_sums);
 }
+
+/* All-host-cores variant for the timed CPU baseline (bench.py cpu_baseline.all_cores): the same arithmetic with the
+ * windows processed concurrently -- what the reference's `parallel` feature does with rayon
+ * (variable_base.rs:33-37 `cfg_into_iter!(window_starts)`).  OpenMP tasks, so it composes with other tasks of an
+ * enclosing parallel region; called outside one it runs serially. */
+static void EC(msm_pippenger_par)(EC(jac_t) *out, const EC(aff_t) *bases, const uint8_t *inf,
+                                  const uint64_t *scalars, size_t size) {
+    size_t c = size < 32 ? 3 : (size_t)(orc_log2(size) * 69 / 100) + 2;
+    const size_t num_bits = 253;
+    const uint64_t fr_one[4] = {1, 0, 0, 0};
+    size_t n_windows = (num_bits + c - 1) / c;
+    size_t n_buckets = ((size_t)1 << c) - 1;
+    EC(jac_t) *window_sums = (EC(jac_t) *)malloc(n_windows * sizeof(EC(jac_t)));
+#pragma omp taskloop grainsize(1) shared(window_sums)
+    for (size_t w = 0; w < n_windows; w++) {
+        EC(jac_t) *buckets = (EC(jac_t) *)malloc(n_buckets * sizeof(EC(jac_t)));
+        size_t w_start = w * c;
+        EC(jac_t) res;
+        EC(jac_zero)(&res);
+        for (size_t b = 0; b < n_buckets; b++) EC(jac_zero)(&buckets[b]);
+        for (size_t i = 0; i < size; i++) {
+            const uint64_t *s = scalars + 4 * i;
+            if ((s[0] | s[1] | s[2] | s[3]) == 0) continue;
+            if (memcmp(s, fr_one, sizeof fr_one) == 0) {
+                if (w_start == 0) EC(jac_add_mixed)(&res, &bases[i], inf[i]);
+                continue;
+            }
+            size_t limb = w_start / 64, off = w_start % 64;
+            uint64_t lo = limb < 4 ? s[limb] >> off : 0;
+            if (off && limb + 1 < 4) lo |= s[limb + 1] << (64 - off);
+            uint64_t digit = lo & (((uint64_t)1 << c) - 1);
+            if (digit) EC(jac_add_mixed)(&buckets[digit - 1], &bases[i], inf[i]);
+        }
+        EC(jac_t) running;
+        EC(jac_zero)(&running);
+        for (size_t b = n_buckets; b-- > 0;) {
+            EC(jac_add)(&running, &buckets[b]);
+            EC(jac_add)(&res, &running);
+        }
+        window_sums[w] = res;
+        free(buckets);
+    }
+    EC(jac_t) total;
+    EC(jac_zero)(&total);
+    for (size_t w = n_windows - 1; w >= 1; w--) {
+        EC(jac_add)(&total, &window_sums[w]);
+        for (size_t k = 0; k < c; k++) EC(jac_double)(&total);
+    }
+    EC(jac_t) lowest = window_sums[0];
+    EC(jac_add)(&lowest, &total);
+    *out = lowest;
+    free(window_sums);
+}
+
+/* P_0 = G, P_{i+1} = 2 P_i + G as affine points: n distinct subgroup points in O(n) group operations and ONE field
+ * inversion per 1024 points (Montgomery's trick on the z coordinates) -- input generation for the CPU baseline only. */
+static void EC(chain_points)(EC(aff_t) *out, size_t n, const EC(aff_t) *gen) {
+    enum { CH = 1024 };
+    EC(jac_t) *jac = (EC(jac_t) *)malloc(CH * sizeof(EC(jac_t)));
+    BF_T *pre = (BF_T *)malloc(CH * sizeof(BF_T));
+    EC(jac_t) cur;
+    cur.x = gen->x; cur.y = gen->y; BF(one)(&cur.z);
+    for (size_t start = 0; start < n; start += CH) {
+        size_t m = n - start < CH ? n - start : CH;
+        BF_T acc;
+        BF(one)(&acc);
+        for (size_t i = 0; i < m; i++) {
+            jac[i] = cur;
+            pre[i] = acc;
+            BF(mul)(&acc, &acc, &cur.z);
+            EC(jac_double)(&cur);
+            EC(jac_add_mixed)(&cur, gen, 0);
+        }
+        BF_T inv;
+        BF(inv)(&inv, &acc);
+        for (size_t i = m; i-- > 0;) {
+            BF_T zi, zi2, zi3;
+            BF(mul)(&zi, &inv, &pre[i]);
+            BF(mul)(&inv, &inv, &jac[i].z);
+            BF(sqr)(&zi2, &zi);
+            BF(mul)(&zi3, &zi2, &zi);
+            BF(mul)(&out[start + i].x, &jac[i].x, &zi2);
+            BF(mul)(&out[start + i].y, &jac[i].y, &zi3);
+        }
+    }
+    free(jac);
+    free(pre);
+}

@@ -287,3 +287,42 @@ def fr_batch_inverse(v, coeff):
     if len(v):
         lib().orc_fr_batch_inverse(_p(v), C.c_size_t(len(v)), _p(coeff))
     return v
+
+
+# ----------------------------------------------------------------------------- all-host-cores CPU baseline (bench.py)
+def max_threads() -> int:
+    fn = lib().orc_max_threads
+    fn.restype = C.c_int
+    return int(fn())
+
+
+def generator_affine(g):
+    """Montgomery limbs of the G1 / G2 generator (curves/bls12_377/src/curves/g1.rs:46-51, g2.rs:64-86)."""
+    from pyref import G1_GEN, G2_GEN, fq_to_mont
+    if g == 1:
+        return ints_to_limbs([fq_to_mont(G1_GEN[0]), fq_to_mont(G1_GEN[1])], 6).reshape(-1)
+    return ints_to_limbs([fq_to_mont(G2_GEN[0][0]), fq_to_mont(G2_GEN[0][1]), fq_to_mont(G2_GEN[1][0]), fq_to_mont(G2_GEN[1][1])], 6).reshape(-1)
+
+
+def chain_points(g, n):
+    """n distinct subgroup points P_0 = G, P_{i+1} = 2 P_i + G (affine): cheap bases for timing runs."""
+    aff_w, _ = _grp(g)
+    gen = _u64(generator_affine(g))
+    out = np.zeros((n, aff_w), dtype=np.uint64)
+    getattr(lib(), f"orc_g{g}_chain_points")(_p(gen), _p(out), C.c_size_t(n))
+    return out
+
+
+def groth16_local_par(log_d, N, a, b, c, wit, asg, h_q, l_q, a_q, b1_q, b2_q, inf_b, threads=0):
+    """One proof's local compute (witness map + 5 MSMs per share lane) with OpenMP tasks on `threads` host threads
+    (0 = all).  a, b, c: (lanes, D, 4) and are overwritten; returns (lanes, 108) u64: h, l, a, b_g1 Jacobian (18 each), b_g2 (36)."""
+    a, b, c = _u64(a), _u64(b), _u64(c)
+    lanes = a.shape[0]
+    wit, asg = _u64(wit), _u64(asg)
+    h_q, l_q, a_q, b1_q, b2_q = (_u64(x) for x in (h_q, l_q, a_q, b1_q, b2_q))
+    inf0 = np.zeros(max(h_q.shape[0], N + 1), dtype=np.uint8)
+    inf_b = np.ascontiguousarray(inf_b, dtype=np.uint8)
+    out = np.zeros((lanes, 108), dtype=np.uint64)
+    lib().orc_groth16_local_par(C.c_uint(log_d), C.c_size_t(N), C.c_size_t(lanes), _p(a), _p(b), _p(c), _p(wit), _p(asg), _p(h_q), _p(l_q),
+                                _p(a_q), _p(b1_q), _p(b2_q), _p(inf0), _p(inf_b), _p(out), C.c_int(threads))
+    return out
