@@ -355,6 +355,15 @@ class Bases:
     def __len__(self):
         return int(lib().czk_bases_len(self._h))
 
+    def layout(self):
+        """(window width c, number of windows) chosen at registration."""
+        c, w = C.c_uint(0), C.c_uint(0)
+        lib().czk_bases_layout(self._h, C.byref(c), C.byref(w))
+        return c.value, w.value
+
+    def windows(self) -> int:
+        return self.layout()[1]
+
     def release(self):
         if self._h:
             lib().czk_bases_release(self._h)

@@ -878,6 +878,12 @@ extern "C" void czk_bases_release(czk_bases* b) {
 }
 
 extern "C" size_t czk_bases_len(const czk_bases* b) { return b ? b->n : 0; }
+extern "C" int czk_bases_layout(const czk_bases* b, unsigned* c, unsigned* windows) {
+    if (!b) return CZK_ERR_ARG;
+    if (c) *c = b->c;
+    if (windows) *windows = b->W;
+    return CZK_OK;
+}
 
 static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,
                       uint64_t* out_jac, bool blocking) {

@@ -1,0 +1,277 @@
+"""Host-side callers of the hot path: the per-party LOCAL compute of the reference's MPC provers, driven through the
+C ABI (binding.py).  Mirrors the reference's call sequences, not its protocol logic:
+
+  Groth16Local   R1CStoQAP::witness_map (mpc-snarks/src/groth/r1cs_to_qap.rs:47-113) + the MSM sequence of create_proof
+                 (mpc-snarks/src/groth/prover.rs:66-178), Beaver local half (mpc-algebra/src/share/field.rs:97-127)
+
+Used by bench.py (timed) and tests/ (parity against the checker).  torch provides device memory and streams only.
+"""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+import torch
+
+R_MOD = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+_MASK64 = (1 << 64) - 1
+
+
+def splitmix_u64(seed: int, n: int) -> np.ndarray:
+    """n SplitMix64 outputs (deterministic inputs, independent of rand 0.7)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = np.uint64(seed & _MASK64) + idx * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+_R_LIMBS = np.array([(R_MOD >> (64 * i)) & _MASK64 for i in range(4)], dtype=np.uint64)
+
+
+def rand_fr_canonical(seed: int, n: int) -> np.ndarray:
+    """(n,4) uint64 canonical values < r: top 3 bits masked (REPR_SHAVE_BITS, fr.rs:44), candidates >= r rejected
+    (fields/arithmetic.rs:199-214).  Same stream as tests/util.py."""
+    out = np.zeros((0, 4), dtype=np.uint64)
+    chunk = 0
+    while out.shape[0] < n:
+        m = max(16, int((n - out.shape[0]) * 1.7) + 8)
+        raw = splitmix_u64(seed + 0x1000003 * chunk, 4 * m).reshape(m, 4)
+        raw[:, 3] &= np.uint64(_MASK64 >> 3)
+        lt = np.zeros(m, dtype=bool)
+        eq = np.ones(m, dtype=bool)
+        for j in (3, 2, 1, 0):
+            lt |= eq & (raw[:, j] < _R_LIMBS[j])
+            eq &= raw[:, j] == _R_LIMBS[j]
+        out = np.vstack([out, raw[lt]])
+        chunk += 1
+    return np.ascontiguousarray(out[:n])
+
+
+def to_mont_limbs(vals):
+    """python ints (canonical) -> (n,4) uint64 Montgomery limbs (a * 2^256 mod r)."""
+    R = (1 << 256) % R_MOD
+    buf = b"".join(((v * R) % R_MOD).to_bytes(32, "little") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
+
+
+BASE_SEED = 0xBA5E5   # P_i = [k_i] G with k_i = rand_fr_canonical(BASE_SEED + query id, n)  
+QUERIES = (("h", 1), ("l", 2), ("a", 3), ("b_g1", 4), ("b_g2", 5))
+
+
+class Groth16Local:
+    """Device-resident state + the per-proof pipeline for `n_constraints` constraints of the reference's benchmark
+    circuit (squaring chain, mpc-snarks/src/proof.rs:304-344), SPDZ shares of `parties` parties."""
+
+    def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None):
+        """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
+        configs[1]); with a strict subset, `exchange` (parallel.all_gather_shares) plays mpc-net's broadcast in the two
+        opens of the witness map."""
+        self.czk, self.ctx = czk, ctx
+        self.N = int(n_constraints)
+        self.P = parties
+        self.local = list(range(parties)) if local_parties is None else list(local_parties)
+        self.exchange = exchange
+        self.lanes = 2 * len(self.local)              # SPDZ: sh + mac per party (share/spdz.rs:50-53)
+        self.log_d = (self.N + 2 - 1).bit_length()    # D = next_pow2(N + num_instance) (r1cs_to_qap.rs:63-65)
+        self.D = 1 << self.log_d
+        N, D, L = self.N, self.D, self.lanes
+        dev = torch.device("cuda")
+
+        # ---- synthetic proving key: P_i = [k_i] G ----------------------------------------------------------
+        def mk_bases(group, n, sd, inf_first=False):
+            k = torch.from_numpy(rand_fr_canonical(BASE_SEED + sd, n).view(np.int64)).to(dev)
+            aw = 12 if group == czk.CZK_G1 else 24
+            pts = torch.empty((n, aw), dtype=torch.int64, device=dev)
+            ctx.fixed_base_points(group, k.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+            inf = torch.zeros(n, dtype=torch.uint8, device=dev)
+            if inf_first:
+                inf[0] = 1   # b_query[1] (the public output has no B entry) is infinity in the real key
+            b = ctx.register_bases(group, pts.data_ptr(), inf.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+            del pts, k
+            return b
+        t0 = time.time()
+        self.query_len = {"h": D - 1, "l": N, "a": N + 1, "b_g1": N + 1, "b_g2": N + 1}   # groth16/src/generator.rs:156-163
+        self.h_query = mk_bases(czk.CZK_G1, D - 1, 1)
+        self.l_query = mk_bases(czk.CZK_G1, N, 2)
+        self.a_query = mk_bases(czk.CZK_G1, N + 1, 3)             # a_query[1..]
+        self.b_g1_query = mk_bases(czk.CZK_G1, N + 1, 4, True)
+        self.b_g2_query = mk_bases(czk.CZK_G2, N + 1, 5, True)
+        self.setup_key_s = time.time() - t0
+
+        # ---- squaring circuit witness (proof.rs:304-344) and its additive shares ---------------------------
+        w = [rand_fr_canonical(seed, 1)[0]]
+        w0 = sum(int(w[0][j]) << (64 * j) for j in range(4))
+        chain = [w0]
+        for _ in range(N):
+            chain.append(chain[-1] * chain[-1] % R_MOD)
+        wm = to_mont_limbs(chain)                                  # w_0 .. w_N (w_N = public output)
+        one = to_mont_limbs([1])[0]
+        # additive sharing on the GPU: parties 0..P-2 uniform, last = value - sum (share/spdz.rs:150-162)
+        wd = torch.from_numpy(wm.view(np.int64)).to(dev)
+        sh = []
+        rest = wd.clone()
+        for p in range(parties - 1):
+            r = torch.from_numpy(rand_fr_canonical(seed + 17 * (p + 1), N + 1).view(np.int64)).to(dev)
+            rm = torch.empty_like(r)
+            ctx.fr_from_repr(r.data_ptr(), out=rm.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+            ctx.fr_vec_op(1, rest.data_ptr(), rm.data_ptr(), out=rest.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+            sh.append(rm)
+        sh.append(rest)
+        ctx.sync()
+        one_t = torch.from_numpy(one.view(np.int64)).to(dev)
+
+        def lanes_buf():
+            return torch.zeros((L, D, 4), dtype=torch.int64, device=dev)
+        # a_i = b_i = w_i, c_i = w_{i+1} for i < N; a[N] = 1 (king only: Public lifted per SURVEY a18), a[N+1] = out
+        # (a0, b0, c0 are written out directly here as the EXPECTED constraint evaluations: step() computes them on the GPU
+        # from `full` with czk_r1cs_matvec; the parity test and the integrity check compare against these)
+        self.a0, self.b0, self.c0 = lanes_buf(), lanes_buf(), lanes_buf()
+        self.wit = torch.zeros((L, N, 4), dtype=torch.int64, device=dev)          # l-MSM scalars: witness
+        self.asg = torch.zeros((L, N + 1, 4), dtype=torch.int64, device=dev)      # a/b-MSM scalars: [out, witness]
+        for j, p in enumerate(self.local):
+            for m in range(2):                                     # mac lane = sh * mac(), mac() = 1 (spdz.rs:41-47)
+                ln = 2 * j + m
+                self.a0[ln, :N] = sh[p][:N]
+                self.b0[ln, :N] = sh[p][:N]
+                self.c0[ln, :N] = sh[p][1:N + 1]
+                if p == 0:
+                    self.a0[ln, N] = one_t
+                self.a0[ln, N + 1] = sh[p][N]
+                self.wit[ln] = sh[p][:N]
+                self.asg[ln, 0] = sh[p][N]
+                self.asg[ln, 1:] = sh[p][:N]
+        # full assignment [1, out | w_0 .. w_{N-1}] per lane (r1cs_to_qap.rs:56-61); Public(1) lifted to the king's lanes
+        self.full = torch.zeros((L, N + 2, 4), dtype=torch.int64, device=dev)
+        for j, p in enumerate(self.local):
+            for m in range(2):
+                ln = 2 * j + m
+                if p == 0:
+                    self.full[ln, 0] = one_t
+                self.full[ln, 1] = sh[p][N]
+                self.full[ln, 2:] = sh[p][:N]
+        # the squaring circuit's matrices (proof.rs:304-344): a_i = b_i = w_i, c_i = w_{i+1} (c_{N-1} = out), all coefficients 1
+        ones = np.tile(one, (N + 2, 1))
+        rp = np.arange(N + 3, dtype=np.uint64)
+        wcols = np.arange(2, N + 2, dtype=np.uint32)
+        self.mat_a = ctx.r1cs_matrix_register(rp, np.concatenate([wcols, np.array([0, 1], dtype=np.uint32)]), ones, N + 2)
+        self.mat_b = ctx.r1cs_matrix_register(rp[: N + 1], wcols, ones[:N], N + 2)
+        self.mat_c = ctx.r1cs_matrix_register(rp[: N + 1], np.concatenate([wcols[1:], np.array([1], dtype=np.uint32)]), ones[:N], N + 2)
+        # dummy Beaver triples (wire/field.rs:41-60): king holds (1,1,1), everyone else (0,0,0)
+        self.tx, self.ty, self.tz = lanes_buf(), lanes_buf(), lanes_buf()
+        self.king_lanes = [2 * j + m for j, p in enumerate(self.local) if p == 0 for m in range(2)]
+        for t in (self.tx, self.ty, self.tz):
+            for ln in self.king_lanes:
+                t[ln, :] = one_t
+        self.a, self.b, self.c = lanes_buf(), lanes_buf(), lanes_buf()
+        self.sx, self.oy = (torch.zeros((D, 4), dtype=torch.int64, device=dev) for _ in range(2))
+        self.chk = torch.zeros((2, D, 4), dtype=torch.int64, device=dev)
+        self.ab = lanes_buf()
+        self.results = {}
+        self.all_results = []
+
+    def ntt_lanes_per_step(self):
+        return 7 * self.lanes
+
+    def describe(self):
+        return f"{7 * self.lanes} Fr NTT lanes of 2^{self.log_d} + 5 MSMs x {self.lanes} share lanes per GPU"
+
+    # one open of a share vector: value = sum of sh lanes; MAC check vector = mac_share*value - sum(mac lanes)
+    def _open(self, shares, out, chk):
+        czk, ctx, D = self.czk, self.ctx, self.D
+        ADD, SUB = 0, 1
+        M = czk.CZK_MEM_DEVICE
+        if len(self.local) < self.P:
+            # party-per-GPU layout: mpc-net's broadcast (multi.rs:145-173) is an all-gather of every party's (sh, mac)
+            # lanes over RCCL; the sums and the MAC comparison of batch_open (spdz.rs:166-185) are one fused kernel
+            assert len(self.local) == 1
+            gathered = self.exchange(shares)                       # (P, 2, D, 4), rank order == party order
+            bad = ctx.fr_spdz_open(gathered.data_ptr(), self.P, D, out.data_ptr())
+            assert bad == 0, "SPDZ MAC check failed"
+            return
+        ctx.fr_vec_op(ADD, shares[0].data_ptr(), shares[2].data_ptr(), out=out.data_ptr(), n=D, mem=M)
+        for p in range(2, self.P):
+            ctx.fr_vec_op(ADD, out.data_ptr(), shares[2 * p].data_ptr(), out=out.data_ptr(), n=D, mem=M)
+        ctx.fr_vec_op(SUB, out.data_ptr(), shares[1].data_ptr(), out=chk.data_ptr(), n=D, mem=M)
+        for p in range(1, self.P):
+            ctx.fr_vec_op(SUB, chk.data_ptr(), shares[2 * p + 1].data_ptr(), out=chk.data_ptr(), n=D, mem=M)
+
+    def new_results(self):
+        L = self.lanes
+        r = {k: np.zeros((L, 18), dtype=np.uint64) for k in ("h", "l", "a", "b_g1")}
+        r["b_g2"] = np.zeros((L, 36), dtype=np.uint64)
+        return r
+
+    def step(self, sync=True):
+        """One proof's local compute.  sync=False only enqueues (consecutive proofs then pipeline: the next proof's
+        witness-only MSMs and NTTs overlap this proof's tail); its results are valid after the next ctx.sync()."""
+        czk, ctx = self.czk, self.ctx
+        D, N, L, ld = self.D, self.N, self.lanes, self.log_d
+        M = czk.CZK_MEM_DEVICE
+        ADD = 0
+        MONT = czk.CZK_SCALAR_MONTGOMERY
+        r = self.results = self.new_results()      # every proof keeps its own output buffers
+        self.all_results.append(r)
+        # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
+        # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
+        ctx.msm_async(self.b_g2_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g2"], stable=True)
+        ctx.msm_async(self.l_query, self.wit.data_ptr(), N, L, MONT, r["l"], stable=True)
+        ctx.msm_async(self.a_query, self.asg.data_ptr(), N + 1, L, MONT, r["a"], stable=True)
+        ctx.msm_async(self.b_g1_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g1"], stable=True)
+        # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
+        # constraint evaluation <A_i, z>, <B_i, z>, <C_i, z> over the share lanes of the full assignment (r1cs_to_qap.rs:
+        # 67-83, 95-100); A carries the two instance-copy rows (:79-83).  Rows beyond each matrix are zero padding that the
+        # first NTT pass supplies itself, so nothing is cleared or copied.
+        ctx.r1cs_matvec(self.mat_a, self.full.data_ptr(), lanes=L, out=self.a.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.r1cs_matvec(self.mat_b, self.full.data_ptr(), lanes=L, out=self.b.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.r1cs_matvec(self.mat_c, self.full.data_ptr(), lanes=L, out=self.c.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.witness_map_pre(self.a.data_ptr(), self.b.data_ptr(), ld, L, a_len=N + 2, b_len=N)   # ifft, ifft, coset_fft, coset_fft
+        # batch_product_in_place -> S::batch_mul (share/field.rs:97-127): (s + x), (o + y), two opens, combine
+        ctx.fr_vec_op(ADD, self.a.data_ptr(), self.tx.data_ptr(), out=self.a.data_ptr(), n=L * D, mem=M)
+        ctx.fr_vec_op(ADD, self.b.data_ptr(), self.ty.data_ptr(), out=self.b.data_ptr(), n=L * D, mem=M)
+        self._open(self.a, self.sx, self.chk[0])
+        self._open(self.b, self.oy, self.chk[1])
+        for ln in range(L):
+            ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
+                                  self.oy.data_ptr(), ln in self.king_lanes, out=self.ab[ln].data_ptr(), n=D, mem=M)
+        ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L, c_len=N)     # h = ab
+        # --- the h MSM (prover.rs:104) needs the witness map's output; NOT flagged stable: the next proof's witness
+        # map overwrites `ab`, so the context's stream waits for this MSM's digit extraction (library-side ordering)
+        ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"])
+        if sync:
+            ctx.sync()
+
+    def msm_scalars(self):
+        """{query: device tensor of the Montgomery scalars its MSM consumed (lanes, n, 4)}; `h` is the LAST proof's."""
+        return {"h": self.ab, "l": self.wit, "a": self.asg, "b_g1": self.asg, "b_g2": self.asg}
+
+    def seam_calls_host_memory(self, reps: int = 1):
+        """The NTT / MSM seam calls of one proof with every buffer in HOST memory (pageable, like a Rust Vec): 7
+        czk_ntt_fr + 5 czk_msm per proof for all local lanes -- what an unmodified reference caller that binds only the
+        two seams (INTEGRATION.md sections 2-3) pays, PCIe staging included.  Values are irrelevant to the timing."""
+        czk, ctx = self.czk, self.ctx
+        D, N, L, ld = self.D, self.N, self.lanes, self.log_d
+        a = self.a0.cpu().numpy().view(np.uint64)
+        wit = self.wit.cpu().numpy().view(np.uint64)
+        asg = self.asg.cpu().numpy().view(np.uint64)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for kind in (czk.CZK_IFFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+                ctx.ntt_fr(a, ld, kind, lanes=L)
+            ctx.msm(self.h_query, a, n_scalars=D, lanes=L, scalar_form=czk.CZK_SCALAR_MONTGOMERY)
+            ctx.msm(self.l_query, wit, n_scalars=N, lanes=L, scalar_form=czk.CZK_SCALAR_MONTGOMERY)
+            for q in (self.a_query, self.b_g1_query, self.b_g2_query):
+                ctx.msm(q, asg, n_scalars=N + 1, lanes=L, scalar_form=czk.CZK_SCALAR_MONTGOMERY)
+        return (time.perf_counter() - t0) / reps
+
+    def g1_accumulate_algorithmic_bytes(self):
+        """an MSM of n points moves n*(96 B base) once + n*32 B of scalars per lane."""
+        tot = 0
+        for n in (self.D - 1, self.N, self.N + 1, self.N + 1):
+            tot += n * 96 + self.lanes * n * 32
+        return tot, 4   # bytes per step, launches per step
+
+    def g1_mixed_additions_per_step(self, windows: int):
+        return windows * self.lanes * ((self.D - 1) + self.N + 2 * (self.N + 1))

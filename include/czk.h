@@ -152,6 +152,9 @@ int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases, const uin
                        czk_bases** out);
 void czk_bases_release(czk_bases* b);
 size_t czk_bases_len(const czk_bases* b);
+/* Pippenger layout chosen at registration (reporting only): *c = signed-digit window width, *windows = ceil(254 / c) =
+ * mixed additions per (point, lane) of an MSM over this array. */
+int czk_bases_layout(const czk_bases* b, unsigned* c, unsigned* windows);
 
 /* Replaces VariableBaseMSM::multi_scalar_mul (algebra/ec/src/msm/variable_base.rs:12-106) / AffineCurve::
  * multi_scalar_mul (ec/src/lib.rs:300-311) as reached from MpcG{1,2}Affine::multi_scalar_mul

@@ -71,3 +71,26 @@ def test_partition_units_covers_everything():
             parts = [parallel.partition_units(n, w, r) for r in range(w)]
             assert sum(parts, []) == list(range(n))
             assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+@pytest.mark.parametrize("gpus,layout", [(2, "replica"), (3, "party")])
+def test_bench_launcher_starts_one_rank_per_gpu(gpus, layout):
+    """`python bench.py --gpus N` (no torchrun environment) must start N ranks itself and report the world size the
+    process group saw; --dry-run skips the GPU work so the launcher is covered on CPU (gloo)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-run", "--layout", layout, "--parties", str(gpus if layout == "party" else 2)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["dry_run"] and d["n_gpus"] == gpus and d["ranks_seen_by_backend"] == gpus
+    assert abs(d["max_over_ranks_s"] - 0.001 * gpus) < 1e-9      # the slowest rank's time
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

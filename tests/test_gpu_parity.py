@@ -4,7 +4,7 @@ MI355X with `-m gpu`."""
 import numpy as np
 import pytest
 
-from util import ints_to_limbs, limbs_to_ints, rand_fr_canonical, R_MOD
+from util import dot_mod_r, ints_to_limbs, limbs_to_ints, rand_fr_canonical, R_MOD
 
 pytestmark = pytest.mark.gpu
 
@@ -71,6 +71,26 @@ def test_ntt_all_kinds_bit_exact(ctx, czk, orc, log_d):
             for ln in range(lanes):
                 want = orc.ntt_fr(x[ln], log_d, kind, in_len)
                 assert np.array_equal(buf[ln], want), (log_d, in_len, kind, ln)
+
+
+@pytest.mark.parametrize("log_d", [17, 18, 19, 20, 21])
+def test_ntt_large_sizes_bit_exact_four_lanes(ctx, czk, orc, log_d):
+    """Every output limb of all four transform kinds against the checker's io/oi restatement (radix2/fft.rs:140-260) at
+    2^17 .. 2^21 (the three-pass decompositions, incl. the 2^21 BASELINE domain), 4 share lanes in device memory; the
+    inverse kinds run on a ragged prefix with a garbage tail (resize(size, zero), radix2/mod.rs:100-101)."""
+    import torch
+    d, lanes = 1 << log_d, 4
+    x = orc.fr_from_repr(rand_fr_canonical(4242 + log_d, lanes * d)).reshape(lanes, d, 4)
+    for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+        in_len = d if kind in (czk.CZK_FFT, czk.CZK_COSET_FFT) else d - 12345
+        buf = x.copy()
+        buf[:, in_len:] = 0xDEADBEEFDEADBEEF
+        t = torch.from_numpy(buf.view(np.int64)).cuda()
+        ctx.ntt_fr(t.data_ptr(), log_d, kind, lanes=lanes, in_len=in_len, mem=czk.CZK_MEM_DEVICE)
+        ctx.sync()
+        got = t.cpu().numpy().view(np.uint64)
+        for ln in range(lanes):
+            assert np.array_equal(got[ln], orc.ntt_fr(x[ln, :in_len], log_d, kind, in_len)), (log_d, kind, ln)
 
 
 def test_ntt_size_errors(ctx, czk):
@@ -211,31 +231,66 @@ def test_msm_empty_and_all_zero(ctx, czk, orc):
     b0.release()
 
 
-@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (1, (1 << 21) - 1), (2, (1 << 17) + 1), (2, (1 << 20) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7), (1, (1 << 22) + 1)])
+@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (1, (1 << 21) - 1), (2, (1 << 17) + 1), (2, (1 << 20) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7), (1, (1 << 22) + 1),
+                                 (2, (1 << 22) + 1), (1, (1 << 23) - 1)])
 def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, n):
-    """Size-independent check at BASELINE scale: bases P_i = [k_i] G, so MSM(P, s) must equal
-    [sum k_i s_i mod r] G; plus linearity between the two lanes.  Sizes: the Groth16 a/b queries and the h query at 2^20
-    constraints (configs[1]), G2 queries, the a/b query at 2^22 constraints (configs[4]), a KZG commit of a 2^18-coefficient polynomial (Plonk, configs[2]) and a
-    non-power-of-two ~3N commit as Marlin's largest polynomials at 2^20 (configs[3]; poly-commit/src/kzg10/mod.rs:159-162)."""
+    """Size-independent check at BASELINE scale, 4 share lanes: bases P_i = [k_i] G, so MSM(P, s) must equal
+    [sum k_i s_i mod r] G; plus linearity between lanes.  Sizes: the Groth16 a/b queries and the h query at 2^20
+    constraints (configs[1]), G2 queries, the a/b (G1 and G2) and h queries at 2^22 constraints (configs[4]: 2^22+1, 2^23-1), a KZG
+    commit of a 2^18-coefficient polynomial (Plonk, configs[2]) and a non-power-of-two ~3N commit as Marlin's largest polynomials
+    at 2^20 (configs[3]; poly-commit/src/kzg10/mod.rs:159-162)."""
     import torch
+    lanes = 4
     k = rand_fr_canonical(0xBA5E5, n)
     aw = 12 if g == 1 else 24
     kd = torch.from_numpy(k.view(np.int64)).cuda()
     pts = torch.empty((n, aw), dtype=torch.int64, device="cuda")
     ctx.fixed_base_points(g, kd.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
     b = ctx.register_bases(g, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
-    s = rand_fr_canonical(0xC0FFEE, 2 * n).reshape(2, n, 4)
+    del pts
+    s = rand_fr_canonical(0xC0FFEE, lanes * n).reshape(lanes, n, 4)
     sd = torch.from_numpy(s.view(np.int64)).cuda()
-    out = ctx.msm(b, sd.data_ptr(), n_scalars=n, lanes=2, mem=czk.CZK_MEM_DEVICE)
-    ki, gen = limbs_to_ints(k), ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
-    for ln in range(2):
-        si = limbs_to_ints(s[ln])
-        e = sum(a * c for a, c in zip(ki, si)) % R_MOD
+    out = ctx.msm(b, sd.data_ptr(), n_scalars=n, lanes=lanes, mem=czk.CZK_MEM_DEVICE)
+    gen = ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
+    for ln in range(lanes):
+        e = dot_mod_r(k, s[ln])
         assert _same_point(ctx, orc, g, out[ln], orc.scalar_mul(g, gen, False, ints_to_limbs([e], 4)[0])), (g, ln)
     # linearity: MSM(s0) + MSM(s1) == MSM(s0 + s1)
     ssum = orc.fr_into_repr(orc.fr_add(orc.fr_from_repr(s[0]), orc.fr_from_repr(s[1])))
     out_sum = ctx.msm(b, ssum, lanes=1)
     assert _same_point(ctx, orc, g, out_sum[0], orc.jac_add(g, out[0], out[1]))
+    b.release()
+
+
+@pytest.mark.parametrize("g,n,oracle_lanes", [(1, (1 << 20) + 1, (0, 3)), (2, (1 << 20) + 1, (1,))])
+def test_msm_full_size_matches_reference_pippenger(ctx, czk, orc, g, n, oracle_lanes):
+    """The a/b-query MSM of BASELINE configs[1] (2^20 + 1 points, 4 share lanes, one infinity base like the real key)
+    against the checker's Pippenger itself (variable_base.rs:12-106: c = 16, 16 windows of 65 535 buckets) -- not only via
+    discrete logs -- compared in affine.  Lanes the checker does not recompute are covered by the discrete-log identity."""
+    import torch
+    lanes = 4
+    k = rand_fr_canonical(0xBA5E5 + 3, n)
+    aw = 12 if g == 1 else 24
+    kd = torch.from_numpy(k.view(np.int64)).cuda()
+    pts = torch.empty((n, aw), dtype=torch.int64, device="cuda")
+    ctx.fixed_base_points(g, kd.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[0] = 1
+    infd = torch.from_numpy(inf).cuda()
+    b = ctx.register_bases(g, pts.data_ptr(), infd.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+    bases_host = pts.cpu().numpy().view(np.uint64)
+    s = orc.fr_from_repr(rand_fr_canonical(0xFACE, lanes * n)).reshape(lanes, n, 4)       # Montgomery scalars, as the MPC wrappers pass them
+    s[2, 5] = orc.fr_from_repr(ints_to_limbs([1], 4))[0]                                 # a unit scalar (variable_base.rs:44-48) and a zero
+    s[2, 6] = 0
+    sd = torch.from_numpy(s.view(np.int64)).cuda()
+    out = ctx.msm(b, sd.data_ptr(), n_scalars=n, lanes=lanes, scalar_form=czk.CZK_SCALAR_MONTGOMERY, mem=czk.CZK_MEM_DEVICE)
+    for ln in oracle_lanes:
+        assert _same_point(ctx, orc, g, out[ln], orc.multi_scalar_mul(g, bases_host, inf, s[ln])), (g, ln)
+    gen = ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
+    k[0] = 0
+    for ln in set(range(lanes)) - set(oracle_lanes):
+        e = dot_mod_r(k, orc.fr_into_repr(s[ln]))
+        assert _same_point(ctx, orc, g, out[ln], orc.scalar_mul(g, gen, False, ints_to_limbs([e], 4)[0])), (g, ln)
     b.release()
 
 
@@ -270,22 +325,20 @@ def test_witness_map_matches_reference_sequence(ctx, czk, orc):
     assert not h[d - 1].any()
 
 
-def test_groth16_local_pipeline_config0_matches_reference(ctx, czk, orc):
-    """BASELINE configs[0] (`bench.zsh groth16 spdz 10 2`: 10 constraints, domain 16, 2 SPDZ parties): the complete
-    per-party local compute of bench.py's step -- witness map with the Beaver local half and device-local opens,
-    then the five MSMs on every share lane -- against the checker: per lane the same NTT / pointwise sequence
-    (r1cs_to_qap.rs:47-113, share/field.rs:97-127) and Pippenger (variable_base.rs) on the same inputs."""
+@pytest.mark.parametrize("n_constraints", [10, 1024, 8])
+def test_groth16_local_pipeline_config0_matches_reference(ctx, czk, orc, n_constraints):
+    """BASELINE configs[0] (`bench.zsh groth16 spdz 10 2`: exactly 10 constraints, domain 16, 2 SPDZ parties; also 2^10
+    constraints, domain 2^11): the complete per-party local compute of bench.py's step -- witness map with the Beaver
+    local half and device-local opens, then the five MSMs on every share lane -- against the checker: per lane the same
+    NTT / pointwise sequence (r1cs_to_qap.rs:47-113, share/field.rs:97-127) and Pippenger (variable_base.rs) on the
+    same inputs."""
     import torch
-    import bench
+    from czk_amd.provers import Groth16Local
     ts = torch.cuda.Stream()
     with torch.cuda.stream(ts):
         c2 = czk.Context(0, ts.cuda_stream)
-        log_n = None
-        p = bench.Groth16Local.__new__(bench.Groth16Local)
-        # build a 10-constraint instance through the same constructor path (log_n is a power of two there, so use
-        # N = 8 constraints + 2 instance variables -> D = 16, the same domain as N = 10)
-        p.__init__(czk, c2, 3, 2)
-        assert p.D == 16 and p.lanes == 4
+        p = Groth16Local(czk, c2, n_constraints, 2)
+        assert p.N == n_constraints and p.D == {10: 16, 8: 16, 1024: 2048}[n_constraints] and p.lanes == 4
         a0, b0, c0 = (t.cpu().numpy().view(np.uint64).copy() for t in (p.a0, p.b0, p.c0))
         tx, ty, tz = (t.cpu().numpy().view(np.uint64).copy() for t in (p.tx, p.ty, p.tz))
         wit, asg = p.wit.cpu().numpy().view(np.uint64).copy(), p.asg.cpu().numpy().view(np.uint64).copy()
@@ -293,7 +346,7 @@ def test_groth16_local_pipeline_config0_matches_reference(ctx, czk, orc):
         torch.cuda.synchronize()
         h_gpu = p.ab.cpu().numpy().view(np.uint64)
         assert not bool(p.chk.any().item())
-    L, D, ld = 4, 16, 4
+    L, D, ld = 4, p.D, p.log_d
     # checker: lane-wise witness map with the Beaver local half
     A = [orc.witness_map_pre(a0[ln], b0[ln], ld) for ln in range(L)]
     sa = [orc.fr_add(A[ln][0], tx[ln]) for ln in range(L)]
@@ -535,32 +588,29 @@ def test_poly_div_linear_full_size_identity(ctx, czk, orc):
         assert np.array_equal(lhs, rhs)
 
 
-@pytest.mark.parametrize("parties", [2, 3])
-def test_party_per_rank_layout_matches_single_gpu_layout(parties):
+@pytest.mark.parametrize("parties,size", [(2, ["--log-n", "12"]), (3, ["--log-n", "10"]), (8, ["--constraints", "100"])])
+def test_party_per_rank_layout_matches_single_gpu_layout(parties, size):
     """bench.py --layout party (one MPC party per rank; the witness map's two opens are all-gathers + the fused
-    open/MAC-check kernel) must produce the same proof elements as the default layout with both parties on one GPU.
-    The ranks share this box's single GPU, so the exchange runs over gloo (RCCL needs one device per rank)."""
+    open/MAC-check kernel) must produce the same proof elements as the default layout with all parties on one GPU
+    (BASELINE configs[4] shape at 8 parties).  bench.py --gpus N launches the N ranks itself; they share this box's
+    single GPU, so the exchange runs over gloo (RCCL needs one device per rank)."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    common = ["--log-n", "12" if parties == 2 else "10", "--parties", str(parties), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    common = size + ["--parties", str(parties), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-seam-report"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(parties), "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo",
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo",
                           "--device", "0"] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
     assert two.returncode == 0, two.stderr[-2000:]
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     d2 = json.loads(two.stdout.strip().splitlines()[-1])
-    assert d2["n_gpus"] == parties and d2["config"]["layout"] == "party"
+    assert d2["n_gpus"] == parties and d2["ranks_seen_by_backend"] == parties and d2["config"]["layout"] == "party"
+    assert d1["results_checked"] and d2["results_checked"]
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
 
 

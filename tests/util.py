@@ -53,3 +53,19 @@ def limbs_to_ints(arr):
     arr = np.asarray(arr, dtype=np.uint64)
     arr = arr.reshape(-1, arr.shape[-1])
     return [sum(int(arr[i, j]) << (64 * j) for j in range(arr.shape[1])) for i in range(arr.shape[0])]
+
+
+def dot_mod_r(k, s) -> int:
+    """sum_i k_i * s_i mod r for (n,4) uint64 limb arrays, exactly and without per-element Python integers: 16-bit limbs as
+    float64, the 16 x 16 limb-pair sums by dgemm in chunks of 2^18 rows (< 2^50: exact), accumulated as Python ints."""
+    tot = [[0] * 16 for _ in range(16)]
+    n = k.shape[0]
+    for lo in range(0, n, 1 << 18):
+        hi = min(n, lo + (1 << 18))
+        K = np.ascontiguousarray(k[lo:hi]).view(np.uint16).reshape(-1, 16).astype(np.float64)
+        S = np.ascontiguousarray(s[lo:hi]).view(np.uint16).reshape(-1, 16).astype(np.float64)
+        m = K.T @ S
+        for a in range(16):
+            for b in range(16):
+                tot[a][b] += int(m[a, b])
+    return sum(tot[a][b] << (16 * (a + b)) for a in range(16) for b in range(16)) % R_MOD
