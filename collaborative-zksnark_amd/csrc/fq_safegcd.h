@@ -1,0 +1,200 @@
+// fq_safegcd.h -- modular inversion in Fq (BLS12-377 base field, 377 bits) by Bernstein-Yang "safegcd" division steps.
+//
+// Why: on a 64-wide SIMD every lane of a wave executes the whole inversion, so Fermat's a^(p-2) (377 squarings + ~190
+// multiplies ~ 270 k instructions) is paid in full no matter how many lanes need it; Montgomery's trick can only amortise
+// it over additions done by the SAME lane.  Division steps work on the low 30 bits of (f, g) for 30 steps at a time and
+// touch the full 13-limb numbers only once per batch (a 2x2 matrix applied to (f, g) and to (d, e) mod p): ~0.8 k
+// instructions per batch, 29 batches -- about 12x cheaper, data-independent control flow (no divergence).
+//
+// The value computed is the unique inverse, i.e. exactly what the reference's binary extended Euclid returns
+// (algebra/ff/src/fields/macros.rs:367-421).
+//
+// Division step (half-delta variant; zeta = -(delta + 1/2), delta starts at 1/2):
+//     if zeta < 0 and g odd:  (zeta, f, g) <- (-zeta - 2, g, (g - f) / 2)
+//     else:                    (zeta, f, g) <- (zeta - 1, f, (g + (g odd ? f : 0)) / 2)
+// For a 377-bit odd modulus f and 0 <= g < f, g reaches 0 within (45907 * 377 + 26313) / 19929 < 870 = 29 * 30 steps
+// (Pornin / Wuille bound for this variant); then f = +-1 and d = +-g_0^-1 mod p.
+// Numbers are 13 signed limbs of 30 bits (390 bits).  p == 1 mod 2^46, so p^-1 mod 2^30 = 1.
+#pragma once
+#include "field.h"
+
+namespace czk {
+
+struct S30 {
+    int32_t v[13];
+};
+constexpr int32_t SG_M30 = (1 << 30) - 1;
+
+CZK_HD int32_t sg_p(int i) {
+    constexpr int32_t m[13] = {0x1, 0x14230000, 0x8, 0x2d7510c, 0x9480017, 0xd88bee8, 0x1138f1ef,
+                               0x367cc03d, 0x93b1a22, 0x1701b285, 0xeac63b0, 0x1185f144, 0x1ae3a};
+    return m[i];
+}
+
+struct SgMat {
+    int32_t u, v, q, r;
+};
+
+// 30 division steps on the low words; returns the transition matrix t with 2^30 (f', g') = t (f, g)
+CZK_HD int32_t sg_divsteps30(int32_t zeta, uint32_t f0, uint32_t g0, SgMat& t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+    uint32_t f = f0, g = g0;
+#pragma unroll
+    for (int i = 0; i < 30; i++) {
+        uint32_t c1 = (uint32_t)(zeta >> 31);          // all ones when zeta < 0
+        uint32_t c2 = 0u - (g & 1u);                   // all ones when g is odd
+        uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;   // (f, u, v) negated when zeta < 0
+        g += x & c2;
+        q += y & c2;
+        r += z & c2;
+        c1 &= c2;                                      // swap case: zeta < 0 and g odd
+        zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;
+        f += g & c1;
+        u += q & c1;
+        v += r & c1;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
+    }
+    t.u = (int32_t)u;
+    t.v = (int32_t)v;
+    t.q = (int32_t)q;
+    t.r = (int32_t)r;
+    return zeta;
+}
+
+// (f, g) <- t (f, g) / 2^30   (exact)
+CZK_HD void sg_update_fg(S30& f, S30& g, const SgMat& t) {
+    int64_t cf = (int64_t)t.u * f.v[0] + (int64_t)t.v * g.v[0];
+    int64_t cg = (int64_t)t.q * f.v[0] + (int64_t)t.r * g.v[0];
+    cf >>= 30;
+    cg >>= 30;
+#pragma unroll
+    for (int i = 1; i < 13; i++) {
+        cf += (int64_t)t.u * f.v[i] + (int64_t)t.v * g.v[i];
+        cg += (int64_t)t.q * f.v[i] + (int64_t)t.r * g.v[i];
+        f.v[i - 1] = (int32_t)cf & SG_M30;
+        g.v[i - 1] = (int32_t)cg & SG_M30;
+        cf >>= 30;
+        cg >>= 30;
+    }
+    f.v[12] = (int32_t)cf;
+    g.v[12] = (int32_t)cg;
+}
+
+// (d, e) <- t (d, e) / 2^30 mod p, both kept in (-2p, p)
+CZK_HD void sg_update_de(S30& d, S30& e, const SgMat& t) {
+    const int32_t sd = d.v[12] >> 31, se = e.v[12] >> 31;       // sign masks
+    int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);   // + p for negative inputs
+    int64_t cd = (int64_t)t.u * d.v[0] + (int64_t)t.v * e.v[0];
+    int64_t ce = (int64_t)t.q * d.v[0] + (int64_t)t.r * e.v[0];
+    // multiples of p that clear the low 30 bits (p^-1 mod 2^30 == 1)
+    md -= ((int32_t)cd + md) & SG_M30;
+    me -= ((int32_t)ce + me) & SG_M30;
+    cd += (int64_t)sg_p(0) * md;
+    ce += (int64_t)sg_p(0) * me;
+    cd >>= 30;
+    ce >>= 30;
+#pragma unroll
+    for (int i = 1; i < 13; i++) {
+        cd += (int64_t)t.u * d.v[i] + (int64_t)t.v * e.v[i] + (int64_t)sg_p(i) * md;
+        ce += (int64_t)t.q * d.v[i] + (int64_t)t.r * e.v[i] + (int64_t)sg_p(i) * me;
+        d.v[i - 1] = (int32_t)cd & SG_M30;
+        e.v[i - 1] = (int32_t)ce & SG_M30;
+        cd >>= 30;
+        ce >>= 30;
+    }
+    d.v[12] = (int32_t)cd;
+    e.v[12] = (int32_t)ce;
+}
+
+// r in (-2p, p), negated when `sign` < 0, brought to [0, p)
+CZK_HD void sg_normalize(S30& r, int32_t sign) {
+    int32_t cond_add = r.v[12] >> 31;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.v[i] += sg_p(i) & cond_add;
+    const int32_t cond_neg = sign >> 31;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.v[i] = (r.v[i] ^ cond_neg) - cond_neg;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        r.v[i] += c;
+        c = r.v[i] >> 30;
+        r.v[i] &= SG_M30;
+    }
+    r.v[12] += c;
+    cond_add = r.v[12] >> 31;
+#pragma unroll
+    for (int i = 0; i < 13; i++) r.v[i] += sg_p(i) & cond_add;
+    c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        r.v[i] += c;
+        c = r.v[i] >> 30;
+        r.v[i] &= SG_M30;
+    }
+    r.v[12] += c;
+}
+
+// 12 x 32-bit integer (< p) -> 13 x 30-bit limbs
+CZK_HD S30 sg_from_words(const u32* w) {
+    S30 r;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        const int bit = 30 * i, k = bit >> 5, off = bit & 31;
+        u32 lo = w[k], hi = (k + 1) < 12 ? w[k + 1] : 0u;
+        u32 val = off == 0 ? lo : (off <= 2 ? (lo >> off) : ((lo >> off) | (hi << (32 - off))));
+        r.v[i] = (int32_t)(val & (u32)SG_M30);
+    }
+    return r;
+}
+// 13 x 30-bit limbs in [0, 2^30) -> 12 x 32-bit integer
+CZK_HD void sg_to_words(const S30& a, u32* w) {
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int bit = 32 * k, i = bit / 30, sh = bit - 30 * i;   // limb i holds bits [30 i, 30 i + 30)
+        u32 val = (u32)a.v[i] >> sh;
+        int have = 30 - sh;
+        if (i + 1 < 13) val |= (u32)a.v[i + 1] << have;
+        have += 30;
+        if (have < 32 && i + 2 < 13) val |= (u32)a.v[i + 2] << have;
+        w[k] = val;
+    }
+}
+
+// x^-1 mod p for the integer 0 < x < p given as 12 x 32-bit words; 0 -> 0.  `all_done(g_is_zero)` lets a caller stop a
+// whole wave early (all lanes finished); pass a functor that returns false to run the full 29 batches.
+template <class Done>
+CZK_HD Fq fq_inv_safegcd_words(const Fq& x, Done all_done) {
+    S30 f, g = sg_from_words(x.l), d, e;
+#pragma unroll
+    for (int i = 0; i < 13; i++) {
+        f.v[i] = sg_p(i);
+        d.v[i] = 0;
+        e.v[i] = 0;
+    }
+    e.v[0] = 1;
+    int32_t zeta = -1;
+    for (int it = 0; it < 29; it++) {
+        SgMat t;
+        zeta = sg_divsteps30(zeta, (u32)f.v[0] | ((u32)f.v[1] << 30), (u32)g.v[0] | ((u32)g.v[1] << 30), t);
+        sg_update_de(d, e, t);
+        sg_update_fg(f, g, t);
+        int32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 13; i++) nz |= g.v[i];
+        if (all_done(nz == 0)) break;
+    }
+    sg_normalize(d, f.v[12]);
+    Fq r;
+    sg_to_words(d, r.l);
+    return r;
+}
+
+struct SgNever {
+    CZK_HD bool operator()(bool) const { return false; }
+};
+CZK_HD Fq fq_inv_safegcd(const Fq& x) { return fq_inv_safegcd_words(x, SgNever{}); }
+
+}  // namespace czk
