@@ -193,6 +193,7 @@ extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
     if (hipSetDevice(device) != hipSuccess) return CZK_ERR_HIP;
     czk_ctx* c = new czk_ctx();
     c->device = device;
+    c->ntt_gen1 = getenv("CZK_NTT_GEN1") != nullptr;
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -218,6 +219,10 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
         if (d.tw_inv) (void)hipFree(d.tw_inv);
         if (d.coset_fwd) (void)hipFree(d.coset_fwd);
         if (d.coset_inv) (void)hipFree(d.coset_inv);
+        if (d.twu_fwd) (void)hipFree(d.twu_fwd);
+        if (d.twu_inv) (void)hipFree(d.twu_inv);
+        if (d.cosetu_fwd) (void)hipFree(d.cosetu_fwd);
+        if (d.cosetu_inv) (void)hipFree(d.cosetu_inv);
     }
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
     if (ctx->poly_scratch.p) (void)hipFree(ctx->poly_scratch.p);

@@ -18,6 +18,9 @@ struct DomainTables {
     u64* tw_inv = nullptr;     // same for w^-1
     u64* coset_fwd = nullptr;  // D entries: g^i, g = 22
     u64* coset_inv = nullptr;  // D entries: size_inv * g^-i
+    // the same four tables in the unsaturated residue system of fru.h (9 x u32 per entry: value * 2^261 mod r), used by the
+    // second-generation passes (ntt_pass.hip) for domains of 2^11 and more
+    uint32_t *twu_fwd = nullptr, *twu_inv = nullptr, *cosetu_fwd = nullptr, *cosetu_inv = nullptr;
     Fr size_inv, group_gen, group_gen_inv, generator, generator_inv, vanishing_inv;
 };
 
@@ -72,6 +75,7 @@ struct czk_ctx {
     std::vector<czk::MsmPending> msm_pending;
     bool msm_sort_onepass = false;   // CZK_SORT_ONEPASS=1 at pipeline creation: the single-pass digit sort (kept as the > 2048-partition fallback)
     unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
+    bool ntt_gen1 = false;           // CZK_NTT_GEN1=1 at context creation: first-generation NTT passes for every size (A/B runs)
     bool profiling = false;
     std::map<std::string, czk::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;

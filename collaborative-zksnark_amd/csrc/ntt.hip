@@ -21,6 +21,7 @@
 //   * lanes (sh / mac share lanes, several parties) ride on gridDim.y.
 // Arithmetic is integer VALU (v_mad_u64_u32); there is no MFMA-shaped work here.
 #include "czk_internal.h"
+#include "ntt_pass.h"
 
 namespace czk {
 
@@ -311,6 +312,8 @@ int get_domain(czk_ctx* ctx, unsigned log_d, DomainTables** out) {
     return CZK_OK;
 }
 
+constexpr unsigned NTT2_MIN_LOG = 11;   // domains from 2^11 on run the second-generation passes (pass sizes 5..7)
+
 // device tables are built lazily (a 2^47 domain has valid constants but no tables)
 static int ensure_tables(czk_ctx* ctx, DomainTables* d, bool need_coset_fwd, bool need_coset_inv) {
     const unsigned n = d->log_d;
@@ -351,6 +354,25 @@ static int ensure_tables(czk_ctx* ctx, DomainTables* d, bool need_coset_fwd, boo
         hipLaunchKernelGGL(k_pow_table, dim3(blocks), dim3(128), 0, ctx->stream, d->coset_inv, D, d->generator_inv, d->size_inv);
         CZK_HIP(ctx, hipGetLastError());
     }
+    if (n >= NTT2_MIN_LOG) {   // second-generation passes: the same tables in the unsaturated residue system (fru.h)
+        if (!d->twu_fwd) {
+            CZK_HIP(ctx, hipMalloc(&d->twu_fwd, (D - 1) * 36));
+            CZK_HIP(ctx, hipMalloc(&d->twu_inv, (D - 1) * 36));
+            launch_table_to_u(ctx->stream, d->tw_fwd, D - 1, d->twu_fwd);
+            launch_table_to_u(ctx->stream, d->tw_inv, D - 1, d->twu_inv);
+            CZK_HIP(ctx, hipGetLastError());
+        }
+        if (need_coset_fwd && !d->cosetu_fwd) {
+            CZK_HIP(ctx, hipMalloc(&d->cosetu_fwd, D * 36));
+            launch_table_to_u(ctx->stream, d->coset_fwd, D, d->cosetu_fwd);
+            CZK_HIP(ctx, hipGetLastError());
+        }
+        if (need_coset_inv && !d->cosetu_inv) {
+            CZK_HIP(ctx, hipMalloc(&d->cosetu_inv, D * 36));
+            launch_table_to_u(ctx->stream, d->coset_inv, D, d->cosetu_inv);
+            CZK_HIP(ctx, hipGetLastError());
+        }
+    }
     return CZK_OK;
 }
 
@@ -383,10 +405,34 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
 
     u64* scratch = nullptr;
     if (m > 1) {
-        CZK_TRY(ensure_buf(ctx, ctx->ntt_scratch, lanes * D * 32));
+        CZK_TRY(ensure_buf(ctx, ctx->ntt_scratch, lanes * D * (n >= NTT2_MIN_LOG ? NTT2_SCRATCH_ELEM_BYTES : 32)));
         scratch = (u64*)ctx->ntt_scratch.p;
     }
     unsigned s_hi_plus1 = n;
+    if (n >= NTT2_MIN_LOG && !ctx->ntt_gen1) {
+        // second-generation passes (ntt_pass.hip): register-resident radix-8 / radix-4 groups, unsaturated arithmetic
+        Pass2Args b;
+        b.tw = inverse ? d->twu_inv : d->twu_fwd;
+        b.n = n;
+        b.in_len = in_len;
+        b.lane_stride = D;
+        b.postconst = host_fr_to_u(d->size_inv);
+        for (unsigned p = 0; p < m; p++) {
+            const bool first = (p == 0), last = (p == m - 1);
+            const unsigned K = groups[p];
+            b.s_lo = s_hi_plus1 - K;
+            s_hi_plus1 = b.s_lo;
+            b.first = first ? 1 : 0;
+            b.prescale = (first && kind == CZK_COSET_FFT) ? d->cosetu_fwd : nullptr;
+            b.posttab = (last && kind == CZK_COSET_IFFT) ? d->cosetu_inv : nullptr;
+            b.post_mode = !last ? 0 : (kind == CZK_IFFT ? 1 : (kind == CZK_COSET_IFFT ? 2 : 0));
+            b.in = first ? data : scratch;
+            b.out = last ? data : scratch;
+            ProfScope ps(ctx, "ntt_pass");
+            CZK_TRY(launch_ntt2_pass(ctx, b, K, last, lanes));
+        }
+        return CZK_OK;
+    }
     for (unsigned p = 0; p < m; p++) {
         const bool first = (p == 0), last = (p == m - 1);
         a.K = groups[p];
