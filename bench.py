@@ -257,6 +257,7 @@ def main():
                          "party: ONE proof, party p's lanes on rank p (--gpus == --parties), opens all-gathered over RCCL")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rigs with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for this rank (default LOCAL_RANK)")
+    ap.add_argument("--commit-opens", action="store_true", help="party layout: dx_t goes through atomic_broadcast (SHA-256 commit-then-open, channel.rs:50-75)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
 
@@ -302,7 +303,8 @@ def main():
     ctx = czk.Context(device, tstream.cuda_stream)
     assert tstream.cuda_stream != 0
     if party_layout:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], exchange=parallel.all_gather_shares)
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank])
+        prover.commit_opens = args.commit_opens
     else:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties)
 
@@ -414,8 +416,9 @@ def main():
                    "constraints": n_constraints, "domain": prover.D, "parties": args.parties, "share_lanes": prover.lanes,
                    "parallelism": (f"{world} independent proofs (one per GPU), no data-path collective; consecutive proofs on a GPU are "
                                    "pipelined (ms_per_step = throughput; latency_ms_single_proof = one proof alone)") if not party_layout else
-                                  (f"ONE proof over {world} GPUs, party p's two share lanes on rank p; the two opens of the witness map are "
-                                   f"all-gathers over {args.backend} (mpc-net broadcast) followed by the fused sum + MAC-check kernel"),
+                                  (f"ONE proof over {world} GPUs, party p's two share lanes on rank p; each of the two opens of the witness map is the "
+                                   f"reference's two broadcast rounds (sh lanes, then dx_t = mac_share * value - mac) as all-gathers over {args.backend}, "
+                                   "sums and the MAC check on device"),
                    "layout": args.layout, "results_sha256": digest},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

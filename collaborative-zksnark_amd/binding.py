@@ -240,6 +240,29 @@ class Context:
         self._ck(lib().czk_fr_spdz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(out_value_ptr), C.byref(bad)))
         return bad.value
 
+    def fr_lanes_sum(self, x_ptr, k: int, n: int, out_ptr=None, count_nonzero: bool = False):
+        """out[i] = sum of k device vectors; returns the number of non-zero sums when count_nonzero."""
+        nz = C.c_uint64(0)
+        self._ck(lib().czk_fr_lanes_sum(self._h, _ptr(x_ptr), C.c_size_t(k), C.c_size_t(n), _ptr(out_ptr), C.byref(nz) if count_nonzero else C.c_void_p(0)))
+        return nz.value
+
+    def fr_spdz_dx(self, value_ptr, mac_ptr, mac_share, out_ptr, n: int):
+        """dx_t = mac_share * value - mac on device vectors (share/spdz.rs:176-180); mac_share: (4,) uint64 Montgomery."""
+        ms = np.ascontiguousarray(mac_share, np.uint64).reshape(4)
+        self._ck(lib().czk_fr_spdz_dx(self._h, _ptr(value_ptr), _ptr(mac_ptr), _ptr(ms), _ptr(out_ptr), C.c_size_t(n)))
+
+    def share_domain_constants(self, parties: int):
+        out = np.zeros((3, 4), dtype=np.uint64)
+        self._ck(lib().czk_share_domain_constants(self._h, C.c_size_t(parties), _ptr(out)))
+        return dict(zip(["size_inv", "group_gen", "group_gen_inv"], out))
+
+    def fr_gsz_open(self, shares_ptr, parties: int, n: int, out_value_ptr, degree: int = 0, degrees_ptr=None) -> int:
+        """Local part of GszFieldShare::batch_open on device buffers; returns the number of degree-bound violations."""
+        bad = C.c_uint64(0)
+        self._ck(lib().czk_fr_gsz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(degrees_ptr), C.c_uint(degree),
+                                       _ptr(out_value_ptr), C.byref(bad)))
+        return bad.value
+
     def r1cs_matrix_register(self, row_ptr, col_idx, coeff, n_vars: int, mem=CZK_MEM_HOST, m=None, nnz=None) -> "R1csMatrix":
         """One of ConstraintMatrices::{a, b, c} in CSR form (host numpy arrays, or device pointers with m / nnz given)."""
         if mem == CZK_MEM_HOST:

@@ -227,6 +227,7 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
     if (ctx->poly_scratch.p) (void)hipFree(ctx->poly_scratch.p);
     if (ctx->open_bad) (void)hipFree(ctx->open_bad);
+    if (ctx->share_tab.p) (void)hipFree(ctx->share_tab.p);
     msm_pipeline_destroy(ctx);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);

@@ -86,6 +86,7 @@ struct czk_ctx {
     std::map<unsigned, czk::DomainTables> domains;
     czk::DeviceBuf ntt_scratch;   // one lane-batch for the out-of-place NTT passes
     czk::DeviceBuf poly_scratch;  // segment sums of czk_poly_div_linear (poly.hip)
+    czk::DeviceBuf share_tab;     // size_inv * w^(-jk) table of czk_fr_gsz_open (share.hip)
     int num_cu = 256;
 };
 

@@ -82,3 +82,136 @@ def all_gather_shares(share: torch.Tensor) -> torch.Tensor:
     out = torch.empty((world,) + tuple(share.shape), dtype=share.dtype, device=share.device)
     dist.all_gather_into_tensor(out, share.contiguous())
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mpc-net's other primitives over torch.distributed (RCCL on GPUs, gloo on CPU) and the reference's wire format
+# ------------------------------------------------------------------------------------------------------------------
+def _world_rank():
+    return (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+
+
+def send_to_king(x: torch.Tensor):
+    """mpc-net `send_to_king` (mpc-net/src/multi.rs:175-210): the king (rank 0) receives every party's buffer as a
+    (world, *x.shape) tensor in party order, everyone else None.  One grouped gather (RCCL: send/recv group)."""
+    world, rank = _world_rank()
+    if world == 1:
+        return x.unsqueeze(0)
+    if dist.get_backend() == "gloo":
+        host = x.contiguous().cpu()
+        out = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, out, dst=0)
+        return torch.stack(out).to(x.device) if rank == 0 else None
+    out = [torch.empty_like(x) for _ in range(world)] if rank == 0 else None
+    dist.gather(x.contiguous(), out, dst=0)
+    return torch.stack(out) if rank == 0 else None
+
+
+def recv_from_king(xs, like: torch.Tensor) -> torch.Tensor:
+    """mpc-net `recv_from_king` (multi.rs:211-242): the king hands party p the p-th of equally long buffers (xs: (world,
+    *like.shape) on the king, None elsewhere); returns this party's buffer.  One grouped scatter."""
+    world, rank = _world_rank()
+    if world == 1:
+        return xs[0]
+    gloo = dist.get_backend() == "gloo"
+    out = torch.empty_like(like.cpu() if gloo else like)
+    parts = None
+    if rank == 0:
+        assert xs.shape[0] == world
+        parts = [(xs[p].contiguous().cpu() if gloo else xs[p].contiguous()) for p in range(world)]
+    dist.scatter(out, parts, src=0)
+    return out.to(like.device)
+
+
+def king_compute(x: torch.Tensor, f):
+    """mpc-algebra/src/channel.rs:77-80: send to the king, the king applies f to the stacked inputs, everyone gets its part back."""
+    got = send_to_king(x)
+    return recv_from_king(f(got) if got is not None else None, x)
+
+
+COMMIT_RAND_BYTES = 32   # mpc-algebra/src/channel.rs:89
+
+
+def serialize_fr_vec(canonical_limbs) -> bytes:
+    """`Vec<Fr>::serialize` (algebra/serialize/src/lib.rs:220-229; fields/macros.rs impl_prime_field_serializer with EmptyFlags):
+    u64 little-endian length, then 32 little-endian bytes of into_repr() per element.  Input: (n, 4) uint64 canonical limbs
+    (czk_fr_into_repr's output) as a numpy array or CPU tensor."""
+    import numpy as np
+    a = canonical_limbs.numpy() if isinstance(canonical_limbs, torch.Tensor) else np.asarray(canonical_limbs)
+    a = np.ascontiguousarray(a).view(np.uint64).reshape(-1, 4)
+    return int(a.shape[0]).to_bytes(8, "little") + a.astype("<u8").tobytes()
+
+
+def deserialize_fr_vec(buf: bytes):
+    """Inverse of serialize_fr_vec: (n, 4) uint64 canonical limbs; raises on a length that does not match the payload."""
+    import numpy as np
+    n = int.from_bytes(buf[:8], "little")
+    if len(buf) != 8 + 32 * n:
+        raise ValueError("Vec<Fr> wire format: length prefix does not match the payload")
+    return np.frombuffer(buf[8:], dtype="<u8").reshape(n, 4).astype(np.uint64)
+
+
+def atomic_broadcast(ctx, x: torch.Tensor, rand32: bytes | None = None) -> torch.Tensor:
+    """mpc-algebra/src/channel.rs:50-75 `atomic_broadcast` of one Fr vector (device tensor, Montgomery limbs): every party first
+    broadcasts SHA-256(serialized vector || 32 random bytes), then the data itself; each receiver re-hashes what the others
+    sent and compares (commit-then-open: nobody can choose its vector after seeing the others').  Returns the gathered
+    vectors (world, n, 4).  The commitment runs over the reference's wire bytes (canonical limbs with a u64 length prefix), so
+    the hashes equal the reference's for equal data and randomness.  Host-side hashing: this is the protocol's check, not hot-path
+    arithmetic; pass commit=False to spdz_batch_open to skip it."""
+    import hashlib
+    import os as _os
+    import numpy as np
+    world, rank = _world_rank()
+    n = x.shape[0]
+    rep = torch.empty_like(x)
+    ctx.fr_into_repr(x.data_ptr(), out=rep.data_ptr(), n=n, mem=1)
+    ctx.sync()
+    wire = serialize_fr_vec(rep.cpu().numpy().view(np.uint64))
+    rnd = rand32 if rand32 is not None else _os.urandom(COMMIT_RAND_BYTES)
+    digest = hashlib.sha256(wire + rnd).digest()
+    dev = x.device
+    commits = all_gather_shares(torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(dev))           # round 1: commitments
+    data = all_gather_shares(x)                                                                              # round 2: the vectors ...
+    rnds = all_gather_shares(torch.frombuffer(bytearray(rnd), dtype=torch.uint8).to(dev))                   # ... and the randomness
+    for p in range(world):
+        if p == rank:
+            continue
+        other = torch.empty_like(x)
+        ctx.fr_into_repr(data[p].contiguous().data_ptr(), out=other.data_ptr(), n=n, mem=1)
+        ctx.sync()
+        w = serialize_fr_vec(other.cpu().numpy().view(np.uint64))
+        if hashlib.sha256(w + bytes(rnds[p].cpu().numpy())).digest() != bytes(commits[p].cpu().numpy()):
+            raise AssertionError(f"atomic_broadcast: party {p}'s data does not match its commitment")
+    return data
+
+
+def spdz_batch_open(ctx, sh: torch.Tensor, mac: torch.Tensor, mac_share, commit: bool = True) -> torch.Tensor:
+    """SpdzFieldShare::batch_open as the reference runs it with one process per party (mpc-algebra/src/share/spdz.rs:166-185):
+    round 1 broadcast of the `sh` lanes and their sum; dx_t = mac_share * value - mac; round 2 atomic_broadcast of dx_t, whose
+    sum must vanish.  MAC shares themselves never leave the party.  sh, mac: (n, 4) device tensors; mac_share: (4,) uint64."""
+    world, _ = _world_rank()
+    n = sh.shape[0]
+    ctx.sync()   # `sh` / `mac` may still be in flight on the context's stream
+    gathered = all_gather_shares(sh)                                       # Net::broadcast(&s_vals)
+    vals = torch.empty_like(sh)
+    ctx.fr_lanes_sum(gathered.data_ptr(), world, n, out_ptr=vals.data_ptr())
+    dx = torch.empty_like(sh)
+    ctx.fr_spdz_dx(vals.data_ptr(), mac.data_ptr(), mac_share, dx.data_ptr(), n)
+    ctx.sync()   # the exchange below runs on torch's stream (or through the host): the context's kernels must have finished
+    all_dx = atomic_broadcast(ctx, dx) if commit else all_gather_shares(dx)   # Net::atomic_broadcast(&dx_ts)
+    bad = ctx.fr_lanes_sum(all_dx.contiguous().data_ptr(), world, n, count_nonzero=True)
+    assert bad == 0, "SPDZ MAC check failed"                              # assert!(sum.is_zero())
+    return vals
+
+
+def gsz_batch_open(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
+    """GszFieldShare::batch_open (mpc-algebra/src/share/gsz20/mod.rs:286-300): broadcast, per element the size-n_parties
+    inverse DFT with the degree check, p(0)."""
+    world, _ = _world_rank()
+    n = val.shape[0]
+    ctx.sync()   # `val` may still be in flight on the context's stream
+    gathered = all_gather_shares(val)
+    out = torch.empty_like(val)
+    bad = ctx.fr_gsz_open(gathered.data_ptr(), world, n, out.data_ptr(), degree=degree)
+    assert bad == 0, "GSZ open: a share polynomial exceeds its degree bound"
+    return out

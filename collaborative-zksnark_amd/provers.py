@@ -66,13 +66,16 @@ class Groth16Local:
 
     def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None):
         """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
-        configs[1]); with a strict subset, `exchange` (parallel.all_gather_shares) plays mpc-net's broadcast in the two
-        opens of the witness map."""
+        configs[1]); with one party per rank the two opens of the witness map run the reference's two broadcast rounds
+        over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused."""
         self.czk, self.ctx = czk, ctx
         self.N = int(n_constraints)
         self.P = parties
         self.local = list(range(parties)) if local_parties is None else list(local_parties)
         self.exchange = exchange
+        self.commit_opens = False                     # True: dx_t goes through atomic_broadcast (commit-then-open, channel.rs:50-75)
+        # mac_share() = 1 on the king, 0 elsewhere (share/spdz.rs:30-37: the reference's stand-in MAC key is 1)
+        self.mac_share = to_mont_limbs([1 if (self.local and self.local[0] == 0) else 0])[0]
         self.lanes = 2 * len(self.local)              # SPDZ: sh + mac per party (share/spdz.rs:50-53)
         self.log_d = (self.N + 2 - 1).bit_length()    # D = next_pow2(N + num_instance) (r1cs_to_qap.rs:63-65)
         self.D = 1 << self.log_d
@@ -183,12 +186,13 @@ class Groth16Local:
         ADD, SUB = 0, 1
         M = czk.CZK_MEM_DEVICE
         if len(self.local) < self.P:
-            # party-per-GPU layout: mpc-net's broadcast (multi.rs:145-173) is an all-gather of every party's (sh, mac)
-            # lanes over RCCL; the sums and the MAC comparison of batch_open (spdz.rs:166-185) are one fused kernel
+            # party-per-GPU layout: the reference's batch_open round by round (share/spdz.rs:166-185) -- broadcast of the `sh`
+            # lanes (mpc-net/src/multi.rs:145-173 = one all-gather over RCCL), dx_t = mac_share * value - mac, broadcast of
+            # dx_t (atomic_broadcast when self.commit_opens), sum == 0.  MAC shares stay on their party.
             assert len(self.local) == 1
-            gathered = self.exchange(shares)                       # (P, 2, D, 4), rank order == party order
-            bad = ctx.fr_spdz_open(gathered.data_ptr(), self.P, D, out.data_ptr())
-            assert bad == 0, "SPDZ MAC check failed"
+            from . import parallel
+            vals = parallel.spdz_batch_open(ctx, shares[0], shares[1], self.mac_share, commit=self.commit_opens)
+            out.copy_(vals)
             return
         ctx.fr_vec_op(ADD, shares[0].data_ptr(), shares[2].data_ptr(), out=out.data_ptr(), n=D, mem=M)
         for p in range(2, self.P):

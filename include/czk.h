@@ -107,6 +107,30 @@ int czk_fr_beaver_combine(czk_ctx* ctx, const uint64_t* x, const uint64_t* y, co
  * *out_bad (host) receives the number of i with check[i] != 0 (the reference asserts it is 0). */
 int czk_fr_spdz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t n, uint64_t* out_value, uint64_t* out_bad);
 
+/* The same open round by round, as the reference runs it when every party is its own process (share/spdz.rs:166-185) --
+ * between the calls the caller moves the vectors with mpc-net's broadcast / atomic_broadcast (RCCL all-gather here):
+ *   round 1: every party broadcasts its `sh` lane;  values = czk_fr_lanes_sum(gathered sh lanes)
+ *   local  : dx_t = czk_fr_spdz_dx(values, own mac lane, own mac_share)      (mac_share: one Montgomery Fr, HOST memory)
+ *   round 2: atomic_broadcast(dx_t);  czk_fr_lanes_sum(gathered dx_t, out = NULL, &nonzero) must report 0.
+ * czk_fr_lanes_sum: out[i] = sum_{j<k} x[j][i] over k vectors of n Fr (x: k x n, DEVICE); out (device, may be NULL) receives
+ * the sums, *out_nonzero (host, may be NULL) the number of non-zero sums. */
+int czk_fr_lanes_sum(czk_ctx* ctx, const uint64_t* x, size_t k, size_t n, uint64_t* out, uint64_t* out_nonzero);
+int czk_fr_spdz_dx(czk_ctx* ctx, const uint64_t* value, const uint64_t* mac, const uint64_t* mac_share, uint64_t* out, size_t n);
+
+/* GSZ / Shamir shares (mpc-algebra/src/share/gsz20/mod.rs): party j of n holds p(w^j), w = the order-n root of
+ * MixedRadixEvaluationDomain::new(n_parties) (gsz20/mod.rs:98-105; algebra/poly/src/domain/mixed_radix.rs:57-107; root rule
+ * algebra/ff/src/fields/mod.rs:337-367 with SMALL_SUBGROUP_BASE = 3).  A GSZ share vector is ONE Fr lane for the NTT / MSM
+ * entry points (add / scale are lane-wise, gsz20/mod.rs:260-284).
+ * czk_share_domain_constants: out[0..4) size_inv, [4..8) group_gen, [8..12) group_gen_inv (Montgomery limbs); CZK_ERR_SIZE when
+ * n_parties is not 2^a or 3 * 2^a (the reference's `domain()` panics).
+ * czk_fr_gsz_open = the local part of batch_open (:286-300) -> open_degree_vec (:440-466) once all parties' values are on this
+ * GPU: shares: parties x n Fr (party-major, DEVICE); per element the size-n inverse DFT, p(0) -> out_value (n Fr, device);
+ * *out_bad (host) = number of elements whose interpolating polynomial exceeds its degree bound (the reference asserts
+ * p.degree() <= d): bound = degrees[i] (device u32 array) or `degree` when degrees is NULL. */
+int czk_share_domain_constants(czk_ctx* ctx, size_t parties, uint64_t* out12);
+int czk_fr_gsz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t n, const uint32_t* degrees, unsigned degree,
+                    uint64_t* out_value, uint64_t* out_bad);
+
 /* ---- callers either side of the NTT: constraint evaluation and division by (X - z) ------------------ */
 /* R1CS matrix (one of ConstraintMatrices::{a, b, c}, Vec<Vec<(F, usize)>>) in CSR form, pinned on the GPU once per
  * circuit: row_ptr m+1 offsets (row_ptr[0] = 0, row_ptr[m] = nnz), col_idx nnz variable indices into the full

@@ -647,6 +647,84 @@ int orc_max_threads(void) { return omp_get_max_threads(); }
 void orc_g1_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g1_chain_points((g1_aff_t *)out, n, (const g1_aff_t *)gen_aff); }
 void orc_g2_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g2_chain_points((g2_aff_t *)out, n, (const g2_aff_t *)gen_aff); }
 
+/* ------------------------------------------------------------------ GSZ / Shamir open (test infrastructure)
+ * algebra/ff/src/fields/utils.rs:3-14 -- k_adicity */
+static unsigned orc_k_adicity(size_t k, size_t n) {
+    unsigned r = 0;
+    while (n > 1) {
+        if (n % k == 0) { r++; n /= k; } else return r;
+    }
+    return r;
+}
+/* algebra/ff/src/fields/mod.rs:337-367 -- get_root_of_unity(n), LARGE_SUBGROUP branch in full (q = SMALL_SUBGROUP_BASE = 3,
+ * SMALL_SUBGROUP_BASE_ADICITY = 1: fr.rs:19-20) */
+int orc_fr_root_of_unity_mixed(size_t n, uint64_t *out) {
+    const size_t q = 3;
+    const unsigned small_subgroup_base_adicity = 1;
+    unsigned q_adicity = orc_k_adicity(q, n);
+    size_t q_part = 1;
+    for (unsigned i = 0; i < q_adicity; i++) q_part *= q;
+    unsigned two_adicity = orc_k_adicity(2, n);
+    size_t two_part = (size_t)1 << two_adicity;
+    if (n != two_part * q_part || two_adicity > FR_TWO_ADICITY || q_adicity > small_subgroup_base_adicity) return 1;   /* None */
+    fr_t omega;
+    memcpy(omega.l, fr_LARGE_ROOT, sizeof omega.l);
+    const uint64_t qq[1] = {q};
+    for (unsigned i = q_adicity; i < small_subgroup_base_adicity; i++) fr_pow(&omega, &omega, qq, 1);
+    for (unsigned i = two_adicity; i < FR_TWO_ADICITY; i++) fr_sqr(&omega, &omega);
+    memcpy(out, omega.l, 32);
+    return 0;
+}
+/* mpc-algebra/src/share/gsz20/mod.rs:440-466 -- open_degree_vec over every element of a batch (batch_open :286-300):
+ * shares: parties x n (party j's value of element i at shares[j][i]); ifft over MixedRadixEvaluationDomain::new(parties)
+ * (mixed_radix.rs:141-151: the inverse DFT with group_gen_inv, then * size_inv -- evaluated here as the plain O(n^2) sum, the
+ * same field values), `assert!(p.degree() <= d)` counted in *bad, result p.evaluate(0).  Returns 1 when no such domain exists. */
+int orc_gsz_open(const uint64_t *shares, size_t parties, size_t n, const uint32_t *degrees, unsigned degree, uint64_t *out, uint64_t *bad) {
+    fr_t w, winv, sz, size_inv;
+    if (orc_fr_root_of_unity_mixed(parties, (uint64_t *)w.l)) return 1;
+    fr_inv(&winv, &w);
+    fr_from_u64(&sz, parties);
+    fr_inv(&size_inv, &sz);
+    fr_t *coef = (fr_t *)malloc(parties * sizeof(fr_t));
+    *bad = 0;
+    for (size_t i = 0; i < n; i++) {
+        for (size_t k = 0; k < parties; k++) {
+            fr_t acc, wk, pw;
+            fr_zero(&acc);
+            uint64_t e[1] = {k};
+            fr_pow(&wk, &winv, e, 1);            /* (w^-1)^k */
+            fr_one(&pw);
+            for (size_t j = 0; j < parties; j++) {
+                fr_t t;
+                fr_mul(&t, (const fr_t *)(shares + 4 * (j * n + i)), &pw);
+                fr_add(&acc, &acc, &t);
+                fr_mul(&pw, &pw, &wk);
+            }
+            fr_mul(&coef[k], &acc, &size_inv);
+        }
+        /* DensePolynomial::from_coefficients_vec strips trailing zeros; degree() of the zero polynomial is 0 */
+        size_t deg = 0;
+        for (size_t k = parties; k-- > 0;) if (!fr_is_zero(&coef[k])) { deg = k; break; }
+        unsigned d = degrees ? degrees[i] : degree;
+        if (deg > d) (*bad)++;
+        memcpy(out + 4 * i, coef[0].l, 32);      /* evaluate(0): Horner at zero leaves the constant coefficient */
+    }
+    free(coef);
+    return 0;
+}
+/* share vector of a degree-`deg` polynomial with the given coefficients (deg + 1 Fr, Montgomery): out[j] = p(w^j), j < parties
+ * -- how tests make t-shares (d.fft of the coefficient vector, as DomainCoeff does for MixedRadixEvaluationDomain) */
+int orc_gsz_share(const uint64_t *coeffs, size_t n_coeffs, size_t parties, uint64_t *out) {
+    fr_t w, x;
+    if (orc_fr_root_of_unity_mixed(parties, (uint64_t *)w.l)) return 1;
+    fr_one(&x);
+    for (size_t j = 0; j < parties; j++) {
+        orc_fr_horner(coeffs, n_coeffs, (const uint64_t *)x.l, out + 4 * j);
+        fr_mul(&x, &x, &w);
+    }
+    return 0;
+}
+
 /* ---- callers either side of the NTT ("next" rows; test infrastructure like everything in this file) ------------- */
 /* evaluate_constraint over every row of one R1CS matrix (mpc-snarks/src/groth/r1cs_to_qap.rs:12-42, 70-77, 95-100):
  * sum += (coeff == 1) ? val : val * coeff, in term order. */

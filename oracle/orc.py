@@ -326,3 +326,38 @@ def groth16_local_par(log_d, N, a, b, c, wit, asg, h_q, l_q, a_q, b1_q, b2_q, in
     lib().orc_groth16_local_par(C.c_uint(log_d), C.c_size_t(N), C.c_size_t(lanes), _p(a), _p(b), _p(c), _p(wit), _p(asg), _p(h_q), _p(l_q),
                                 _p(a_q), _p(b1_q), _p(b2_q), _p(inf0), _p(inf_b), _p(out), C.c_int(threads))
     return out
+
+
+# ----------------------------------------------------------------------------- GSZ / Shamir shares (gsz20/mod.rs)
+def fr_root_of_unity_mixed(n):
+    """F::get_root_of_unity(n) for n = 2^a * 3^b (fields/mod.rs:337-367); None when no such subgroup exists."""
+    out = np.zeros(4, dtype=np.uint64)
+    fn = lib().orc_fr_root_of_unity_mixed
+    fn.restype = C.c_int
+    return None if fn(C.c_size_t(n), _p(out)) else out
+
+
+def gsz_open(shares, degree=0, degrees=None):
+    """batch_open of GSZ shares: shares (parties, n, 4) -> (values (n,4), number of degree-bound violations)."""
+    shares = _u64(shares)
+    parties, n = shares.shape[0], shares.shape[1]
+    out = np.zeros((n, 4), dtype=np.uint64)
+    bad = C.c_uint64(0)
+    dg = None if degrees is None else np.ascontiguousarray(degrees, dtype=np.uint32)
+    fn = lib().orc_gsz_open
+    fn.restype = C.c_int
+    rc = fn(_p(shares), C.c_size_t(parties), C.c_size_t(n), _p(dg) if dg is not None else C.c_void_p(0), C.c_uint(degree), _p(out), C.byref(bad))
+    if rc:
+        raise ValueError(f"no evaluation domain of size {parties}")
+    return out, bad.value
+
+
+def gsz_share(coeffs, parties):
+    """(parties, 4): p(w^j) for the polynomial with Montgomery coefficients `coeffs` (k, 4)."""
+    coeffs = _u64(coeffs).reshape(-1, 4)
+    out = np.zeros((parties, 4), dtype=np.uint64)
+    fn = lib().orc_gsz_share
+    fn.restype = C.c_int
+    if fn(_p(coeffs), C.c_size_t(coeffs.shape[0]), C.c_size_t(parties), _p(out)):
+        raise ValueError(f"no evaluation domain of size {parties}")
+    return out

@@ -1,0 +1,81 @@
+//! Raw bindings of `libczk_hip.so` -- GENERATED from include/czk.h by tools/gen_rust_sys.py; do not edit.
+//! One `extern "C"` declaration per C declaration; constants mirror the C enums.  Safe wrappers live in the `czk` crate.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_uint, c_void};
+
+#[repr(C)]
+pub struct czk_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct czk_bases {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct czk_r1cs_matrix {
+    _private: [u8; 0],
+}
+
+pub const CZK_OK: c_int = 0; // czk_status
+pub const CZK_ERR_SIZE: c_int = 1; // czk_status
+pub const CZK_ERR_HIP: c_int = 2; // czk_status
+pub const CZK_ERR_ARG: c_int = 3; // czk_status
+pub const CZK_ERR_NOMEM: c_int = 4; // czk_status
+pub const CZK_MEM_HOST: c_int = 0; // czk_mem
+pub const CZK_MEM_DEVICE: c_int = 1; // czk_mem
+pub const CZK_MEM_STABLE: c_int = 16; // czk_mem
+pub const CZK_FFT: c_int = 0; // czk_ntt_kind
+pub const CZK_IFFT: c_int = 1; // czk_ntt_kind
+pub const CZK_COSET_FFT: c_int = 2; // czk_ntt_kind
+pub const CZK_COSET_IFFT: c_int = 3; // czk_ntt_kind
+pub const CZK_SCALAR_CANONICAL: c_int = 0; // czk_scalar_form
+pub const CZK_SCALAR_MONTGOMERY: c_int = 1; // czk_scalar_form
+pub const CZK_G1: c_int = 1; // czk_group
+pub const CZK_G2: c_int = 2; // czk_group
+pub const CZK_OP_ADD: c_int = 0; // czk_binop
+pub const CZK_OP_SUB: c_int = 1; // czk_binop
+pub const CZK_OP_MUL: c_int = 2; // czk_binop
+
+#[link(name = "czk_hip")]
+extern "C" {
+    pub fn czk_ctx_create(out: *mut *mut czk_ctx, device: c_int, hip_stream: *mut c_void) -> c_int;
+    pub fn czk_ctx_destroy(ctx: *mut czk_ctx);
+    pub fn czk_ctx_sync(ctx: *mut czk_ctx) -> c_int;
+    pub fn czk_last_error(ctx: *const czk_ctx) -> *const c_char;
+    pub fn czk_version() -> *const c_char;
+    pub fn czk_ntt_fr(ctx: *mut czk_ctx, data: *mut u64, log_d: c_uint, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
+    pub fn czk_domain_constants(ctx: *mut czk_ctx, log_d: c_uint, out24: *mut u64) -> c_int;
+    pub fn czk_fr_vec_op(ctx: *mut czk_ctx, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
+    pub fn czk_fr_vec_scale(ctx: *mut czk_ctx, a: *const u64, k: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
+    pub fn czk_fr_beaver_combine(ctx: *mut czk_ctx, x: *const u64, y: *const u64, z: *const u64, sx: *const u64, oy: *const u64, add_open: c_int, out: *mut u64, n: usize, mem: c_int) -> c_int;
+    pub fn czk_fr_spdz_open(ctx: *mut czk_ctx, shares: *const u64, parties: usize, n: usize, out_value: *mut u64, out_bad: *mut u64) -> c_int;
+    pub fn czk_fr_lanes_sum(ctx: *mut czk_ctx, x: *const u64, k: usize, n: usize, out: *mut u64, out_nonzero: *mut u64) -> c_int;
+    pub fn czk_fr_spdz_dx(ctx: *mut czk_ctx, value: *const u64, mac: *const u64, mac_share: *const u64, out: *mut u64, n: usize) -> c_int;
+    pub fn czk_share_domain_constants(ctx: *mut czk_ctx, parties: usize, out12: *mut u64) -> c_int;
+    pub fn czk_fr_gsz_open(ctx: *mut czk_ctx, shares: *const u64, parties: usize, n: usize, degrees: *const u32, degree: c_uint, out_value: *mut u64, out_bad: *mut u64) -> c_int;
+    pub fn czk_r1cs_matrix_register(ctx: *mut czk_ctx, row_ptr: *const u64, col_idx: *const u32, coeff: *const u64, m: usize, nnz: usize, n_vars: usize, mem: c_int, out: *mut *mut czk_r1cs_matrix) -> c_int;
+    pub fn czk_r1cs_matrix_release(a: *mut czk_r1cs_matrix);
+    pub fn czk_r1cs_matvec(ctx: *mut czk_ctx, a: *const czk_r1cs_matrix, z: *const u64, z_stride: usize, lanes: usize, out: *mut u64, out_stride: usize, mem: c_int) -> c_int;
+    pub fn czk_poly_div_linear(ctx: *mut czk_ctx, coeffs: *const u64, n: usize, lanes: usize, z: *const u64, quotient: *mut u64, remainder: *mut u64, mem: c_int) -> c_int;
+    pub fn czk_fr_prefix_product(ctx: *mut czk_ctx, x: *const u64, n: usize, out: *mut u64, mem: c_int) -> c_int;
+    pub fn czk_fr_batch_inverse(ctx: *mut czk_ctx, v: *const u64, n: usize, coeff: *const u64, out: *mut u64, mem: c_int) -> c_int;
+    pub fn czk_fr_into_repr(ctx: *mut czk_ctx, a: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
+    pub fn czk_fr_from_repr(ctx: *mut czk_ctx, a: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
+    pub fn czk_bases_register(ctx: *mut czk_ctx, group: c_int, bases: *const u64, inf: *const u8, n: usize, mem: c_int, out: *mut *mut czk_bases) -> c_int;
+    pub fn czk_bases_release(b: *mut czk_bases);
+    pub fn czk_bases_len(b: *const czk_bases) -> usize;
+    pub fn czk_bases_layout(b: *const czk_bases, c: *mut c_uint, windows: *mut c_uint) -> c_int;
+    pub fn czk_msm(ctx: *mut czk_ctx, bases: *const czk_bases, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_msm_async(ctx: *mut czk_ctx, bases: *const czk_bases, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_msm_g1(ctx: *mut czk_ctx, bases_xy: *const u64, inf: *const u8, scalars: *const u64, n: usize, lanes: usize, scalar_form: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_msm_g2(ctx: *mut czk_ctx, bases_xy: *const u64, inf: *const u8, scalars: *const u64, n: usize, lanes: usize, scalar_form: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_jac_to_affine(ctx: *mut czk_ctx, group: c_int, jac: *const u64, n: usize, out_aff: *mut u64, out_inf: *mut u8) -> c_int;
+    pub fn czk_jac_add(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, b_jac: *const u64, out_jac: *mut u64) -> c_int;
+    pub fn czk_jac_add_mixed(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, b_aff: *const u64, b_inf: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_fixed_base_points(ctx: *mut czk_ctx, group: c_int, k: *const u64, n: usize, out: *mut u64, mem: c_int) -> c_int;
+    pub fn czk_witness_map_pre(ctx: *mut czk_ctx, a: *mut u64, a_len: usize, b: *mut u64, b_len: usize, log_d: c_uint, lanes: usize) -> c_int;
+    pub fn czk_witness_map_post(ctx: *mut czk_ctx, ab: *mut u64, c: *mut u64, c_len: usize, log_d: c_uint, lanes: usize) -> c_int;
+    pub fn czk_profile_enable(ctx: *mut czk_ctx, on: c_int) -> c_int;
+    pub fn czk_profile_reset(ctx: *mut czk_ctx) -> c_int;
+    pub fn czk_profile_read(ctx: *mut czk_ctx, kernel: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
+}

@@ -64,6 +64,38 @@ def test_cpp_host_mirror_runs_on_gpu():
     assert out.returncode == 0 and "host_demo OK" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.gpu
+def test_cpp_mirror_share_lift_matches_checker_for_king_and_other_party(orc):
+    """MpcField vectors mixing Public and Shared entries through the C++ mirror's EvaluationDomain (include/czk.hpp), as the king
+    and as a non-king party, against the checker: per SURVEY a18 the result must equal the reference transform of the lanes in
+    which every Public(x) was lifted to (king ? x : 0, mac_share * x), mac_share = 1 on the king and 0 elsewhere
+    (mpc-algebra/src/share/spdz.rs:30-37, 204-208)."""
+    import subprocess
+    import numpy as np
+    out = subprocess.run([_build_host_demo(), "dump-lift"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    raw = np.array([(0x9e3779b97f4a7c15 * (i + 1) % (1 << 64)) >> 7 for i in range(26)], dtype=np.uint64)
+    x = orc.fr_from_repr(np.stack([raw, np.zeros(26, np.uint64), np.zeros(26, np.uint64), np.zeros(26, np.uint64)], axis=1))
+    cases = out.stdout.split("case ")[1:]
+    assert len(cases) == 4
+    for block in cases:
+        head, *lines = block.strip().splitlines()
+        king = "king=1" in head
+        kind = orc.COSET_FFT if "coset_fft" in head else orc.IFFT
+        got = {"sh": [], "mac": []}
+        for ln in lines:
+            tag, *limbs = ln.split()
+            got[tag].append([int(v, 16) for v in limbs])
+        sh_in, mac_in = np.zeros((13, 4), np.uint64), np.zeros((13, 4), np.uint64)
+        for i in range(13):
+            if i % 3 != 1:
+                sh_in[i], mac_in[i] = x[i], x[13 + i]
+            elif king:
+                sh_in[i], mac_in[i] = x[i], x[i]
+        assert np.array_equal(np.array(got["sh"], dtype=np.uint64), orc.ntt_fr(sh_in, 4, kind, 13)), head
+        assert np.array_equal(np.array(got["mac"], dtype=np.uint64), orc.ntt_fr(mac_in, 4, kind, 13)), head
+
+
 def test_host_side_field_code_matches_checker(orc):
     """czk_jac_to_affine is host arithmetic from the same field.h the kernels use (Montgomery multiply, dedicated
     squaring, Fermat inverse, Fq2): check it against the checker's From<Projective> on random Jacobian points."""

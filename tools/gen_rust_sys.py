@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Generates rust/czk-sys/src/lib.rs -- the raw `extern "C"` block -- from include/czk.h, one declaration per C declaration, so
+the two cannot drift (tests/test_rust_shim.py re-runs the generator and compares).
+
+    python tools/gen_rust_sys.py [--check]
+"""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "czk.h")
+OUT = os.path.join(ROOT, "rust", "czk-sys", "src", "lib.rs")
+
+TYPES = {
+    "int": "c_int", "unsigned": "c_uint", "size_t": "usize", "void": "()", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8",
+    "char": "c_char", "double": "f64", "czk_ctx": "czk_ctx", "czk_bases": "czk_bases", "czk_r1cs_matrix": "czk_r1cs_matrix",
+}
+
+
+def rust_type(c: str) -> str:
+    c = c.strip()
+    stars = c.count("*")
+    base = c.replace("*", " ").split()
+    const = "const" in base
+    base = [b for b in base if b != "const"]
+    t = TYPES[" ".join(base)]
+    if stars == 0:
+        return t
+    if t == "()":
+        t = "c_void"
+    out = t
+    for level in range(stars):
+        # only the innermost pointer carries the C `const`
+        out = ("*const " if (const and level == 0) else "*mut ") + out
+    return out
+
+
+def parse_header(text: str):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    enums = []
+    for m in re.finditer(r"typedef enum\s*\{(.*?)\}\s*(\w+);", text, flags=re.S):
+        for item in m.group(1).split(","):
+            item = item.strip()
+            if item:
+                name, val = [v.strip() for v in item.split("=")]
+                enums.append((m.group(2), name, int(val)))
+    funcs = []
+    for m in re.finditer(r"^([\w\s\*]+?)\b(czk_\w+)\s*\(([^;{]*?)\)\s*;", text, flags=re.M | re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), " ".join(m.group(3).split())
+        if ret.startswith("typedef"):
+            continue
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                mm = re.match(r"(.*?)(\w+)$", a)
+                params.append((mm.group(2), mm.group(1).strip()))
+        funcs.append((name, ret, params))
+    return enums, funcs
+
+
+def generate() -> str:
+    enums, funcs = parse_header(open(HEADER).read())
+    out = ["//! Raw bindings of `libczk_hip.so` -- GENERATED from include/czk.h by tools/gen_rust_sys.py; do not edit.",
+           "//! One `extern \"C\"` declaration per C declaration; constants mirror the C enums.  Safe wrappers live in the `czk` crate.",
+           "#![allow(non_camel_case_types)]", "use std::os::raw::{c_char, c_int, c_uint, c_void};", ""]
+    for opaque in ("czk_ctx", "czk_bases", "czk_r1cs_matrix"):
+        out += ["#[repr(C)]", f"pub struct {opaque} {{", "    _private: [u8; 0],", "}"]
+    out.append("")
+    for ty, name, val in enums:
+        out.append(f"pub const {name}: c_int = {val}; // {ty}")
+    out += ["", "#[link(name = \"czk_hip\")]", "extern \"C\" {"]
+    for name, ret, params in funcs:
+        ps = ", ".join(f"{('type_' if p == 'type' else p)}: {rust_type(t)}" for p, t in params)
+        r = rust_type(ret)
+        out.append(f"    pub fn {name}({ps})" + ("" if r == "()" else f" -> {r}") + ";")
+    out.append("}")
+    return "\n".join(out) + "\n"
+
+
+if __name__ == "__main__":
+    src = generate()
+    if "--check" in sys.argv:
+        sys.exit(0 if open(OUT).read() == src else 1)
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    open(OUT, "w").write(src)
+    print("wrote", OUT, f"({src.count('pub fn ')} functions)")

@@ -16,8 +16,38 @@ static std::vector<Fr> fr_from_u64(const Context& ctx, const std::vector<uint64_
 static bool eq(const Fr& a, const Fr& b) { return memcmp(a.l, b.l, 32) == 0; }
 #define REQUIRE(c) do { if (!(c)) { printf("FAILED: %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
 
-int main() {
+// `host_demo.bin dump-lift`: prints the share lanes of a mixed Public / Shared vector after coset_fft and after ifft, once as
+// the king and once as another party, for tests/test_abi.py to compare with the CHECKER (oracle/) applied to the lifted lanes --
+// the C++ mirror is checked against the reference restatement, not against itself.
+static void print_fr(const char* tag, const Fr& f) { printf("%s %016lx %016lx %016lx %016lx\n", tag, (unsigned long)f.l[0], (unsigned long)f.l[1], (unsigned long)f.l[2], (unsigned long)f.l[3]); }
+static int dump_lift(const Context& ctx) {
+    std::vector<uint64_t> raw;
+    for (uint64_t i = 0; i < 26; i++) raw.push_back(0x9e3779b97f4a7c15ull * (i + 1) >> 7);
+    std::vector<Fr> x = fr_from_u64(ctx, raw);
+    for (int king = 1; king >= 0; king--) {
+        auto dom = Radix2EvaluationDomain::create(ctx, 13, king != 0);
+        for (int kind = 0; kind < 2; kind++) {
+            std::vector<MpcField> mv(13);
+            for (size_t i = 0; i < 13; i++) {
+                mv[i].shared = (i % 3) != 1;            // entries 1, 4, 7, 10 are Public
+                mv[i].sh = x[i];
+                mv[i].mac = x[13 + i];
+            }
+            if (kind == 0) dom->coset_fft_in_place(mv);
+            else dom->ifft_in_place(mv);
+            printf("case king=%d kind=%s\n", king, kind == 0 ? "coset_fft" : "ifft");
+            for (size_t i = 0; i < 16; i++) {
+                print_fr("sh", mv[i].sh);
+                print_fr("mac", mv[i].mac);
+            }
+        }
+    }
+    return 0;
+}
+
+int main(int argc, char** argv) {
     Context ctx(0);
+    if (argc > 1 && strcmp(argv[1], "dump-lift") == 0) return dump_lift(ctx);
     // EvaluationDomain::new -> None beyond 2^47 (radix2/mod.rs:61-63)
     REQUIRE(!Radix2EvaluationDomain::create(ctx, (size_t)1 << 48).has_value());
     auto dom = Radix2EvaluationDomain::create(ctx, 13);
