@@ -120,6 +120,21 @@ class Context:
                                   C.c_int(mem)))
         return data
 
+    def ntt_fr_mixed(self, data, size: int, kind: int, lanes: int = 1, in_len: int | None = None, mem: int = CZK_MEM_HOST):
+        """MixedRadixEvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place over a domain of `size` = 2^a or 3 * 2^a."""
+        if in_len is None:
+            in_len = size
+        if isinstance(data, np.ndarray):
+            assert data.dtype == np.uint64 and data.size == lanes * size * 4, "buffer must hold lanes x size x 4 u64"
+        self._ck(lib().czk_ntt_fr_mixed(self._h, _ptr(data), C.c_size_t(size), C.c_size_t(lanes), C.c_int(kind), C.c_size_t(in_len), C.c_int(mem)))
+        return data
+
+    def mixed_domain_constants(self, size: int):
+        out = np.zeros((6, 4), dtype=np.uint64)
+        self._ck(lib().czk_mixed_domain_constants(self._h, C.c_size_t(size), _ptr(out)))
+        names = ["size_inv", "group_gen", "group_gen_inv", "generator", "generator_inv", "vanishing_inv"]
+        return dict(zip(names, out))
+
     def domain_constants(self, log_d: int):
         out = np.zeros((6, 4), dtype=np.uint64)
         self._ck(lib().czk_domain_constants(self._h, C.c_uint(log_d), _ptr(out)))

@@ -224,6 +224,14 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
         if (d.cosetu_fwd) (void)hipFree(d.cosetu_fwd);
         if (d.cosetu_inv) (void)hipFree(d.cosetu_inv);
     }
+    for (auto& kv : ctx->mixed_domains) {
+        MixedDomain& d = kv.second;
+        if (d.tw_fwd) (void)hipFree(d.tw_fwd);
+        if (d.tw_inv) (void)hipFree(d.tw_inv);
+        if (d.coset_fwd) (void)hipFree(d.coset_fwd);
+        if (d.coset_inv) (void)hipFree(d.coset_inv);
+    }
+    if (ctx->mixed_scratch.p) (void)hipFree(ctx->mixed_scratch.p);
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
     if (ctx->poly_scratch.p) (void)hipFree(ctx->poly_scratch.p);
     if (ctx->open_bad) (void)hipFree(ctx->open_bad);

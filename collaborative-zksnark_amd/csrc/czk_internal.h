@@ -24,6 +24,14 @@ struct DomainTables {
     Fr size_inv, group_gen, group_gen_inv, generator, generator_inv, vanishing_inv;
 };
 
+// MixedRadixEvaluationDomain of size 3 * 2^k (ntt_mixed.hip)
+struct MixedDomain {
+    unsigned k = 0;
+    u64 *tw_fwd = nullptr, *tw_inv = nullptr;       // 3 * 2^k entries: w^j, w^-j
+    u64 *coset_fwd = nullptr, *coset_inv = nullptr; // g^j;  (1/3) g^-j
+    Fr size_inv, group_gen, group_gen_inv, generator, generator_inv, vanishing_inv, half_neg, c2_fwd, c2_inv, third;
+};
+
 template <class F>
 struct GT;
 template <>
@@ -84,6 +92,8 @@ struct czk_ctx {
     bool own_stream = false;
     std::string err;
     std::map<unsigned, czk::DomainTables> domains;
+    std::map<unsigned, czk::MixedDomain> mixed_domains;
+    czk::DeviceBuf mixed_scratch;   // de-interleaved lanes of the mixed-radix NTT
     czk::DeviceBuf ntt_scratch;   // one lane-batch for the out-of-place NTT passes
     czk::DeviceBuf poly_scratch;  // segment sums of czk_poly_div_linear (poly.hip)
     czk::DeviceBuf share_tab;     // size_inv * w^(-jk) table of czk_fr_gsz_open (share.hip)
@@ -156,6 +166,9 @@ struct ProfScope {
 
 // implemented in ntt.hip
 int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len);
+// implemented in ntt_mixed.hip
+int get_mixed_domain(czk_ctx* ctx, unsigned k, MixedDomain** out);
+int ntt_mixed_device(czk_ctx* ctx, u64* data, unsigned k, size_t lanes, int kind, size_t in_len);
 // implemented in msm.hip
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
                int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable);

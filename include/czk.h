@@ -87,6 +87,15 @@ int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int k
  * [20..24) (generator^D - 1)^-1 used by divide_by_vanishing_poly_on_coset_in_place (domain/mod.rs:184-191). */
 int czk_domain_constants(czk_ctx* ctx, unsigned log_d, uint64_t* out24);
 
+/* MixedRadixEvaluationDomain<Fr>::{fft, ifft, coset_fft, coset_ifft}_in_place (algebra/poly/src/domain/mixed_radix.rs:130-157,
+ * 286-404): domains of `size` = 2^a or 3 * 2^a (SMALL_SUBGROUP_BASE = 3 with adicity 1, fr.rs:19-20) -- the Plonk prover's wire
+ * domain has 3 * n_gates elements (mpc-plonk/src/relations/flat.rs:282-300).  Same conventions as czk_ntt_fr (data: lanes x size
+ * x 4 u64, natural order in and out, in_len <= size, tail taken as zero); root = get_root_of_unity(size)
+ * (algebra/ff/src/fields/mod.rs:337-367).  CZK_ERR_SIZE when no such domain exists.  A power-of-two size is the radix-2 transform.
+ * czk_mixed_domain_constants: the six constants of czk_domain_constants for MixedRadixEvaluationDomain::new(size). */
+int czk_ntt_fr_mixed(czk_ctx* ctx, uint64_t* data, size_t size, size_t lanes, int kind, size_t in_len, int mem);
+int czk_mixed_domain_constants(czk_ctx* ctx, size_t size, uint64_t* out24);
+
 /* ---- element-wise Fr vector ops (the share-local pointwise steps of witness_map) ------------------ */
 /* out[i] = a[i] op b[i], n elements of 4 u64; out may alias a or b.  r1cs_to_qap.rs:92 (plain product), :105-107 (sub). */
 typedef enum { CZK_OP_ADD = 0, CZK_OP_SUB = 1, CZK_OP_MUL = 2 } czk_binop;

@@ -647,6 +647,124 @@ int orc_max_threads(void) { return omp_get_max_threads(); }
 void orc_g1_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g1_chain_points((g1_aff_t *)out, n, (const g1_aff_t *)gen_aff); }
 void orc_g2_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g2_chain_points((g2_aff_t *)out, n, (const g2_aff_t *)gen_aff); }
 
+/* ------------------------------------------------------------------ MixedRadixEvaluationDomain<Fr> (size 2^a * 3^b, b <= 1)
+ * algebra/poly/src/domain/mixed_radix.rs:232-262 -- mixed_radix_fft_permute */
+static size_t orc_mixed_permute(unsigned two_adicity, unsigned q_adicity, size_t q, size_t n, size_t i) {
+    size_t res = 0, shift = n;
+    for (unsigned t = 0; t < two_adicity; t++) { shift /= 2; res += (i % 2) * shift; i /= 2; }
+    for (unsigned t = 0; t < q_adicity; t++) { shift /= q; res += (i % q) * shift; i /= q; }
+    return res;
+}
+static unsigned orc_k_adicity_fwd(size_t k, size_t n) {
+    unsigned r = 0;
+    while (n > 1) { if (n % k == 0) { r++; n /= k; } else return r; }
+    return r;
+}
+int orc_fr_root_of_unity_mixed(size_t n, uint64_t *out);
+/* mixed_radix.rs:286-404 -- serial_mixed_radix_fft (decimation in time: index permutation, the radix-q merge passes, then the
+ * radix-2 merge passes), q = SMALL_SUBGROUP_BASE = 3 */
+static void orc_serial_mixed_radix_fft(fr_t *a, size_t n, const fr_t *omega, unsigned two_adicity) {
+    const size_t q = 3;
+    unsigned q_adicity = orc_k_adicity_fwd(q, n);
+    size_t m = 1;
+    if (q_adicity > 0) {
+        unsigned char *seen = (unsigned char *)calloc(n, 1);
+        for (size_t k = 0; k < n; k++) {
+            size_t i = k;
+            fr_t a_i = a[i];
+            while (!seen[i]) {
+                size_t dest = orc_mixed_permute(two_adicity, q_adicity, q, n, i);
+                fr_t a_dest = a[dest];
+                a[dest] = a_i;
+                seen[i] = 1;
+                a_i = a_dest;
+                i = dest;
+            }
+        }
+        free(seen);
+        fr_t omega_q, qth_roots[3], terms[2];
+        uint64_t e[1] = {(uint64_t)(n / q)};
+        fr_pow(&omega_q, omega, e, 1);
+        fr_one(&qth_roots[0]);
+        for (size_t i = 1; i < q; i++) fr_mul(&qth_roots[i], &qth_roots[i - 1], &omega_q);
+        for (unsigned pass = 0; pass < q_adicity; pass++) {
+            fr_t w_m;
+            uint64_t em[1] = {(uint64_t)(n / (q * m))};
+            fr_pow(&w_m, omega, em, 1);
+            for (size_t k = 0; k < n; k += q * m) {
+                fr_t w_j;
+                fr_one(&w_j);
+                for (size_t j = 0; j < m; j++) {
+                    fr_t base_term = a[k + j], w_j_i = w_j;
+                    for (size_t i = 1; i < q; i++) {
+                        terms[i - 1] = a[k + j + i * m];
+                        fr_mul(&terms[i - 1], &terms[i - 1], &w_j_i);
+                        fr_mul(&w_j_i, &w_j_i, &w_j);
+                    }
+                    for (size_t i = 0; i < q; i++) {
+                        a[k + j + i * m] = base_term;
+                        for (size_t l = 1; l < q; l++) {
+                            fr_t tmp;
+                            fr_mul(&tmp, &terms[l - 1], &qth_roots[(i * l) % q]);
+                            fr_add(&a[k + j + i * m], &a[k + j + i * m], &tmp);
+                        }
+                    }
+                    fr_mul(&w_j, &w_j, &w_m);
+                }
+            }
+            m *= q;
+        }
+    } else {
+        for (size_t k = 0; k < n; k++) {
+            size_t rk = 0, t = k;
+            for (unsigned b = 0; b < two_adicity; b++) { rk = (rk << 1) | (t & 1); t >>= 1; }
+            if (k < rk) { fr_t tmp = a[k]; a[k] = a[rk]; a[rk] = tmp; }
+        }
+    }
+    for (unsigned pass = 0; pass < two_adicity; pass++) {
+        fr_t w_m;
+        uint64_t em[1] = {(uint64_t)(n / (2 * m))};
+        fr_pow(&w_m, omega, em, 1);
+        for (size_t k = 0; k < n; k += 2 * m) {
+            fr_t w;
+            fr_one(&w);
+            for (size_t j = 0; j < m; j++) {
+                fr_t t;
+                fr_mul(&t, &a[(k + m) + j], &w);
+                fr_sub(&a[(k + m) + j], &a[k + j], &t);
+                fr_add(&a[k + j], &a[k + j], &t);
+                fr_mul(&w, &w, &w_m);
+            }
+        }
+        m *= 2;
+    }
+}
+/* {fft, ifft, coset_fft, coset_ifft}_in_place of MixedRadixEvaluationDomain (mixed_radix.rs:130-157; coset_fft is the trait
+ * default domain/mod.rs:139-142) on a buffer of `size` = 2^a or 3 * 2^a elements whose first in_len entries are the caller's
+ * vector.  Returns 1 when no such domain exists. */
+int orc_ntt_fr_mixed(uint64_t *data, size_t size, int kind, size_t in_len) {
+    fr_t omega, omega_inv, sz, size_inv, gen, gen_inv, one;
+    if (in_len > size || orc_fr_root_of_unity_mixed(size, (uint64_t *)omega.l)) return 1;
+    unsigned two_adicity = orc_k_adicity_fwd(2, size);
+    fr_inv(&omega_inv, &omega);
+    fr_from_u64(&sz, size);
+    fr_inv(&size_inv, &sz);
+    memcpy(gen.l, fr_GENERATOR, sizeof gen.l);
+    fr_inv(&gen_inv, &gen);
+    fr_one(&one);
+    fr_t *x = (fr_t *)data;
+    if (kind == ORC_COSET_FFT) orc_distribute_powers(x, in_len, &gen, &one);
+    for (size_t i = in_len; i < size; i++) fr_zero(&x[i]);
+    if (kind == ORC_FFT || kind == ORC_COSET_FFT) {
+        orc_serial_mixed_radix_fft(x, size, &omega, two_adicity);
+    } else {
+        orc_serial_mixed_radix_fft(x, size, &omega_inv, two_adicity);
+        for (size_t i = 0; i < size; i++) fr_mul(&x[i], &x[i], &size_inv);
+        if (kind == ORC_COSET_IFFT) orc_distribute_powers(x, size, &gen_inv, &one);
+    }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ GSZ / Shamir open (test infrastructure)
  * algebra/ff/src/fields/utils.rs:3-14 -- k_adicity */
 static unsigned orc_k_adicity(size_t k, size_t n) {

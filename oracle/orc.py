@@ -361,3 +361,17 @@ def gsz_share(coeffs, parties):
     if fn(_p(coeffs), C.c_size_t(coeffs.shape[0]), C.c_size_t(parties), _p(out)):
         raise ValueError(f"no evaluation domain of size {parties}")
     return out
+
+
+def ntt_fr_mixed(data, size, kind, in_len=None):
+    """MixedRadixEvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place over a domain of `size` = 2^a or 3 * 2^a."""
+    data = _u64(data).reshape(-1, 4)
+    if in_len is None:
+        in_len = data.shape[0]
+    buf = np.zeros((size, 4), dtype=np.uint64)
+    buf[:in_len] = data[:in_len]
+    fn = lib().orc_ntt_fr_mixed
+    fn.restype = C.c_int
+    if fn(_p(buf), C.c_size_t(size), C.c_int(kind), C.c_size_t(in_len)):
+        raise ValueError("no mixed-radix domain of that size (or in_len > size)")
+    return buf

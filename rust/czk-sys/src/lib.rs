@@ -45,6 +45,8 @@ extern "C" {
     pub fn czk_version() -> *const c_char;
     pub fn czk_ntt_fr(ctx: *mut czk_ctx, data: *mut u64, log_d: c_uint, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
     pub fn czk_domain_constants(ctx: *mut czk_ctx, log_d: c_uint, out24: *mut u64) -> c_int;
+    pub fn czk_ntt_fr_mixed(ctx: *mut czk_ctx, data: *mut u64, size: usize, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
+    pub fn czk_mixed_domain_constants(ctx: *mut czk_ctx, size: usize, out24: *mut u64) -> c_int;
     pub fn czk_fr_vec_op(ctx: *mut czk_ctx, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
     pub fn czk_fr_vec_scale(ctx: *mut czk_ctx, a: *const u64, k: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
     pub fn czk_fr_beaver_combine(ctx: *mut czk_ctx, x: *const u64, y: *const u64, z: *const u64, sx: *const u64, oy: *const u64, add_open: c_int, out: *mut u64, n: usize, mem: c_int) -> c_int;

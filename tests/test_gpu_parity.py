@@ -682,3 +682,47 @@ def test_msm_over_full_buckets(ctx, czk, orc, g, n):
         assert _same_point(ctx, orc, g, out[ln], orc.scalar_mul(g, gen, False, ints_to_limbs([e], 4)[0])), (g, ln)
     assert dt < 1.0, f"over-full bucket path took {dt:.2f} s"    # one thread per bucket would need seconds here
     b.release()
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 8, 10, 11, 13, 16])
+def test_mixed_radix_ntt_all_kinds_bit_exact(ctx, czk, orc, k):
+    """MixedRadixEvaluationDomain (size 3 * 2^k) transforms against the checker's restatement of serial_mixed_radix_fft
+    (mixed_radix.rs:286-404): every output limb, all four kinds, 2 lanes, ragged prefix with a garbage tail."""
+    size = 3 << k
+    kc = ctx.mixed_domain_constants(size)
+    assert np.array_equal(kc["group_gen"], orc.fr_root_of_unity_mixed(size))
+    for in_len in sorted({size, max(1, size - 5), (size + 1) // 2}):
+        lanes = 2
+        x = orc.fr_from_repr(rand_fr_canonical(300 + k, lanes * in_len)).reshape(lanes, in_len, 4)
+        for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+            buf = np.full((lanes, size, 4), 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+            buf[:, :in_len] = x
+            ctx.ntt_fr_mixed(buf, size, kind, lanes=lanes, in_len=in_len)
+            for ln in range(lanes):
+                assert np.array_equal(buf[ln], orc.ntt_fr_mixed(x[ln], size, kind, in_len)), (k, in_len, kind, ln)
+
+
+def test_mixed_radix_ntt_plonk_wire_domain_and_errors(ctx, czk, orc):
+    """The wire domain of BASELINE configs[2] (Plonk, 2^18 gates: 3 * 2^18 points), one GSZ lane, device memory: bit-exact
+    against the checker for the forward transforms, exact round trips; sizes without a domain are refused."""
+    import torch
+    import czk_amd
+    size = 3 << 18
+    x = orc.fr_from_repr(rand_fr_canonical(31337, size))
+    for fwd, inv in ((czk.CZK_FFT, czk.CZK_IFFT), (czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT)):
+        t = torch.from_numpy(x.view(np.int64)).cuda()
+        ctx.ntt_fr_mixed(t.data_ptr(), size, fwd, mem=czk.CZK_MEM_DEVICE)
+        ctx.sync()
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), orc.ntt_fr_mixed(x, size, fwd))
+        ctx.ntt_fr_mixed(t.data_ptr(), size, inv, mem=czk.CZK_MEM_DEVICE)
+        ctx.sync()
+        assert np.array_equal(t.cpu().numpy().view(np.uint64), x)
+    for bad in (5, 9, 3 * 5, 3 * 3 * 4):
+        with pytest.raises(czk_amd.CzkError) as e:
+            ctx.ntt_fr_mixed(np.zeros((bad, 4), dtype=np.uint64), bad, czk.CZK_FFT)
+        assert e.value.code == 1
+    # a power-of-two size is the radix-2 domain
+    y = orc.fr_from_repr(rand_fr_canonical(5, 64))
+    buf = y.copy()
+    ctx.ntt_fr_mixed(buf, 64, czk.CZK_COSET_FFT)
+    assert np.array_equal(buf, orc.ntt_fr(y, 6, orc.COSET_FFT))
