@@ -239,6 +239,143 @@ def cpu_baseline(log_n_sample: int, log_n_full: int, parties: int, all_cores_log
     return out
 
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# Plonk / Marlin workloads (BASELINE configs[2] / configs[3]): collaborative-zksnark_amd/polyvm.py drives the library
+# ---------------------------------------------------------------------------------------------------------------
+def _ec_add(F, p, q):
+    if p is None:
+        return q
+    if q is None:
+        return p
+    if p[0] == q[0]:
+        if F.add(p[1], q[1]) == F.zero:
+            return None
+        lam = F.mul(F.mul(F.add(F.add(p[0], p[0]), p[0]), p[0]), F.inv(F.add(p[1], p[1])))
+    else:
+        lam = F.mul(F.sub(q[1], p[1]), F.inv(F.sub(q[0], p[0])))
+    x = F.sub(F.sub(F.mul(lam, lam), p[0]), q[0])
+    return (x, F.sub(F.mul(lam, F.sub(p[0], x)), p[1]))
+
+
+def verify_openings(czk, ctx, B, out) -> dict:
+    """Every KZG opening against its commitment, on the host, with the KNOWN tau of the synthetic SRS (polyvm.GpuBackend):
+    C - [v] G == [tau - x] W in affine big-integer arithmetic.  Marlin's batched opening at beta is checked against the folded
+    commitment sum_j ch^j C_j."""
+    t0 = time.perf_counter()
+    q_rinv = pow(1 << 384, -1, Q_MOD)
+    r_rinv = pow(1 << 256, -1, R_MOD)
+
+    def pt(aff, inf):
+        if inf:
+            return None
+        v = [sum(int(aff[6 * k + j]) << (64 * j) for j in range(6)) * q_rinv % Q_MOD for k in range(2)]
+        return (v[0], v[1])
+
+    def fr(limbs):
+        return sum(int(limbs[j]) << (64 * j) for j in range(4)) * r_rinv % R_MOD
+    g = pt(ctx.fixed_base_points(czk.CZK_G1, np.array([[1, 0, 0, 0]], dtype=np.uint64))[0], 0)
+    neg = lambda p: None if p is None else (p[0], (-p[1]) % Q_MOD)
+    checked = 0
+
+    def check(cmts, opening):
+        nonlocal checked
+        lanes = opening["value"].shape[0]
+        for ln in range(lanes):
+            C = cmts(ln)
+            v = fr(opening["value"][ln])
+            W = pt(opening["proof"][0][ln], opening["proof"][1][ln])
+            lhs = _ec_add(_Fq, C, neg(_ec_scalar_mul(_Fq, g, v)))
+            rhs = _ec_scalar_mul(_Fq, W, (B.tau - opening["point"]) % R_MOD) if W is not None else None
+            assert lhs == rhs, "KZG opening does not verify"
+            checked += 1
+    for k, o in out.items():
+        if isinstance(o, dict) and o.get("of"):
+            c = out[o["of"] + "_cmt"]
+            check(lambda ln: pt(c[0][ln], c[1][ln]), o)
+    if "open_beta" in out:
+        labels = ["w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1"]
+        ch = out["open_beta"]["fold"]
+
+        def folded(ln):
+            acc, c = None, 1
+            for lb in labels:
+                cm = out[lb + "_cmt"]
+                l2 = ln if cm[0].shape[0] > 1 else 0
+                acc = _ec_add(_Fq, acc, _ec_scalar_mul(_Fq, pt(cm[0][l2], cm[1][l2]), c))
+                c = c * ch % R_MOD
+            return acc
+        check(folded, out["open_beta"])
+    return {"results_checked": True, "results_checked_points": checked, "results_check_s": round(time.perf_counter() - t0, 2),
+            "results_check": "every KZG opening verified on the host against its commitment with the synthetic SRS's known tau"}
+
+
+def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
+    import torch
+    from czk_amd import polyvm
+    if args.layout != "replica":
+        raise SystemExit("--workload plonk / marlin: replica layout only (all parties' lanes on each GPU; opens are lane-local)")
+    plonk = args.workload == "plonk"
+    if plonk:
+        lanes, lift = args.parties, None                                   # GSZ: one lane per party, public addends on every lane
+        max_deg = polyvm.plonk_max_degree(n)
+        prove = lambda B: polyvm.plonk_prove(B, n)
+        scheme, what = "GSZ", f"mpc-plonk Prover::prove, {n} gates (wire domain 3 x {size_txt}, mixed radix)"
+    else:
+        lanes, lift = 2 * args.parties, tuple([1, 1] + [0] * (2 * args.parties - 2))   # SPDZ: sh + mac per party; public addends on the king's lanes
+        max_deg = polyvm.marlin_max_degree(n)
+        prove = lambda B: polyvm.marlin_prove(B, n)
+        scheme, what = "SPDZ", f"Marlin AHP rounds + commitments + batched openings, {n} constraints"
+    t0 = time.time()
+    B = polyvm.GpuBackend(czk, ctx, lanes, max_deg, lift=lift)
+    setup_s = time.time() - t0
+
+    def barrier():
+        parallel.barrier(torch.cuda.synchronize)
+    t0 = time.perf_counter()
+    prove(B)
+    ctx.sync()
+    first_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(max(0, args.warmup - 1)):
+        prove(B)
+    B.msm_count = B.ntt_count = B.msm_points = 0
+    ctx.profile_reset()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = prove(B)
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
+    checked = {"results_checked": False} if args.no_result_check else verify_openings(czk, ctx, B, out)
+    acc_ms, acc_n = ctx.profile_read("msm_accumulate_g1")
+    breakdown = {k: ctx.profile_read(k)[0] / max(1, args.steps) for k in ("ntt_pass", "ntt_mixed", "msm_sort", "msm_accumulate_g1", "msm_reduce")}
+    pts = B.msm_points / max(1, args.steps)                       # (point, lane) pairs per proof
+    alg_bytes = pts * 32 + (B.msm_points / max(1, B.msm_count) * 96) * (B.msm_count / lanes / max(1, args.steps))   # scalars per lane + bases once per MSM
+    achieved = alg_bytes * args.steps / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
+    res = {
+        "metric": f"collaborative {'Plonk' if plonk else 'Marlin'} proofs/sec (BLS12-377, {size_txt} constraints, {scheme} N={args.parties})",
+        "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "ranks_seen_by_backend": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "first_proof_ms": first_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic", **checked,
+        "config": {"workload": f"{what}; {scheme} {args.parties} parties as {lanes} share lanes on one GPU; synthetic circuit / index and SRS, fixed "
+                               "Fiat-Shamir challenges (collaborative-zksnark_amd/polyvm.py)",
+                   "constraints": n, "parties": args.parties, "share_lanes": lanes, "layout": "replica",
+                   "ntt_lanes_per_proof": B.ntt_count / max(1, args.steps), "msms_per_proof": B.msm_count / max(1, args.steps),
+                   "msm_point_lanes_per_proof": pts},
+        "roofline": {"bound": "hbm", "kernel": "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
+                     "note": "integer-VALU bound; MSMs here are blocking single calls (one per commitment / opening), not the pipelined Groth16 sequence"},
+        "breakdown_ms_per_step": breakdown, "setup_srs_s": setup_s,
+    }
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
 # ---------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -252,6 +389,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-result-check", action="store_true")
     ap.add_argument("--no-seam-report", action="store_true")
+    ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
+                    help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "
+                         "--parties 3 --log-n 18); marlin: AHP rounds + commitments + batched openings, SPDZ lanes (configs[3]: --log-n 20)")
     ap.add_argument("--layout", choices=("replica", "party"), default="replica",
                     help="replica (default, BASELINE configs[1]): every GPU proves independently with all parties' lanes on it; "
                          "party: ONE proof, party p's lanes on rank p (--gpus == --parties), opens all-gathered over RCCL")
@@ -302,6 +442,8 @@ def main():
     torch.cuda.set_stream(tstream)
     ctx = czk.Context(device, tstream.cuda_stream)
     assert tstream.cuda_stream != 0
+    if args.workload != "groth16":
+        return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)
     if party_layout:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank])
         prover.commit_opens = args.commit_opens

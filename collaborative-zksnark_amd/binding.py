@@ -158,6 +158,15 @@ class Context:
         self._ck(lib().czk_fr_vec_scale(self._h, _ptr(a), _ptr(k), _ptr(out), C.c_size_t(n), C.c_int(mem)))
         return out
 
+    def fr_powers(self, g, n: int, c=None, out=None, mem=CZK_MEM_HOST):
+        """out[i] = c * g^i (g, c: (4,) uint64 Montgomery)."""
+        g = np.ascontiguousarray(g, np.uint64).reshape(4)
+        cc = None if c is None else np.ascontiguousarray(c, np.uint64).reshape(4)
+        if mem == CZK_MEM_HOST:
+            out = np.zeros((n, 4), dtype=np.uint64)
+        self._ck(lib().czk_fr_powers(self._h, _ptr(g), _ptr(cc), C.c_size_t(n), _ptr(out), C.c_int(mem)))
+        return out
+
     def fr_beaver_combine(self, x, y, z, sx, oy, add_open, out=None, n=None, mem=CZK_MEM_HOST):
         if mem == CZK_MEM_HOST:
             x, y, z, sx, oy = (np.ascontiguousarray(v, np.uint64) for v in (x, y, z, sx, oy))

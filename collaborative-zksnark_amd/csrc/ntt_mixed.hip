@@ -216,3 +216,15 @@ extern "C" int czk_mixed_domain_constants(czk_ctx* ctx, size_t size, uint64_t* o
         for (int i = 0; i < 4; i++) out24[4 * j + i] = (u64)v[j]->l[2 * i] | ((u64)v[j]->l[2 * i + 1] << 32);
     return CZK_OK;
 }
+
+extern "C" int czk_fr_powers(czk_ctx* ctx, const uint64_t* g, const uint64_t* c, size_t n, uint64_t* out, int mem) {
+    if (!ctx || !g || (n && !out)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null powers argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
+    if (!n) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    Staged so{ctx};
+    CZK_TRY(so.to_device(mem == CZK_MEM_HOST ? nullptr : out, n * 32, mem));
+    hipLaunchKernelGGL(k_pow_table_m, dim3((unsigned)(((n + 63) / 64 + 127) / 128)), dim3(128), 0, ctx->stream, (u64*)so.dev, n, host_fr(g), c ? host_fr(c) : Fr::one());
+    CZK_HIP(ctx, hipGetLastError());
+    return so.to_host(out, n * 32);
+}

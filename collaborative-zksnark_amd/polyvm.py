@@ -1,0 +1,523 @@
+"""Backend-neutral restatement of the LOCAL compute of the reference's polynomial-IOP provers (Plonk, Marlin) plus the GPU
+backend that runs it through the C ABI.
+
+The provers are written once against a small polynomial "machine" (`Backend`): arrays of Fr lanes with NTTs over radix-2 /
+mixed-radix domains, element-wise arithmetic, multiplication by power tables, division by (X - z), running products, batch
+inversion and KZG commitments (MSMs over a registered `powers_of_g`).  `GpuBackend` below is the product path; tests/ supplies a
+second backend on top of the CPU checker and compares every commitment and evaluation the two produce.
+
+What is restated: the call sequence and sizes of
+    mpc-plonk/src/lib.rs:110-258 (prove_unit_product, prove_wiring), :259-340 (prove_public, prove_gates), :343-448 (eval, commit,
+    prove);  marlin/src/ahp/prover.rs:300-704 (three AHP rounds), marlin/src/lib.rs:176-318 (commitments and openings)
+What is NOT: protocol logic.  Fiat-Shamir challenges are fixed field elements (the hashing of commitments is host-side glue),
+blinding factors are fixed, and a product of two shared vectors is the lane-wise product (for the reference's king_share
+stand-in sharing every party holds the value itself, mpc-algebra/src/share/gsz20/mod.rs:190-213; the degree-reduction exchange
+of `mult` is an open, covered by parallel.gsz_batch_open).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+R_MOD = 8444461749428370424248824938781546531375899335154063827935233455917409239041
+FFT, IFFT, COSET_FFT, COSET_IFFT = 0, 1, 2, 3
+
+
+def mont(v: int) -> np.ndarray:
+    """canonical integer -> (4,) uint64 Montgomery limbs"""
+    x = v % R_MOD * ((1 << 256) % R_MOD) % R_MOD
+    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def unmont(limbs) -> int:
+    x = sum(int(limbs[i]) << (64 * i) for i in range(4))
+    return x * pow(1 << 256, -1, R_MOD) % R_MOD
+
+
+def next_pow2(n: int) -> int:
+    return 1 << max(0, (n - 1).bit_length())
+
+
+def challenge(tag: str) -> int:
+    """A fixed, documented stand-in for a Fiat-Shamir challenge: SHA-256(tag) mod r."""
+    import hashlib
+    return int.from_bytes(hashlib.sha256(tag.encode()).digest(), "little") % R_MOD
+
+
+class Backend:
+    """Arrays are (lanes, n, 4) Fr limbs (Montgomery).  Public data has lanes == 1.  Public * shared scales every lane; public
+    +- shared is the reference's `shift`: the public operand is added on the lanes listed in `lift` only (GSZ: every lane, a
+    share is an evaluation; SPDZ: the king's sh and mac lanes, share/spdz.rs:204-208 with mac_share() in {0, 1})."""
+    lanes: int
+    lift: tuple   # per lane: 1 = this lane takes public addends
+
+    def zeros(self, lanes: int, n: int): raise NotImplementedError
+    def lanes_of(self, a) -> int: raise NotImplementedError
+    def lane_stack(self, parts): raise NotImplementedError           # list of (1, n, 4) arrays -> (len, n, 4)
+
+    def lifted(self, a_public):
+        """(lanes, n, 4): the public array on the lifting lanes, zero elsewhere."""
+        n = self.length(a_public)
+        z = self.zeros(1, n)
+        return self.lane_stack([a_public if w else z for w in self.lift])
+
+    def _addends(self, a, b):
+        la, lb = self.lanes_of(a), self.lanes_of(b)
+        if la == lb:
+            return a, b
+        return (self.lifted(a), b) if la == 1 else (a, self.lifted(b))
+
+    # --- storage
+    def upload(self, a: np.ndarray): raise NotImplementedError
+    def download(self, a) -> np.ndarray: raise NotImplementedError
+    def length(self, a) -> int: raise NotImplementedError
+    def resized(self, a, n: int): raise NotImplementedError          # copy, zero-padded or truncated to n
+    def drop_first(self, a, k: int): raise NotImplementedError       # coefficients k.. (copy)
+    # --- transforms and arithmetic
+    def ntt(self, a, size: int, kind: int): raise NotImplementedError   # new array of `size` elements
+    def add(self, a, b): raise NotImplementedError                   # same lane count (use plus / minus for public operands)
+    def sub(self, a, b): raise NotImplementedError
+    def mul(self, a, b): raise NotImplementedError                   # broadcasts a public operand over the lanes
+    def scale(self, a, k: int): raise NotImplementedError            # k: canonical integer
+    def powers(self, g: int, n: int): raise NotImplementedError      # public (1, n, 4): g^i
+    def div_linear(self, a, z: int): raise NotImplementedError       # (quotient array, remainder (lanes, 4) numpy)
+    def prefix_product(self, a): raise NotImplementedError
+    def inverse(self, a): raise NotImplementedError                  # element-wise, zeros stay zero
+    def commit(self, a): raise NotImplementedError                   # -> ((lanes, 12) affine limbs, (lanes,) infinity flags) numpy
+    def random(self, seed: int, n: int): raise NotImplementedError   # public (1, n, 4): rand_fr_canonical(seed, n) in Montgomery form
+    def root_of_unity(self, size: int) -> int: raise NotImplementedError   # get_root_of_unity(size), canonical integer
+
+    # --- derived (shared by every backend) ----------------------------------------------------------------------
+    def plus(self, a, b):
+        return self.add(*self._addends(a, b))
+
+    def minus(self, a, b):
+        return self.sub(*self._addends(a, b))
+
+    def const(self, k: int, n: int):
+        """public array of n copies of k"""
+        return self.upload(np.tile(mont(k), (n, 1)))
+
+    def add_const(self, a, k: int):
+        return self.plus(a, self.const(k, self.length(a)))
+
+    def poly_mul(self, a, b):
+        """`&DensePolynomial * &DensePolynomial` (algebra/poly/src/polynomial/univariate/dense.rs): both operands are
+        evaluated over GeneralEvaluationDomain::new(len a + len b - 1) -- always the radix-2 domain (domain/general.rs:168-181)
+        -- multiplied point-wise and interpolated."""
+        n = self.length(a) + self.length(b) - 1
+        size = next_pow2(n)
+        return self.resized(self.ntt(self.mul(self.ntt(a, size, FFT), self.ntt(b, size, FFT)), size, IFFT), n)
+
+    def div_vanishing(self, a, n: int):
+        """`divide_by_vanishing_poly` in coefficient form: (q, r) with a = q (X^n - 1) + r
+        (algebra/poly/src/polynomial/univariate/dense.rs: q_i = sum_{j >= 1} a_{i + j n}, r_i = sum_{j >= 0} a_{i + j n})."""
+        m = self.length(a)
+        if m <= n:
+            return self.resized(a, 0), a
+        chunks = [self.resized(self.drop_first(a, lo), n) for lo in range(0, m, n)]   # the last chunk is zero-padded
+        suffix = chunks[-1]
+        q_chunks = [None] * (len(chunks) - 1)
+        for j in range(len(chunks) - 2, -1, -1):
+            q_chunks[j] = suffix
+            suffix = self.add(suffix, chunks[j])
+        q = self.concat(q_chunks)
+        return self.resized(q, m - n), suffix
+
+    def concat(self, parts): raise NotImplementedError
+
+    def shift(self, a, w: int):
+        """mpc-plonk/src/util.rs:11-18: coefficient i times w^i."""
+        return self.mul(a, self.powers(w, self.length(a)))
+
+    def open_at(self, a, x: int):
+        """`Prover::eval` (mpc-plonk/src/lib.rs:343-369) / KZG10::open (poly-commit/src/kzg10/mod.rs:225-265): the witness
+        polynomial a / (X - x), its commitment, and the evaluation."""
+        wit, value = self.div_linear(a, x)
+        self.reveal(value)
+        return {"value": value, "proof": self.commit(wit), "point": x}
+
+    def reveal(self, value):
+        """`y.publicize()` of an evaluation (mpc-plonk/src/lib.rs:362-365; marlin/src/lib.rs:290): with one party per process the
+        share of the value is opened over the network; with all lanes on one GPU there is nothing to exchange."""
+        return None
+
+
+def shared_stream_context(czk, device: int = 0):
+    """A context whose kernels run on torch's current stream: GpuBackend mixes torch tensor operations (copies, concatenation,
+    zero fills) with library calls, so both must be ordered on ONE stream (torch's default stream has handle 0, which the C ABI
+    reads as "create a private stream": hence an explicit torch stream)."""
+    import torch
+    ts = torch.cuda.Stream(device=device)
+    torch.cuda.set_stream(ts)
+    return czk.Context(device, ts.cuda_stream)
+
+
+class GpuBackend(Backend):
+    """The product path: device tensors, every operation one or a few C-ABI calls on the context's stream -- which must be
+    torch's current stream (shared_stream_context)."""
+
+    def __init__(self, czk, ctx, lanes: int, max_degree: int, base_seed: int = 0xBA5E5 + 77, lift=None):
+        import torch
+        self.czk, self.ctx, self.lanes, self.torch = czk, ctx, lanes, torch
+        self.lift = tuple([1] * lanes) if lift is None else tuple(lift)
+        self.dev = torch.device("cuda")
+        # powers_of_g = [tau^i] G for a FIXED, KNOWN tau (a real SRS hides tau; knowing it lets bench.py verify every opening on the
+        # host without a pairing: C - [v] G == [tau - x] W).  k_i = tau^i as canonical scalars, computed on the device.
+        n = max_degree + 1
+        self.tau = challenge("kzg.tau.%x" % base_seed)
+        pw = torch.empty((n, 4), dtype=torch.int64, device=self.dev)
+        ctx.fr_powers(mont(self.tau), n, out=pw.data_ptr(), mem=czk.CZK_MEM_DEVICE)
+        k = torch.empty_like(pw)
+        ctx.fr_into_repr(pw.data_ptr(), out=k.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+        pts = torch.empty((n, 12), dtype=torch.int64, device=self.dev)
+        ctx.fixed_base_points(czk.CZK_G1, k.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+        self.bases = ctx.register_bases(czk.CZK_G1, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
+        ctx.sync()
+        self.bases_host = (lambda: pts.cpu().numpy().view(np.uint64))      # for the checker-side backend of the tests
+        self.base_seed, self.n_bases = base_seed, n
+        self.msm_count = self.ntt_count = 0
+        self.opener = None      # party-per-rank layouts: callable(backend, value (lanes, 4) numpy) running the open over torch.distributed
+        self.msm_points = 0
+
+    M = 1   # CZK_MEM_DEVICE
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        if a.ndim == 2:
+            a = a[None]
+        return self.torch.from_numpy(a.view(np.int64)).to(self.dev)
+
+    def download(self, a):
+        self.ctx.sync()
+        return a.cpu().numpy().view(np.uint64)
+
+    def length(self, a):
+        return a.shape[1]
+
+    def lanes_of(self, a):
+        return a.shape[0]
+
+    def zeros(self, lanes, n):
+        return self.torch.zeros((lanes, n, 4), dtype=self.torch.int64, device=self.dev)
+
+    def lane_stack(self, parts):
+        return self.torch.cat(parts, dim=0).contiguous()
+
+    def resized(self, a, n):
+        out = self.torch.zeros((a.shape[0], n, 4), dtype=self.torch.int64, device=self.dev)
+        m = min(n, a.shape[1])
+        out[:, :m] = a[:, :m]
+        return out
+
+    def drop_first(self, a, k):
+        return a[:, k:].contiguous()
+
+    def concat(self, parts):
+        return self.torch.cat(parts, dim=1).contiguous()
+
+    def _bc(self, a, b):
+        la, lb = a.shape[0], b.shape[0]
+        if la != lb:
+            if la == 1:
+                a = a.expand(lb, -1, -1).contiguous()
+            else:
+                b = b.expand(la, -1, -1).contiguous()
+        return a.contiguous(), b.contiguous()
+
+    def _vec(self, op, a, b):
+        if op == 2:
+            a, b = self._bc(a, b)
+        assert a.shape == b.shape, (a.shape, b.shape)
+        a, b = a.contiguous(), b.contiguous()
+        out = self.torch.empty_like(a)
+        self.ctx.fr_vec_op(op, a.data_ptr(), b.data_ptr(), out=out.data_ptr(), n=a.shape[0] * a.shape[1], mem=self.M)
+        return out
+
+    def add(self, a, b):
+        return self._vec(0, a, b)
+
+    def sub(self, a, b):
+        return self._vec(1, a, b)
+
+    def mul(self, a, b):
+        return self._vec(2, a, b)
+
+    def scale(self, a, k):
+        a = a.contiguous()
+        out = self.torch.empty_like(a)
+        kd = self.torch.from_numpy(mont(k).view(np.int64)).to(self.dev)     # device memory mode: the scalar is read from the device too
+        self.ctx.fr_vec_scale(a.data_ptr(), kd.data_ptr(), out=out.data_ptr(), n=a.shape[0] * a.shape[1], mem=self.M)
+        return out
+
+    def powers(self, g, n):
+        out = self.torch.empty((1, n, 4), dtype=self.torch.int64, device=self.dev)
+        self.ctx.fr_powers(mont(g), n, out=out.data_ptr(), mem=self.M)
+        return out
+
+    def ntt(self, a, size, kind):
+        buf = self.resized(a, size)
+        self.ctx.ntt_fr_mixed(buf.data_ptr(), size, kind, lanes=buf.shape[0], in_len=min(a.shape[1], size), mem=self.M)
+        self.ntt_count += buf.shape[0]
+        return buf
+
+    def div_linear(self, a, z):
+        a = a.contiguous()
+        lanes, n = a.shape[0], a.shape[1]
+        q = self.torch.empty((lanes, max(n - 1, 0), 4), dtype=self.torch.int64, device=self.dev)
+        rem = self.torch.empty((lanes, 4), dtype=self.torch.int64, device=self.dev)
+        self.ctx.poly_div_linear(a.data_ptr(), mont(z), lanes=lanes, n=n, quotient=q.data_ptr(), remainder=rem.data_ptr(), mem=self.M)
+        self.ctx.sync()
+        return q, rem.cpu().numpy().view(np.uint64)
+
+    def prefix_product(self, a):
+        a = a.contiguous()
+        out = self.torch.empty_like(a)
+        for ln in range(a.shape[0]):
+            self.ctx.fr_prefix_product(a[ln].data_ptr(), n=a.shape[1], out=out[ln].data_ptr(), mem=self.M)
+        return out
+
+    def inverse(self, a):
+        a = a.contiguous()
+        out = self.torch.empty_like(a)
+        self.ctx.fr_batch_inverse(a.data_ptr(), n=a.shape[0] * a.shape[1], out=out.data_ptr(), mem=self.M)
+        return out
+
+    def random(self, seed, n):
+        from .provers import rand_fr_canonical
+        t = self.torch.from_numpy(rand_fr_canonical(seed, n).view(np.int64)).to(self.dev)
+        out = self.torch.empty((1, n, 4), dtype=self.torch.int64, device=self.dev)
+        self.ctx.fr_from_repr(t.data_ptr(), out=out.data_ptr(), n=n, mem=self.M)
+        return out
+
+    def root_of_unity(self, size):
+        return unmont(self.ctx.mixed_domain_constants(size)["group_gen"])
+
+    def reveal(self, value):
+        if self.opener is not None:
+            self.opener(self, value)
+
+    def commit(self, a):
+        a = a.contiguous()
+        n = a.shape[1]
+        assert n <= self.n_bases, "polynomial longer than powers_of_g"
+        jac = self.ctx.msm(self.bases, a.data_ptr(), n_scalars=n, lanes=a.shape[0], scalar_form=self.czk.CZK_SCALAR_MONTGOMERY, mem=self.M)
+        self.msm_count += a.shape[0]
+        self.msm_points += a.shape[0] * n
+        return self.ctx.jac_to_affine(self.czk.CZK_G1, jac)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Plonk (mpc-plonk/src/lib.rs)
+# ---------------------------------------------------------------------------------------------------------------------
+GENERATOR = 22   # Fr::multiplicative_generator() (fr.rs:69-74)
+
+
+def vanishing(size: int, point: int) -> int:
+    """evaluate_vanishing_polynomial: point^size - 1"""
+    return (pow(point, size, R_MOD) - 1) % R_MOD
+
+
+def shared_copy(B: Backend, a_public):
+    """The same values on every lane: the reference's king_share stand-in hands every party the value itself
+    (gsz20/mod.rs:190-213); for SPDZ benchmarks the lanes are filled the same way (values do not affect the work)."""
+    return B.lane_stack([a_public] * B.lanes)
+
+
+def plonk_prove(B: Backend, n_gates: int, seed: int = 0x9107) -> dict:
+    """Local compute of `Prover::prove` (mpc-plonk/src/lib.rs:430-448) on a synthetic circuit layout of `n_gates` gates
+    (relations/flat.rs:24-130): wire-value polynomial p (secret, 3 n_gates coefficients), selector s (public, n_gates), wiring
+    permutation w (public, 3 n_gates), one public wire.  Returns every commitment and opening in the reference's order."""
+    G, W = n_gates, 3 * n_gates
+    w = B.root_of_unity(W)                                                     # domains.wires.group_gen (mixed radix)
+    zinv_w = pow(vanishing(W, GENERATOR), -1, R_MOD)                           # divide_by_vanishing_poly_on_coset (domain/mod.rs:184-191)
+    out = {}
+    p = shared_copy(B, B.random(seed + 1, W))
+    s_pub, w_pub = B.random(seed + 2, G), B.random(seed + 3, W)
+
+    def commit(label, a):
+        out[label + "_cmt"] = B.commit(a)
+
+    def open_(label, a, x, of=None):
+        out[label] = B.open_at(a, x)
+        out[label]["of"] = of          # label of the opened polynomial's commitment (None: an index polynomial, committed at setup)
+
+    commit("p", p)                                                             # :434-441
+    # prove_public (:259-292) with one public wire: v = p(x_pub) constant, z = X - x_pub, q = (p - v) / z
+    q_pub, _y = B.div_linear(p, w)
+    commit("pub_q", q_pub)
+    x = challenge("plonk.public.x")
+    open_("pub_q_open", q_pub, x, "pub_q")
+    open_("pub_p_open", p, x, "p")
+    # prove_gates (:295-340): d = s (p + pw) + (1 - s)(p pw) - pww, q = d / v_gates
+    pw = B.shift(p, w)
+    pww = B.shift(p, w * w % R_MOD)
+    one_minus_s = B.add_const(B.scale(s_pub, R_MOD - 1), 1)                    # public
+    d = B.sub(_padded_add(B, B.poly_mul(s_pub, B.add(p, pw)), B.poly_mul(one_minus_s, B.poly_mul(p, pw))), B.resized(pww, G + 2 * W - 2))
+    q_gates, _r = B.div_vanishing(d, G)
+    commit("gates_q", q_gates)
+    x = challenge("plonk.gates.x")
+    open_("gates_s_open", s_pub, x)
+    open_("gates_p_open", p, x, "p")
+    open_("gates_q_open", q_gates, x, "gates_q")
+    open_("gates_p_w_open", p, w * x % R_MOD, "p")
+    open_("gates_p_w2_open", p, w * w % R_MOD * x % R_MOD, "p")
+    # prove_wiring (:201-257) over the wire domain
+    y, z = challenge("plonk.wiring.y"), challenge("plonk.wiring.z")
+    p_evals = B.ntt(p, W, FFT)
+    w_evals = B.ntt(w_pub, W, FFT)
+    yx_z = B.ntt(B.upload(np.stack([mont(z), mont(y)])), W, FFT)
+    num_evals = B.add_const(B.plus(p_evals, B.scale(w_evals, y)), z)
+    den_evals = B.plus(p_evals, yx_z)
+    l1_evals = B.mul(num_evals, B.inverse(den_evals))
+    l1 = B.ntt(l1_evals, W, IFFT)
+    commit("l1", l1)
+    # prove_unit_product(l1) (:115-198)
+    t = B.ntt(B.prefix_product(B.ntt(l1, W, FFT)), W, IFFT)
+    commit("t", t)
+    f_c = B.ntt(B.shift(l1, w), W, COSET_FFT)
+    t_c = B.ntt(t, W, COSET_FFT)
+    tw_c = B.ntt(B.shift(t, w), W, COSET_FFT)
+    q_up = B.ntt(B.scale(B.sub(tw_c, B.mul(f_c, t_c)), zinv_w), W, COSET_IFFT)
+    commit("q", q_up)
+    r = challenge("plonk.product.r")
+    open_("t_wr_open", t, w * r % R_MOD, "t")
+    open_("t_r_open", t, r, "t")
+    open_("t_wk_open", t, pow(w, W - 1, R_MOD), "t")
+    open_("f_wr_open", l1, w * r % R_MOD, "l1")
+    open_("q_r_open", q_up, r, "q")
+    # l2_q (:228-243)
+    l1_v = B.ntt(l1, W, COSET_FFT)
+    num_v = B.ntt(B.ntt(num_evals, W, IFFT), W, COSET_FFT)
+    den_v = B.ntt(B.ntt(den_evals, W, IFFT), W, COSET_FFT)
+    l2_q = B.ntt(B.scale(B.sub(B.mul(l1_v, den_v), num_v), zinv_w), W, COSET_IFFT)
+    commit("l2_q", l2_q)
+    x = challenge("plonk.wiring.x")
+    open_("l2_q_x_open", l2_q, x, "l2_q")
+    open_("w_x_open", w_pub, x)
+    open_("l1_x_open", l1, x, "l1")
+    open_("p_x_open", p, x, "p")
+    return out
+
+
+def _padded_add(B, a, b):
+    n = max(B.length(a), B.length(b))
+    return B.plus(B.resized(a, n), B.resized(b, n))
+
+
+def plonk_max_degree(n_gates: int) -> int:
+    """Longest committed polynomial: gates_q has (G + 2 W - 2) - G = 6 G - 2 coefficients."""
+    return 6 * n_gates
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Marlin (marlin/src/ahp/prover.rs, marlin/src/lib.rs)
+# ---------------------------------------------------------------------------------------------------------------------
+def marlin_prove(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
+    """Local compute of the three AHP prover rounds (marlin/src/ahp/prover.rs:300-704) and of Marlin::prove's commitments and
+    openings (marlin/src/lib.rs:176-318) on a synthetic index: |H| = next_pow2(n_constraints), |K| = next_pow2(non-zeros) with one
+    non-zero per row and matrix (the reference's squaring circuit), two formatted inputs.  Witness-side polynomials are share
+    lanes, the arithmetised matrices and everything in the third round are public, as in the reference."""
+    H = next_pow2(n_constraints)
+    K = next_pow2(n_constraints)
+    X = 2
+    out = {}
+
+    def commit(label, a):
+        out[label + "_cmt"] = B.commit(a)
+
+    def mask(a, tag, n_dom):
+        """a + rand * v_H: the zk blinding of the first-round polynomials (prover.rs:359-374); the blinding scalar is a fixed
+        constant here.  rand * (X^n - 1) is added share-wise like any public polynomial."""
+        rr = challenge("marlin.blind." + tag)
+        bump = np.zeros((n_dom + 1, 4), dtype=np.uint64)
+        bump[0], bump[n_dom] = mont(R_MOD - rr), mont(rr)
+        return B.plus(B.resized(a, n_dom + 1), B.upload(bump))
+    # ---- first round (prover.rs:300-398) -------------------------------------------------------------------
+    x_poly = B.ntt(B.random(seed + 4, X), X, IFFT)                                # public input polynomial (:324-330)
+    x_evals = B.ntt(x_poly, H, FFT)
+    w_evals = shared_copy(B, B.concat([B.random(seed + 1, H - X), B.zeros(1, X)]))
+    w_poly = B.ntt(B.minus(w_evals, x_evals), H, IFFT)                            # witness minus x on H, interpolated (:343-356)
+    w_poly, _ = B.div_vanishing(mask(w_poly, "w", H), X)                          # / v_X (:357)
+    z_a = mask(B.ntt(shared_copy(B, B.random(seed + 2, H)), H, IFFT), "za", H)
+    z_b = mask(B.ntt(shared_copy(B, B.random(seed + 3, H)), H, IFFT), "zb", H)
+    mask_poly = shared_copy(B, B.random(seed + 5, 3 * H))                         # degree 3|H| + 2 zk - 3 with zk_bound = 1 (:376-380)
+    for label, a in (("w", w_poly), ("z_a", z_a), ("z_b", z_b), ("mask_poly", mask_poly)):
+        commit(label, a)
+    # ---- second round (:439-556) ----------------------------------------------------------------------------
+    alpha, eta_a, eta_b, eta_c = (challenge("marlin." + t) for t in ("alpha", "eta_a", "eta_b", "eta_c"))
+    z_c = B.poly_mul(z_a, z_b)                                                    # shared x shared (:466)
+    summed = _padded_add(B, B.scale(z_c, eta_c), B.add(B.scale(z_a, eta_a), B.scale(z_b, eta_b)))   # (:468-476)
+    # r(alpha, X) on H, unnormalised bivariate Lagrange: (alpha^|H| - 1) / (alpha - h^i)  (:480-482), public
+    hpow = B.powers(B.root_of_unity(H), H)
+    r_alpha_evals = B.scale(B.inverse(B.add_const(B.scale(hpow, R_MOD - 1), alpha)), vanishing(H, alpha))
+    r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT)
+    t_poly = B.ntt(B.mul(B.random(seed + 6, H), r_alpha_evals), H, IFFT)          # calculate_t (:400-416): matrix-weighted r_alpha on H
+    z_poly = _padded_add(B, _mul_by_vanishing(B, w_poly, X), x_poly)              # w v_X + x (:512-517)
+    n_rhs = max(B.length(r_alpha_poly) + B.length(summed), B.length(t_poly) + B.length(z_poly)) - 1
+    mul_size = next_pow2(max(B.length(mask_poly), n_rhs + 1))                     # GeneralEvaluationDomain::new(max(..)) (:522-531)
+    ev = lambda a: B.ntt(a, mul_size, FFT)
+    rhs = B.resized(B.ntt(B.sub(B.mul(ev(r_alpha_poly), ev(summed)), B.mul(ev(z_poly), ev(t_poly))), mul_size, IFFT), n_rhs)
+    q_1 = _padded_add(B, mask_poly, rhs)
+    h_1, x_g_1 = B.div_vanishing(q_1, H)
+    g_1 = B.drop_first(x_g_1, 1)
+    for label, a in (("t", t_poly), ("g_1", g_1), ("h_1", h_1)):
+        commit(label, a)
+    # ---- third round (:585-704): everything public ---------------------------------------------------------------
+    beta = challenge("marlin.beta")
+    vh = vanishing(H, alpha) * vanishing(H, beta) % R_MOD
+    b_size = next_pow2(3 * K - 3)
+    etas = {"a": eta_a, "b": eta_b, "c": eta_c}
+    f_evals, den_b, val_b = None, {}, {}
+    for i, m in enumerate("abc"):
+        row, col, val = (B.random(seed + 10 * (i + 1) + j, K) for j in range(3))   # a_star.evals_on_K.{row, col, val}
+        inv = B.inverse(B.mul(B.add_const(B.scale(row, R_MOD - 1), beta), B.add_const(B.scale(col, R_MOD - 1), alpha)))   # (:612-620)
+        term = B.scale(B.mul(val, inv), etas[m])
+        f_evals = term if f_evals is None else B.add(f_evals, term)
+        rb, cb, rcb, vb = (B.random(seed + 10 * (i + 1) + 3 + j, b_size) for j in range(4))    # a_star.evals_on_B.*, row_col_evals_on_B
+        # beta alpha - r alpha - beta c + r_c  (:641-658)
+        den_b[m] = B.add_const(B.add(B.sub(rcb, B.scale(rb, alpha)), B.scale(cb, R_MOD - beta)), beta * alpha % R_MOD)
+        val_b[m] = vb
+    f = B.ntt(B.scale(f_evals, vh), K, IFFT)
+    g_2 = B.drop_first(f, 1)
+    a_on_b = None
+    for m, o1, o2 in (("a", "b", "c"), ("b", "a", "c"), ("c", "a", "b")):
+        term = B.scale(B.mul(val_b[m], B.mul(den_b[o1], den_b[o2])), etas[m])      # (:664-673)
+        a_on_b = term if a_on_b is None else B.add(a_on_b, term)
+    # in a real index a and b have degree < 3 |K| - 3 (that is why domain_b has that size, :636): keep that many coefficients
+    a_poly = B.resized(B.ntt(B.scale(a_on_b, vh), b_size, IFFT), 3 * K - 3)
+    b_poly = B.resized(B.ntt(B.mul(den_b["a"], B.mul(den_b["b"], den_b["c"])), b_size, IFFT), 3 * K - 3)
+    bf = B.poly_mul(b_poly, f)
+    h_2, _ = B.div_vanishing(B.sub(B.resized(a_poly, B.length(bf)), bf), K)        # (a - b f) / v_K (:693-696)
+    for label, a in (("g_2", g_2), ("h_2", h_2)):
+        commit(label, a)
+    # ---- openings (marlin/src/lib.rs:262-318 -> PC::open_combinations, poly-commit/src/marlin_pc/mod.rs): every oracle is evaluated at
+    # its query point (first / second round oracles at beta, third round oracles and the index polynomials at gamma) and all
+    # polynomials queried at one point are folded with powers of the opening challenge into ONE witness polynomial = one MSM
+    ch = challenge("marlin.opening_challenge")
+    gamma = challenge("marlin.gamma")
+    idx_polys = [B.ntt(B.random(seed + 100 + j, K), K, IFFT) for j in range(12)]      # row / col / val / row_col of A, B, C (index time)
+    for tag, pt, polys in (("beta", beta, [w_poly, z_a, z_b, mask_poly, t_poly, g_1, h_1]), ("gamma", gamma, [g_2, h_2] + idx_polys)):
+        folded, c = None, 1
+        for a in polys:
+            out.setdefault("evals_" + tag, []).append(B.div_linear(a, pt)[1])       # get_lc_eval: the polynomial's value at the point
+            term = B.scale(a, c)
+            folded = term if folded is None else _padded_add(B, folded, term)
+            c = c * ch % R_MOD
+        out["open_" + tag] = B.open_at(folded, pt)
+        out["open_" + tag]["fold"] = ch
+    # degree-bounded oracles (g_1: |H| - 2, g_2: |K| - 2) carry a second, shifted commitment (marlin_pc commit with a degree
+    # bound): the same scalars over the shifted powers -- same work; the stand-in commits over the same prefix of powers
+    commit("g_1_shifted", g_1)
+    commit("g_2_shifted", g_2)
+    return out
+
+
+def _mul_by_vanishing(B, a, n):
+    """a * (X^n - 1) (dense.rs mul_by_vanishing_poly): a shifted up by n, minus a"""
+    m = B.length(a)
+    return B.sub(B.concat([B.zeros(B.lanes_of(a), n), a]), B.resized(a, m + n))
+
+
+def marlin_max_degree(n_constraints: int) -> int:
+    """Longest committed polynomial: mask_poly (3 |H| coefficients) or h_2 = (a - b f) / v_K (3 |K| - 4)."""
+    return 3 * next_pow2(n_constraints) + 8

@@ -102,6 +102,11 @@ typedef enum { CZK_OP_ADD = 0, CZK_OP_SUB = 1, CZK_OP_MUL = 2 } czk_binop;
 int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int mem);
 /* out[i] = a[i] * k  (k: one Montgomery Fr; domain/mod.rs:184-191) */
 int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n, int mem);
+/* out[i] = c * g^i for i < n (g, c: one Montgomery Fr each, HOST memory; c NULL = one): the table behind
+ * EvaluationDomain::distribute_powers / distribute_powers_and_mul_by_const (algebra/poly/src/domain/mod.rs:93-106) for any g --
+ * coset shifts other than the generator, and `shift(p, w)` of the Plonk prover (mpc-plonk/src/util.rs).  Multiply with
+ * czk_fr_vec_op(CZK_OP_MUL) per lane. */
+int czk_fr_powers(czk_ctx* ctx, const uint64_t* g, const uint64_t* c, size_t n, uint64_t* out, int mem);
 /* Local half of Beaver multiplication (mpc-algebra/src/share/field.rs:97-127), per lane:
  *   out[i] = z[i] - y[i]*sx[i] - x[i]*oy[i] + (add_open ? sx[i]*oy[i] : 0)
  * x, y, z: this party's triple shares; sx, oy: the opened values; add_open = this party applies `shift`

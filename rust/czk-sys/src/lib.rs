@@ -49,6 +49,7 @@ extern "C" {
     pub fn czk_mixed_domain_constants(ctx: *mut czk_ctx, size: usize, out24: *mut u64) -> c_int;
     pub fn czk_fr_vec_op(ctx: *mut czk_ctx, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
     pub fn czk_fr_vec_scale(ctx: *mut czk_ctx, a: *const u64, k: *const u64, out: *mut u64, n: usize, mem: c_int) -> c_int;
+    pub fn czk_fr_powers(ctx: *mut czk_ctx, g: *const u64, c: *const u64, n: usize, out: *mut u64, mem: c_int) -> c_int;
     pub fn czk_fr_beaver_combine(ctx: *mut czk_ctx, x: *const u64, y: *const u64, z: *const u64, sx: *const u64, oy: *const u64, add_open: c_int, out: *mut u64, n: usize, mem: c_int) -> c_int;
     pub fn czk_fr_spdz_open(ctx: *mut czk_ctx, shares: *const u64, parties: usize, n: usize, out_value: *mut u64, out_bad: *mut u64) -> c_int;
     pub fn czk_fr_lanes_sum(ctx: *mut czk_ctx, x: *const u64, k: usize, n: usize, out: *mut u64, out_nonzero: *mut u64) -> c_int;
