@@ -114,6 +114,16 @@ class Backend:
         m = self.length(a)
         if m <= n:
             return self.resized(a, 0), a
+        if n < (m + n - 1) // n:
+            # few residues, many terms (Marlin divides by v_X with |X| = 2): the n residue classes a[c], a[c + n], ... are
+            # independent polynomials in Y = X^n, and q's class c is the quotient of that polynomial by (Y - 1)
+            L = (m + n - 1) // n
+            classes = self.strided_split(self.resized(a, L * n), n)            # (lanes * n, L, 4)
+            qc, rem = self.div_linear(classes, 1)
+            lanes = self.lanes_of(a)
+            q = self.strided_merge(self.resized(qc, L), n, lanes)               # back to (lanes, L * n, 4); the top n slots are zero
+            r = self.upload(rem.reshape(lanes, n, 4))
+            return self.resized(q, m - n), r
         chunks = [self.resized(self.drop_first(a, lo), n) for lo in range(0, m, n)]   # the last chunk is zero-padded
         suffix = chunks[-1]
         q_chunks = [None] * (len(chunks) - 1)
@@ -124,6 +134,8 @@ class Backend:
         return self.resized(q, m - n), suffix
 
     def concat(self, parts): raise NotImplementedError
+    def strided_split(self, a, n: int): raise NotImplementedError    # (lanes, L n, 4) -> (lanes n, L, 4): class c of lane l at l n + c
+    def strided_merge(self, a, n: int, lanes: int): raise NotImplementedError   # inverse of strided_split
 
     def shift(self, a, w: int):
         """mpc-plonk/src/util.rs:11-18: coefficient i times w^i."""
@@ -214,6 +226,14 @@ class GpuBackend(Backend):
 
     def concat(self, parts):
         return self.torch.cat(parts, dim=1).contiguous()
+
+    def strided_split(self, a, n):
+        lanes, total = a.shape[0], a.shape[1]
+        return a.reshape(lanes, total // n, n, 4).permute(0, 2, 1, 3).reshape(lanes * n, total // n, 4).contiguous()
+
+    def strided_merge(self, a, n, lanes):
+        L = a.shape[1]
+        return a.reshape(lanes, n, L, 4).permute(0, 2, 1, 3).reshape(lanes, L * n, 4).contiguous()
 
     def _bc(self, a, b):
         la, lb = a.shape[0], b.shape[0]
@@ -323,16 +343,22 @@ def shared_copy(B: Backend, a_public):
     return B.lane_stack([a_public] * B.lanes)
 
 
-def plonk_prove(B: Backend, n_gates: int, seed: int = 0x9107) -> dict:
-    """Local compute of `Prover::prove` (mpc-plonk/src/lib.rs:430-448) on a synthetic circuit layout of `n_gates` gates
-    (relations/flat.rs:24-130): wire-value polynomial p (secret, 3 n_gates coefficients), selector s (public, n_gates), wiring
-    permutation w (public, 3 n_gates), one public wire.  Returns every commitment and opening in the reference's order."""
-    G, W = n_gates, 3 * n_gates
+def plonk_inputs(B: Backend, n_gates: int, seed: int = 0x9107) -> dict:
+    """A synthetic circuit layout of `n_gates` gates (relations/flat.rs:24-130): wire-value polynomial p (secret, 3 n_gates
+    coefficients), selector s (public, n_gates), wiring permutation w (public, 3 n_gates), one public wire."""
+    W = 3 * n_gates
+    return {"n_gates": n_gates, "p": shared_copy(B, B.random(seed + 1, W)), "s": B.random(seed + 2, n_gates), "w": B.random(seed + 3, W)}
+
+
+def plonk_prove(B: Backend, inp: dict) -> dict:
+    """Local compute of `Prover::prove` (mpc-plonk/src/lib.rs:430-448) on plonk_inputs.  Returns every commitment and opening in
+    the reference's order."""
+    G = inp["n_gates"]
+    W = 3 * G
     w = B.root_of_unity(W)                                                     # domains.wires.group_gen (mixed radix)
     zinv_w = pow(vanishing(W, GENERATOR), -1, R_MOD)                           # divide_by_vanishing_poly_on_coset (domain/mod.rs:184-191)
     out = {}
-    p = shared_copy(B, B.random(seed + 1, W))
-    s_pub, w_pub = B.random(seed + 2, G), B.random(seed + 3, W)
+    p, s_pub, w_pub = inp["p"], inp["s"], inp["w"]
 
     def commit(label, a):
         out[label + "_cmt"] = B.commit(a)
@@ -412,14 +438,31 @@ def plonk_max_degree(n_gates: int) -> int:
 # ---------------------------------------------------------------------------------------------------------------------
 # Marlin (marlin/src/ahp/prover.rs, marlin/src/lib.rs)
 # ---------------------------------------------------------------------------------------------------------------------
-def marlin_prove(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
-    """Local compute of the three AHP prover rounds (marlin/src/ahp/prover.rs:300-704) and of Marlin::prove's commitments and
-    openings (marlin/src/lib.rs:176-318) on a synthetic index: |H| = next_pow2(n_constraints), |K| = next_pow2(non-zeros) with one
-    non-zero per row and matrix (the reference's squaring circuit), two formatted inputs.  Witness-side polynomials are share
-    lanes, the arithmetised matrices and everything in the third round are public, as in the reference."""
-    H = next_pow2(n_constraints)
-    K = next_pow2(n_constraints)
+def marlin_inputs(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
+    """A synthetic index and assignment: |H| = next_pow2(n_constraints), |K| = next_pow2(non-zeros) with one non-zero per row
+    and matrix (the reference's squaring circuit), two formatted inputs.  Witness-side vectors are share lanes; the arithmetised
+    matrices (evaluations on K and on B, the index polynomials) are public index-time data (ahp/indexer.rs)."""
+    H = K = next_pow2(n_constraints)
     X = 2
+    b_size = next_pow2(3 * K - 3)
+    inp = {"H": H, "K": K, "X": X, "b_size": b_size,
+           "x": B.random(seed + 4, X),
+           "w": shared_copy(B, B.concat([B.random(seed + 1, H - X), B.zeros(1, X)])),
+           "z_a": shared_copy(B, B.random(seed + 2, H)), "z_b": shared_copy(B, B.random(seed + 3, H)),
+           "mask_poly": shared_copy(B, B.random(seed + 5, 3 * H)),                # degree 3|H| + 2 zk - 3 with zk_bound = 1 (:376-380)
+           "t_rows": B.random(seed + 6, H), "star": {}}
+    for i, m in enumerate("abc"):
+        inp["star"][m] = {"on_K": [B.random(seed + 10 * (i + 1) + j, K) for j in range(3)],              # row, col, val
+                          "on_B": [B.random(seed + 10 * (i + 1) + 3 + j, b_size) for j in range(4)]}    # row, col, row_col, val
+    inp["index_polys"] = [B.ntt(B.random(seed + 100 + j, K), K, IFFT) for j in range(12)]                 # row / col / val / row_col of A, B, C
+    return inp
+
+
+def marlin_prove(B: Backend, inp: dict) -> dict:
+    """Local compute of the three AHP prover rounds (marlin/src/ahp/prover.rs:300-704) and of Marlin::prove's commitments and
+    openings (marlin/src/lib.rs:176-318) on marlin_inputs.  Witness-side polynomials are share lanes, the arithmetised matrices
+    and everything in the third round are public, as in the reference."""
+    H, K, X, b_size = inp["H"], inp["K"], inp["X"], inp["b_size"]
     out = {}
 
     def commit(label, a):
@@ -433,14 +476,14 @@ def marlin_prove(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
         bump[0], bump[n_dom] = mont(R_MOD - rr), mont(rr)
         return B.plus(B.resized(a, n_dom + 1), B.upload(bump))
     # ---- first round (prover.rs:300-398) -------------------------------------------------------------------
-    x_poly = B.ntt(B.random(seed + 4, X), X, IFFT)                                # public input polynomial (:324-330)
+    x_poly = B.ntt(inp["x"], X, IFFT)                                            # public input polynomial (:324-330)
     x_evals = B.ntt(x_poly, H, FFT)
-    w_evals = shared_copy(B, B.concat([B.random(seed + 1, H - X), B.zeros(1, X)]))
+    w_evals = inp["w"]
     w_poly = B.ntt(B.minus(w_evals, x_evals), H, IFFT)                            # witness minus x on H, interpolated (:343-356)
     w_poly, _ = B.div_vanishing(mask(w_poly, "w", H), X)                          # / v_X (:357)
-    z_a = mask(B.ntt(shared_copy(B, B.random(seed + 2, H)), H, IFFT), "za", H)
-    z_b = mask(B.ntt(shared_copy(B, B.random(seed + 3, H)), H, IFFT), "zb", H)
-    mask_poly = shared_copy(B, B.random(seed + 5, 3 * H))                         # degree 3|H| + 2 zk - 3 with zk_bound = 1 (:376-380)
+    z_a = mask(B.ntt(inp["z_a"], H, IFFT), "za", H)
+    z_b = mask(B.ntt(inp["z_b"], H, IFFT), "zb", H)
+    mask_poly = inp["mask_poly"]
     for label, a in (("w", w_poly), ("z_a", z_a), ("z_b", z_b), ("mask_poly", mask_poly)):
         commit(label, a)
     # ---- second round (:439-556) ----------------------------------------------------------------------------
@@ -451,7 +494,7 @@ def marlin_prove(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
     hpow = B.powers(B.root_of_unity(H), H)
     r_alpha_evals = B.scale(B.inverse(B.add_const(B.scale(hpow, R_MOD - 1), alpha)), vanishing(H, alpha))
     r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT)
-    t_poly = B.ntt(B.mul(B.random(seed + 6, H), r_alpha_evals), H, IFFT)          # calculate_t (:400-416): matrix-weighted r_alpha on H
+    t_poly = B.ntt(B.mul(inp["t_rows"], r_alpha_evals), H, IFFT)          # calculate_t (:400-416): matrix-weighted r_alpha on H
     z_poly = _padded_add(B, _mul_by_vanishing(B, w_poly, X), x_poly)              # w v_X + x (:512-517)
     n_rhs = max(B.length(r_alpha_poly) + B.length(summed), B.length(t_poly) + B.length(z_poly)) - 1
     mul_size = next_pow2(max(B.length(mask_poly), n_rhs + 1))                     # GeneralEvaluationDomain::new(max(..)) (:522-531)
@@ -465,15 +508,14 @@ def marlin_prove(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
     # ---- third round (:585-704): everything public ---------------------------------------------------------------
     beta = challenge("marlin.beta")
     vh = vanishing(H, alpha) * vanishing(H, beta) % R_MOD
-    b_size = next_pow2(3 * K - 3)
     etas = {"a": eta_a, "b": eta_b, "c": eta_c}
     f_evals, den_b, val_b = None, {}, {}
     for i, m in enumerate("abc"):
-        row, col, val = (B.random(seed + 10 * (i + 1) + j, K) for j in range(3))   # a_star.evals_on_K.{row, col, val}
+        row, col, val = inp["star"][m]["on_K"]                                     # a_star.evals_on_K.{row, col, val}
         inv = B.inverse(B.mul(B.add_const(B.scale(row, R_MOD - 1), beta), B.add_const(B.scale(col, R_MOD - 1), alpha)))   # (:612-620)
         term = B.scale(B.mul(val, inv), etas[m])
         f_evals = term if f_evals is None else B.add(f_evals, term)
-        rb, cb, rcb, vb = (B.random(seed + 10 * (i + 1) + 3 + j, b_size) for j in range(4))    # a_star.evals_on_B.*, row_col_evals_on_B
+        rb, cb, rcb, vb = inp["star"][m]["on_B"]                                    # a_star.evals_on_B.*, row_col_evals_on_B
         # beta alpha - r alpha - beta c + r_c  (:641-658)
         den_b[m] = B.add_const(B.add(B.sub(rcb, B.scale(rb, alpha)), B.scale(cb, R_MOD - beta)), beta * alpha % R_MOD)
         val_b[m] = vb
@@ -495,7 +537,7 @@ def marlin_prove(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
     # polynomials queried at one point are folded with powers of the opening challenge into ONE witness polynomial = one MSM
     ch = challenge("marlin.opening_challenge")
     gamma = challenge("marlin.gamma")
-    idx_polys = [B.ntt(B.random(seed + 100 + j, K), K, IFFT) for j in range(12)]      # row / col / val / row_col of A, B, C (index time)
+    idx_polys = inp["index_polys"]
     for tag, pt, polys in (("beta", beta, [w_poly, z_a, z_b, mask_poly, t_poly, g_1, h_1]), ("gamma", gamma, [g_2, h_2] + idx_polys)):
         folded, c = None, 1
         for a in polys:

@@ -34,6 +34,14 @@ def make_backend(orc, polyvm, lanes, max_degree, base_seed=0xBA5E5 + 77, lift=No
         def concat(self, parts):
             return np.concatenate(parts, axis=1)
 
+        def strided_split(self, a, n):
+            lanes, total = a.shape[0], a.shape[1]
+            return np.ascontiguousarray(a.reshape(lanes, total // n, n, 4).transpose(0, 2, 1, 3).reshape(lanes * n, total // n, 4))
+
+        def strided_merge(self, a, n, l):
+            L = a.shape[1]
+            return np.ascontiguousarray(a.reshape(l, n, L, 4).transpose(0, 2, 1, 3).reshape(l, L * n, 4))
+
         def resized(self, a, n):
             out = np.zeros((a.shape[0], n, 4), dtype=np.uint64)
             m = min(n, a.shape[1])
@@ -145,6 +153,8 @@ def make_lockstep(polyvm, gpu, cpu):
         def lane_stack(self, parts): return self._chk("lane_stack", gpu.lane_stack([p[0] for p in parts]), cpu.lane_stack([p[1] for p in parts]))
         def concat(self, parts): return self._chk("concat", gpu.concat([p[0] for p in parts]), cpu.concat([p[1] for p in parts]))
         def resized(self, a, n): return self._both("resized", a, n)
+        def strided_split(self, a, n): return self._both("strided_split", a, n)
+        def strided_merge(self, a, n, l): return self._both("strided_merge", a, n, l)
         def drop_first(self, a, k): return self._both("drop_first", a, k)
         def ntt(self, a, size, kind): return self._both("ntt", a, size, kind)
         def add(self, a, b): return self._both("add", a, b)

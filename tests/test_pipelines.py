@@ -34,10 +34,11 @@ def test_plonk_gsz_pipeline_matches_checker(orc, n_gates, parties):
     gpu = polyvm.GpuBackend(czk_amd, ctx, parties, md)
     cpu = make_backend(orc, polyvm, parties, md, bases=gpu.bases_host())
     from oracle_backend import make_lockstep
-    polyvm.plonk_prove(make_lockstep(polyvm, gpu, cpu), n_gates)   # operation by operation: a divergence names the primitive
+    ls = make_lockstep(polyvm, gpu, cpu)
+    polyvm.plonk_prove(ls, polyvm.plonk_inputs(ls, n_gates))   # operation by operation: a divergence names the primitive
     gpu.msm_count = 0
-    got = polyvm.plonk_prove(gpu, n_gates)
-    want = polyvm.plonk_prove(cpu, n_gates)
+    got = polyvm.plonk_prove(gpu, polyvm.plonk_inputs(gpu, n_gates))
+    want = polyvm.plonk_prove(cpu, polyvm.plonk_inputs(cpu, n_gates))
     _compare(got, want)
     assert gpu.msm_count == parties * (7 + 16 - 2) + 2          # 7 commitments + 16 openings; the two openings of public polynomials are single-lane
     ctx.close()
@@ -56,8 +57,9 @@ def test_marlin_spdz_pipeline_matches_checker(orc, n_constraints):
     gpu = polyvm.GpuBackend(czk_amd, ctx, 4, md, lift=lift)
     cpu = make_backend(orc, polyvm, 4, md, lift=lift, bases=gpu.bases_host())
     from oracle_backend import make_lockstep
-    polyvm.marlin_prove(make_lockstep(polyvm, gpu, cpu), n_constraints)
-    got = polyvm.marlin_prove(gpu, n_constraints)
-    want = polyvm.marlin_prove(cpu, n_constraints)
+    ls = make_lockstep(polyvm, gpu, cpu)
+    polyvm.marlin_prove(ls, polyvm.marlin_inputs(ls, n_constraints))
+    got = polyvm.marlin_prove(gpu, polyvm.marlin_inputs(gpu, n_constraints))
+    want = polyvm.marlin_prove(cpu, polyvm.marlin_inputs(cpu, n_constraints))
     _compare(got, want)
     ctx.close()
