@@ -228,9 +228,9 @@ def cpu_baseline(log_n_sample: int, log_n_full: int, parties: int, all_cores_log
         N, log_d, D, b1, b2, x = inputs(all_cores_log_n)
     xs = np.ascontiguousarray(np.broadcast_to(x, (lanes,) + x.shape))
     inf_b = np.zeros(N + 1, dtype=np.uint8)
+    bufs = [xs.copy(), xs.copy(), xs.copy(), xs[:, :N].copy(), xs[:, :N + 1].copy()]
     t0 = time.perf_counter()
-    orc.groth16_local_par(log_d, N, xs.copy(), xs.copy(), xs.copy(), xs[:, :N].copy(), xs[:, :N + 1].copy(), b1[:D - 1], b1[:N], b1[:N + 1], b1[:N + 1],
-                          b2, inf_b)
+    orc.groth16_local_par(log_d, N, *bufs, b1[:D - 1], b1[:N], b1[:N + 1], b1[:N + 1], b2, inf_b)
     dt_mt = time.perf_counter() - t0
     scale_mt = _ref_work(1 << log_n_full) / _ref_work(1 << all_cores_log_n)
     out["all_cores"] = {"value": 1.0 / (dt_mt * scale_mt), "unit": "proofs/s", "cores": orc.max_threads(), "host_cores": cores,

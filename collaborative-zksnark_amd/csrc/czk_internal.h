@@ -59,7 +59,7 @@ struct DeviceBuf {
     size_t bytes = 0;
 };
 struct MsmSlot {
-    DeviceBuf ws_sort, ws_red;
+    DeviceBuf ws_sort, ws_red, ws_aff;
     hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_fix = nullptr, ev_red = nullptr;
     bool used = false;
 };
@@ -81,6 +81,7 @@ struct czk_ctx {
     char* msm_pinned = nullptr;
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
     std::vector<czk::MsmPending> msm_pending;
+    unsigned msm_affine_rounds = 0;  // CZK_MSM_AFFINE=R at pipeline creation: R rounds of batched-affine pair additions in front of the G1 bucket accumulation
     bool msm_sort_onepass = false;   // CZK_SORT_ONEPASS=1 at pipeline creation: the single-pass digit sort (kept as the > 2048-partition fallback)
     unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
     bool ntt_gen1 = false;           // CZK_NTT_GEN1=1 at context creation: first-generation NTT passes for every size (A/B runs)
@@ -203,6 +204,23 @@ void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sor
 void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords);
+// batched-affine pre-reduction of the bucket lists (msm_aff.h; G1)
+struct AffArgs {
+    unsigned rounds = 0, lanes = 0, n_parts = 0, part_shift = 0, part_log = 0;
+    size_t B = 0, sorted_stride = 0, S[3] = {0, 0, 0};
+    const u32 *sorted = nullptr, *offsets = nullptr, *counts = nullptr;
+    void* rec[3] = {nullptr, nullptr, nullptr};       // uint2 records per round
+    uint8_t* pend[3] = {nullptr, nullptr, nullptr};   // per-slot "redo with complete formulas" flags
+    u32 *off[2] = {nullptr, nullptr}, *cnt[2] = {nullptr, nullptr};   // bucket offsets / counts of level r at index r & 1
+    void* lvl[2] = {nullptr, nullptr};                // level arrays, ping-pong
+    void* scratch = nullptr;                          // running products of the resident waves
+};
+void aff_plan(size_t total0, size_t B, unsigned rounds, size_t* S);
+size_t aff_scratch_bytes(czk_ctx* ctx);
+void launch_affine_build_g1(hipStream_t st, const AffArgs& a);
+void launch_affine_accumulate_g1(czk_ctx* ctx, hipStream_t st, const AffArgs& a, const u64* pts, const u32* perm, u64* buckets, uint8_t* dirty);
+void launch_accumulate_g1_u_fixup_lvl(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                                      u64* buckets, unsigned lanes, uint8_t* dirty, const void* lvl);
 void launch_accumulate_g2_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,

@@ -574,10 +574,41 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     size_t need_sort = lanes * ((size_t)W * size * (4 * 3 + 2) + B * 4 * 4 + CNT_BINS * 4 + (size_t)n_parts * 12 + 64) + (1 << 16);
     const u32 heavy_cap = (u32)(lanes * (size_t)W * size / 256 + 64);   // >= number of 256-entry work items of over-full buckets (msm_acc.h HEAVY_SUB)
     size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B + (size_t)12 * 513 * XW * 8) + (size_t)heavy_cap * (XW * 8 + 32) + (1 << 17);
-    if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red) {
+    // batched-affine pre-reduction (G1, unsaturated tables): records, two level arrays, per-level bucket offsets / counts
+    AffArgs aff;
+    const bool one_pass_sort = ctx->msm_sort_onepass || n_parts > MAX_PARTS;
+    size_t need_aff = 0;
+    if (GT<F>::AW == 12 && b->unsat && ctx->msm_affine_rounds > 0 && size > 0) {
+        aff.rounds = ctx->msm_affine_rounds;
+        aff.lanes = (unsigned)lanes;
+        aff.B = B;
+        aff.sorted_stride = (size_t)W * size;
+        aff.n_parts = one_pass_sort ? 0 : n_parts;
+        aff.part_shift = part_shift;
+        aff.part_log = PART_LOG;
+        aff_plan((size_t)W * size, B, aff.rounds, aff.S);
+        for (unsigned r = 0; r < aff.rounds; r++) need_aff += lanes * aff.S[r] * (8 + 1) + 512;
+        need_aff += lanes * aff.S[0] * 128 + (aff.rounds > 1 ? lanes * aff.S[1] * 128 : 0) + 4 * lanes * B * 4 + aff_scratch_bytes(ctx) + (1 << 16);
+    }
+    if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red || slot.ws_aff.bytes < need_aff) {
         CZK_TRY(msm_pipeline_sync(ctx));
         CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
         CZK_TRY(ensure_buf(ctx, slot.ws_red, need_red));
+        if (need_aff) CZK_TRY(ensure_buf(ctx, slot.ws_aff, need_aff));
+    }
+    if (aff.rounds) {
+        Bump ba{(char*)slot.ws_aff.p};
+        for (unsigned r = 0; r < aff.rounds; r++) {
+            aff.rec[r] = ba.take<u64>(lanes * aff.S[r]);
+            aff.pend[r] = ba.take<uint8_t>(lanes * aff.S[r]);
+        }
+        aff.lvl[0] = ba.take<char>(lanes * aff.S[0] * 128);
+        aff.lvl[1] = aff.rounds > 1 ? ba.take<char>(lanes * aff.S[1] * 128) : nullptr;
+        for (int k = 0; k < 2; k++) {
+            aff.off[k] = ba.take<u32>(lanes * B);
+            aff.cnt[k] = ba.take<u32>(lanes * B);
+        }
+        aff.scratch = ba.take<char>(aff_scratch_bytes(ctx));
     }
     Bump bs{(char*)slot.ws_sort.p};
     u32* digits = bs.take<u32>(lanes * W * size);
@@ -622,7 +653,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_fix, 0));   // slot's sort buffers are read by its accumulate and fix-up kernels
     {
         ProfScope ps(ctx, "msm_sort", ss);
-        const bool one_pass = ctx->msm_sort_onepass || n_parts > MAX_PARTS;
+        const bool one_pass = one_pass_sort;
         if (one_pass) {
             CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
             if (size) {
@@ -655,6 +686,12 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
         hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
         hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
+        if (aff.rounds) {
+            aff.sorted = sorted;
+            aff.offsets = offsets;
+            aff.counts = counts;
+            launch_affine_build_g1(ss, aff);
+        }
         if (b->unsat) {
             // clear the dirty flags / exception list here rather than on the accumulate stream (the critical one); they live
             // in the slot's reduce workspace, which the slot's previous reduction may still be using
@@ -670,7 +707,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     if (b->unsat) {
         // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
-        if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, b->pts, perm, buckets, dirty);
+        else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
         else launch_accumulate_g2_u(ctx, sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
     } else {
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
@@ -687,7 +725,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                          heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
     if (b->unsat) {
         // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
-        if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        if (aff.rounds)
+            launch_accumulate_g1_u_fixup_lvl(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, aff.lvl[(aff.rounds - 1) & 1]);
+        else if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
         else launch_accumulate_g2_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
@@ -731,6 +771,10 @@ int msm_pipeline_init(czk_ctx* ctx) {
     if (ctx->s_sort) return CZK_OK;
     // (stream priorities for the short sort / reduce stages were measured: no gain, so all three are equal)
     ctx->msm_sort_onepass = getenv("CZK_SORT_ONEPASS") != nullptr;   // read once, not per enqueue
+    if (const char* e = getenv("CZK_MSM_AFFINE")) {
+        int v = atoi(e);
+        if (v >= 0 && v <= 3) ctx->msm_affine_rounds = (unsigned)v;
+    }
     if (const char* e = getenv("CZK_MSM_SLOTS")) {
         int v = atoi(e);
         if (v >= 1 && v <= czk_ctx::MSM_SLOTS) ctx->msm_slots_in_use = v;
@@ -774,6 +818,7 @@ void msm_pipeline_destroy(czk_ctx* ctx) {
     for (auto& s : ctx->msm_slots) {
         if (s.ws_sort.p) (void)hipFree(s.ws_sort.p);
         if (s.ws_red.p) (void)hipFree(s.ws_red.p);
+        if (s.ws_aff.p) (void)hipFree(s.ws_aff.p);
         (void)hipEventDestroy(s.ev_sorted);
         (void)hipEventDestroy(s.ev_acc);
         (void)hipEventDestroy(s.ev_fix);

@@ -2,6 +2,7 @@
 #define CZK_FQU_G1 1
 #include "fqu.h"
 #include "msm_acc.h"
+#include "msm_aff.h"
 
 namespace czk {
 void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
@@ -33,6 +34,60 @@ void launch_accumulate_g1_u_fixup(hipStream_t st, const u64* pts, const u32* sor
     hipLaunchKernelGGL(k_accumulate_u_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
                        sorted_stride, buckets, dirty);
     hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
+}
+// ---- batched-affine pre-reduction (msm_aff.h) ----------------------------------------------------------------------------
+// Slot counts of the levels: S_r = round_up_64((S_{r-1} + B + 1) / 2 + 1) with S_0 = entries per lane.
+void aff_plan(size_t total0, size_t B, unsigned rounds, size_t* S) {
+    size_t prev = total0;
+    for (unsigned r = 0; r < rounds; r++) {
+        S[r] = (((prev + B + 1) / 2 + 1) + 63) & ~(size_t)63;
+        prev = S[r];
+    }
+}
+// all records are a function of (offsets, counts) alone: built up front on the sort stream
+void launch_affine_build_g1(hipStream_t st, const AffArgs& a) {
+    const dim3 grid((unsigned)((a.B + 255) / 256), a.lanes), block(256);
+    for (unsigned r = 0; r < a.rounds; r++) {
+        (void)hipMemsetAsync(a.rec[r], 0xff, (size_t)a.lanes * a.S[r] * sizeof(uint2), st);
+        (void)hipMemsetAsync(a.pend[r], 0, (size_t)a.lanes * a.S[r], st);
+        if (r == 0)
+            hipLaunchKernelGGL(k_aff_build_first, grid, block, 0, st, a.sorted, a.sorted_stride, a.offsets, a.counts, a.B, a.n_parts, a.part_shift, a.part_log,
+                               HEAVY_CHUNK, a.S[0], (uint2*)a.rec[0], a.off[0], a.cnt[0]);
+        else
+            hipLaunchKernelGGL(k_aff_build_next, grid, block, 0, st, a.off[(r - 1) & 1], a.cnt[(r - 1) & 1], a.B, a.n_parts, a.part_shift, a.part_log, a.S[r - 1],
+                               a.S[r], (uint2*)a.rec[r], a.off[r & 1], a.cnt[r & 1]);
+    }
+}
+// the rounds, then the XYZZ accumulation of the last level; `st` = the accumulate stream
+void launch_affine_accumulate_g1(czk_ctx* ctx, hipStream_t st, const AffArgs& a, const u64* pts, const u32* perm, u64* buckets, uint8_t* dirty) {
+    size_t flags = ((size_t)a.lanes * a.B + 15) & ~(size_t)15;
+    u32* exc = (u32*)(dirty + flags);
+    ProfScope ps(ctx, "msm_accumulate_g1", st);
+    const unsigned waves = (unsigned)ctx->num_cu * 8;   // two resident waves per SIMD, each looping over work items
+    for (unsigned r = 0; r < a.rounds; r++) {
+        const size_t total = (size_t)a.lanes * a.S[r];
+        const uint4* src = r == 0 ? nullptr : (const uint4*)a.lvl[(r - 1) & 1];
+        uint4* dst = (uint4*)a.lvl[r & 1];
+        if (r == 0) {
+            hipLaunchKernelGGL(k_affine_round<true>, dim3(waves), dim3(64), 0, st, (const uint2*)a.rec[r], total, pts, src, dst, a.pend[r], (uint4*)a.scratch);
+            hipLaunchKernelGGL(k_affine_fix<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint2*)a.rec[r], total, pts, src, dst, a.pend[r]);
+        } else {
+            hipLaunchKernelGGL(k_affine_round<false>, dim3(waves), dim3(64), 0, st, (const uint2*)a.rec[r], total, pts, src, dst, a.pend[r], (uint4*)a.scratch);
+            hipLaunchKernelGGL(k_affine_fix<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const uint2*)a.rec[r], total, pts, src, dst, a.pend[r]);
+        }
+    }
+    const unsigned last = a.rounds - 1;
+    hipLaunchKernelGGL(k_accumulate_u_lvl, dim3((unsigned)((a.B + 127) / 128), a.lanes), dim3(128), 0, st, (const uint4*)a.lvl[last & 1], a.off[last & 1], a.cnt[last & 1], perm,
+                       a.B, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
+}
+size_t aff_scratch_bytes(czk_ctx* ctx) { return (size_t)ctx->num_cu * 8 * AFF_KB * 4 * 64 * 16; }
+void launch_accumulate_g1_u_fixup_lvl(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
+                                      u64* buckets, unsigned lanes, uint8_t* dirty, const void* lvl) {
+    size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
+    u32* exc = (u32*)(dirty + flags);
+    hipLaunchKernelGGL(k_accumulate_u_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
+                       sorted_stride, buckets, dirty);
+    hipLaunchKernelGGL(k_accumulate_u_lvl_cleanup, dim3(1), dim3(64), 0, st, (const uint4*)lvl, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
 }
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords) {
     hipLaunchKernelGGL(k_convert_to_u, dim3((unsigned)((n_coords + 255) / 256)), dim3(256), 0, st, pts, n_coords);

@@ -18,6 +18,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <omp.h>
 
 typedef unsigned __int128 u128;
 
@@ -513,28 +514,40 @@ void orc_witness_map_plain(uint64_t *a, uint64_t *b, uint64_t *c, unsigned log_d
  * Same values as the serial functions above; OpenMP tasks over independent pieces: the windows of an MSM (the
  * reference's `parallel` feature, variable_base.rs:33-37), the butterflies of one NTT stage, the independent a / b / c
  * chains and share lanes of the witness map, and the MSMs of a proof. */
-#include <omp.h>
-static void orc_io_helper_par(fr_t *x, size_t n, const fr_t *roots) {
+/* `tw`: per-stage compacted roots -- the stage with butterfly span `gap` reads tw[gap - 1 + k] = root^(k * (n/2) / gap), k < gap
+ * (what the serial code obtains by compacting its root vector after every stage, fft.rs:194-200): contiguous reads */
+static fr_t *orc_stage_roots_par(size_t n, const fr_t *root) {
+    fr_t *roots = orc_roots(n / 2, root);
+    fr_t *tw = (fr_t *)malloc((n ? n : 1) * sizeof(fr_t));
     for (size_t gap = n / 2; gap > 0; gap /= 2) {
         const size_t stride = (n / 2) / gap;
+#pragma omp taskloop grainsize(65536)
+        for (size_t k = 0; k < gap; k++) tw[gap - 1 + k] = roots[k * stride];
+    }
+    free(roots);
+    return tw;
+}
+static void orc_io_helper_par(fr_t *x, size_t n, const fr_t *tw) {
+    for (size_t gap = n / 2; gap > 0; gap /= 2) {
+        const fr_t *ts = tw + gap - 1;
 #pragma omp taskloop grainsize(16384)
         for (size_t t = 0; t < n / 2; t++) {
             size_t base = (t / gap) * 2 * gap, k = t % gap;
             fr_t *lo = &x[base + k], *hi = &x[base + gap + k], neg;
             fr_sub(&neg, lo, hi);
             fr_add(lo, lo, hi);
-            fr_mul(hi, &neg, &roots[k * stride]);
+            fr_mul(hi, &neg, &ts[k]);
         }
     }
 }
-static void orc_oi_helper_par(fr_t *x, size_t n, const fr_t *roots) {
+static void orc_oi_helper_par(fr_t *x, size_t n, const fr_t *tw) {
     for (size_t gap = 1; gap < n; gap *= 2) {
-        const size_t nchunks = n / (2 * gap);
+        const fr_t *ts = tw + gap - 1;
 #pragma omp taskloop grainsize(16384)
         for (size_t t = 0; t < n / 2; t++) {
             size_t base = (t / gap) * 2 * gap, k = t % gap;
             fr_t *lo = &x[base + k], *hi = &x[base + gap + k], neg;
-            fr_mul(hi, hi, &roots[nchunks * k]);
+            fr_mul(hi, hi, &ts[k]);
             fr_sub(&neg, lo, hi);
             fr_add(lo, lo, hi);
             *hi = neg;
@@ -554,6 +567,14 @@ static void orc_scale_powers_par(fr_t *x, size_t n, const fr_t *g, const fr_t *c
         for (size_t i = s * CH; i < end; i++) { fr_mul(&x[i], &x[i], &pw); fr_mul(&pw, &pw, g); }
     }
 }
+static void orc_derange_par(fr_t *x, size_t n, unsigned log_n) {
+#pragma omp taskloop grainsize(65536)
+    for (uint64_t idx = 1; idx < n - 1; idx++) {
+        uint64_t r = 0, t = idx;
+        for (unsigned b = 0; b < log_n; b++) { r = (r << 1) | (t & 1); t >>= 1; }
+        if (idx < r) { fr_t tmp = x[idx]; x[idx] = x[r]; x[r] = tmp; }   /* each pair is swapped by its smaller index only */
+    }
+}
 static void orc_ntt_fr_par(fr_t *x, unsigned log_d, int kind, const orc_domain_t *d, const fr_t *roots_fwd, const fr_t *roots_inv) {
     size_t n = (size_t)1 << log_d;
     fr_t one;
@@ -561,9 +582,9 @@ static void orc_ntt_fr_par(fr_t *x, unsigned log_d, int kind, const orc_domain_t
     if (kind == ORC_COSET_FFT) orc_scale_powers_par(x, n, &d->generator, &one);
     if (kind == ORC_FFT || kind == ORC_COSET_FFT) {
         orc_io_helper_par(x, n, roots_fwd);
-        orc_derange(x, n, log_d);
+        orc_derange_par(x, n, log_d);
     } else {
-        orc_derange(x, n, log_d);
+        orc_derange_par(x, n, log_d);
         orc_oi_helper_par(x, n, roots_inv);
         if (kind == ORC_IFFT) orc_scale_powers_par(x, n, &one, &d->size_inv);
         else orc_scale_powers_par(x, n, &d->generator_inv, &d->size_inv);
@@ -582,10 +603,14 @@ void orc_groth16_local_par(unsigned log_d, size_t N, size_t lanes, uint64_t *a, 
     orc_domain_constants(log_d, consts);
     fr_t zinv;
     memcpy(zinv.l, consts + 20, 32);
-    fr_t *roots_fwd = orc_roots(D / 2, &d.group_gen), *roots_inv = orc_roots(D / 2, &d.group_gen_inv);
+    fr_t *roots_fwd = orc_stage_roots_par(D, &d.group_gen), *roots_inv = orc_stage_roots_par(D, &d.group_gen_inv);   /* (outside a parallel region: built serially) */
     uint64_t *wit_r = (uint64_t *)malloc(lanes * N * 32), *asg_r = (uint64_t *)malloc(lanes * (N + 1) * 32);
     uint64_t *h_r = (uint64_t *)malloc(lanes * D * 32);
     if (threads > 0) omp_set_num_threads(threads);
+    /* one bucket arena per thread, sized for the largest window (G2, c = window width of the longest MSM) */
+    size_t cmax = (size_t)(orc_log2(D) * 69 / 100) + 2;
+    size_t stride = ((((size_t)1 << cmax) * sizeof(g2_jac_t)) + 4095) & ~(size_t)4095;
+    char *arena = (char *)malloc(stride * (size_t)omp_get_max_threads());
 #pragma omp parallel
 #pragma omp single
     {
@@ -616,7 +641,7 @@ void orc_groth16_local_par(unsigned log_d, size_t N, size_t lanes, uint64_t *a, 
 #pragma omp taskloop grainsize(16384)
                     for (size_t i = 0; i < D; i++) fr_into_repr(h_r + 4 * (ln * D + i), &la[i]);
                     g1_jac_t r;
-                    g1_msm_pippenger_par(&r, (const g1_aff_t *)h_q, inf0, h_r + 4 * ln * D, D - 1);
+                    g1_msm_pippenger_par(&r, (const g1_aff_t *)h_q, inf0, h_r + 4 * ln * D, D - 1, arena, stride);
                     memcpy(lo, &r, sizeof r);
                 }
 #pragma omp task
@@ -628,19 +653,19 @@ void orc_groth16_local_par(unsigned log_d, size_t N, size_t lanes, uint64_t *a, 
 #pragma omp taskgroup
                     {
 #pragma omp task
-                        { g2_jac_t r; g2_msm_pippenger_par(&r, (const g2_aff_t *)b2_q, inf_b, asg_r + 4 * ln * (N + 1), N + 1); memcpy(lo + 72, &r, sizeof r); }
+                        { g2_jac_t r; g2_msm_pippenger_par(&r, (const g2_aff_t *)b2_q, inf_b, asg_r + 4 * ln * (N + 1), N + 1, arena, stride); memcpy(lo + 72, &r, sizeof r); }
 #pragma omp task
-                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)l_q, inf0, wit_r + 4 * ln * N, N); memcpy(lo + 18, &r, sizeof r); }
+                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)l_q, inf0, wit_r + 4 * ln * N, N, arena, stride); memcpy(lo + 18, &r, sizeof r); }
 #pragma omp task
-                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)a_q, inf0, asg_r + 4 * ln * (N + 1), N + 1); memcpy(lo + 36, &r, sizeof r); }
+                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)a_q, inf0, asg_r + 4 * ln * (N + 1), N + 1, arena, stride); memcpy(lo + 36, &r, sizeof r); }
 #pragma omp task
-                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)b1_q, inf_b, asg_r + 4 * ln * (N + 1), N + 1); memcpy(lo + 54, &r, sizeof r); }
+                        { g1_jac_t r; g1_msm_pippenger_par(&r, (const g1_aff_t *)b1_q, inf_b, asg_r + 4 * ln * (N + 1), N + 1, arena, stride); memcpy(lo + 54, &r, sizeof r); }
                     }
                 }
             }
         }
     }
-    free(roots_fwd); free(roots_inv); free(wit_r); free(asg_r); free(h_r);
+    free(roots_fwd); free(roots_inv); free(wit_r); free(asg_r); free(h_r); free(arena);
 }
 int orc_max_threads(void) { return omp_get_max_threads(); }
 /* input generation for the CPU baseline: n distinct subgroup points (see ec_tmpl.h chain_points) */

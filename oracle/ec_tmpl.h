@@ -183,7 +183,7 @@ static void EC(msm_pippenger)(EC(jac_t) *out, const EC(aff_t) *bases, const uint
  * (variable_base.rs:33-37 `cfg_into_iter!(window_starts)`).  OpenMP tasks, so it composes with other tasks of an
  * enclosing parallel region; called outside one it runs serially. */
 static void EC(msm_pippenger_par)(EC(jac_t) *out, const EC(aff_t) *bases, const uint8_t *inf,
-                                  const uint64_t *scalars, size_t size) {
+                                  const uint64_t *scalars, size_t size, char *thread_scratch, size_t scratch_stride) {
     size_t c = size < 32 ? 3 : (size_t)(orc_log2(size) * 69 / 100) + 2;
     const size_t num_bits = 253;
     const uint64_t fr_one[4] = {1, 0, 0, 0};
@@ -192,7 +192,12 @@ static void EC(msm_pippenger_par)(EC(jac_t) *out, const EC(aff_t) *bases, const 
     EC(jac_t) *window_sums = (EC(jac_t) *)malloc(n_windows * sizeof(EC(jac_t)));
 #pragma omp taskloop grainsize(1) shared(window_sums)
     for (size_t w = 0; w < n_windows; w++) {
-        EC(jac_t) *buckets = (EC(jac_t) *)malloc(n_buckets * sizeof(EC(jac_t)));
+        /* bucket arrays come from a per-thread arena allocated once by the caller: 128 threads each malloc-ing and first-touching
+         * ~10-20 MB per window serialise on the process's page-table lock */
+        EC(jac_t) *buckets = thread_scratch && n_buckets * sizeof(EC(jac_t)) <= scratch_stride
+                                 ? (EC(jac_t) *)(thread_scratch + scratch_stride * (size_t)omp_get_thread_num())
+                                 : (EC(jac_t) *)malloc(n_buckets * sizeof(EC(jac_t)));
+        const int own = !(thread_scratch && n_buckets * sizeof(EC(jac_t)) <= scratch_stride);
         size_t w_start = w * c;
         EC(jac_t) res;
         EC(jac_zero)(&res);
@@ -217,7 +222,7 @@ static void EC(msm_pippenger_par)(EC(jac_t) *out, const EC(aff_t) *bases, const 
             EC(jac_add)(&res, &running);
         }
         window_sums[w] = res;
-        free(buckets);
+        if (own) free(buckets);
     }
     EC(jac_t) total;
     EC(jac_zero)(&total);

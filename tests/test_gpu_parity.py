@@ -726,3 +726,31 @@ def test_mixed_radix_ntt_plonk_wire_domain_and_errors(ctx, czk, orc):
     buf = y.copy()
     ctx.ntt_fr_mixed(buf, 64, czk.CZK_COSET_FFT)
     assert np.array_equal(buf, orc.ntt_fr(y, 6, orc.COSET_FFT))
+
+
+@pytest.mark.parametrize("rounds", [1, 3])
+def test_msm_batched_affine_rounds_still_match(czk, orc, monkeypatch, rounds):
+    """The opt-in batched-affine pre-reduction of the bucket lists (csrc/msm_aff.h, CZK_MSM_AFFINE=R; measured slower than the XYZZ
+    kernel and therefore off by default -- profiles/r02_affine_prototype.json) computes the same group elements: checker's
+    Pippenger at n = 4096 with zero / unit scalars and infinity bases, equal and opposite points in one bucket, 4 lanes."""
+    monkeypatch.setenv("CZK_MSM_AFFINE", str(rounds))
+    c = czk.Context(0)
+    n = 4096
+    k = rand_fr_canonical(77, n)
+    bases = c.fixed_base_points(1, k)
+    bases[10] = bases[11]                                   # equal points meeting in one bucket (same scalar below)
+    bases[20, 6:] = orc.fq_neg(bases[21, 6:].reshape(1, 6))[0]   # -P next to P
+    bases[20, :6] = bases[21, :6]
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[5] = 1
+    s = rand_fr_canonical(78, 4 * n).reshape(4, n, 4)
+    s[:, 11] = s[:, 10]
+    s[:, 21] = s[:, 20]
+    s[0, 7] = 0
+    s[1, 8] = (1, 0, 0, 0)
+    b = c.register_bases(1, bases, inf)
+    out = c.msm(b, s, lanes=4)
+    for ln in range(4):
+        assert _same_point(c, orc, 1, out[ln], orc.msm(1, bases, inf, s[ln])), (rounds, ln)
+    b.release()
+    c.close()
