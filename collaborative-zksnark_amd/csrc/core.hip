@@ -204,7 +204,10 @@ extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
         c->own_stream = true;
     }
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cu = prop.multiProcessorCount;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->num_cu = prop.multiProcessorCount;
+        c->lds_per_block = prop.sharedMemPerBlock;
+    }
     *out = c;
     return CZK_OK;
 }

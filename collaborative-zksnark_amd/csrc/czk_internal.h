@@ -99,6 +99,7 @@ struct czk_ctx {
     czk::DeviceBuf poly_scratch;  // segment sums of czk_poly_div_linear (poly.hip)
     czk::DeviceBuf share_tab;     // size_inv * w^(-jk) table of czk_fr_gsz_open (share.hip)
     int num_cu = 256;
+    size_t lds_per_block = 64 * 1024;   // hipDeviceProp_t::sharedMemPerBlock (gfx950: 160 KiB)
 };
 
 struct czk_bases {

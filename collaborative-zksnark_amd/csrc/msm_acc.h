@@ -269,8 +269,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     xyzz_store<Fq>(buckets + (size_t)24 * ((size_t)lane * B + b), out);
 }
 
-// recomputes the buckets k_accumulate_u gave up on, in the saturated residue system (points converted on the fly)
-__global__ __launch_bounds__(128) void k_accumulate_u_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+// recomputes the buckets k_accumulate_u gave up on, in the saturated residue system (points converted on the fly).
+// (<= 128 VGPRs like the over-full-bucket kernels: normally no bucket is dirty and every block returns at once, but at ~250 VGPRs
+// each of its blocks had to wait for a drained SIMD next to the accumulate kernels -- 2.3 ms on average, 11.6 ms worst case, per
+// empty launch in the pipeline: profiles/r02_kernel_trace_stats.txt)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_u_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                          size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     xyzz_store<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), out);
 }
 
-__global__ __launch_bounds__(128) void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                           size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;

@@ -8,7 +8,8 @@
 //
 // Design (MI355X-first, not the reference's stage-by-stage sweep over DRAM):
 //   * log2 D stages are split into ceil(n/7) passes; a pass keeps a (2^K rows x T columns) tile of Fr in
-//     LDS (K<=7, T<=16: 64 KiB -> 2 workgroups per CU) and runs its K decimation-in-frequency stages there,
+//     LDS (K<=7, T<=16: 64 KiB, 68.5 KiB for the padded last pass at K = 7 -- within gfx950's 160 KiB per CU for two workgroups;
+//     checked against the device at launch) and runs its K decimation-in-frequency stages there,
 //     so a 2^21 transform touches HBM 3 times instead of 21 (+ a separate bit-reversal sweep).
 //   * strided passes read/write T consecutive elements per row (512 B runs); the last pass owns T contiguous
 //     2^K chunks whose bit-reversed chunk ids are consecutive, so its transposed store is the bit-reversal
@@ -460,6 +461,7 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
             }
             unsigned blocks = (unsigned)(D >> (a.K + a.logT));
             size_t lds = ((((size_t)1 << a.K) + 1) << a.logT) * 32 + ((size_t)1 << a.K) * 32;
+            if (lds > ctx->lds_per_block) return set_err(ctx, CZK_ERR_HIP, "NTT last pass needs more LDS per workgroup than this device offers");
             hipLaunchKernelGGL(k_ntt_final, dim3(blocks, (unsigned)lanes), dim3(256), lds, ctx->stream, a);
         }
         CZK_HIP(ctx, hipGetLastError());

@@ -332,6 +332,11 @@ int launch_ntt2_pass(czk_ctx* ctx, const Pass2Args& a, unsigned K, bool last, si
     const size_t D = (size_t)1 << a.n;
     const unsigned blocks = (unsigned)(D >> (K + NTT2_LOGT));
     const dim3 grid(blocks, (unsigned)lanes), block((1u << K) * 2);
+    // a 7-stage tile is 9 limb planes x 2048 words = 72 KiB (73.5 KiB with the row padding of the last pass): two workgroups per
+    // CU out of gfx950's 160 KiB.  Checked against the device rather than assumed.
+    const size_t lds_need = last ? (size_t)9 * (((size_t)1 << K) + 1) * NTT2_T * 4 : (size_t)9 * ((size_t)1 << (K + NTT2_LOGT)) * 4;
+    if (lds_need > ctx->lds_per_block)
+        return set_err(ctx, CZK_ERR_HIP, "NTT pass needs " + std::to_string(lds_need) + " bytes of LDS per workgroup; this device offers " + std::to_string(ctx->lds_per_block));
     if (!last) {
         const size_t lds = (size_t)9 * ((size_t)1 << (K + NTT2_LOGT)) * 4;
         if (a.first || !NTT2_LAZY_SCRATCH) {

@@ -754,3 +754,20 @@ def test_msm_batched_affine_rounds_still_match(czk, orc, monkeypatch, rounds):
         assert _same_point(c, orc, 1, out[ln], orc.msm(1, bases, inf, s[ln])), (rounds, ln)
     b.release()
     c.close()
+
+
+def test_ntt_first_generation_passes_still_match(czk, orc, monkeypatch):
+    """CZK_NTT_GEN1=1 keeps the first-generation passes (ntt.hip) for every size -- the A/B switch behind the figures in
+    profiles/r02_pmc_ntt.json; they serve the domains below 2^11 by default.  Bit-exact at sizes that exercise their 6- and
+    7-stage tiles (2^13, 2^14) and all four kinds."""
+    monkeypatch.setenv("CZK_NTT_GEN1", "1")
+    c = czk.Context(0)
+    for log_d in (13, 14):
+        d = 1 << log_d
+        x = orc.fr_from_repr(rand_fr_canonical(900 + log_d, 2 * d)).reshape(2, d, 4)
+        for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+            buf = x.copy()
+            c.ntt_fr(buf, log_d, kind, lanes=2)
+            for ln in range(2):
+                assert np.array_equal(buf[ln], orc.ntt_fr(x[ln], log_d, kind)), (log_d, kind, ln)
+    c.close()
