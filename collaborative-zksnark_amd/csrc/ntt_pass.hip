@@ -72,6 +72,56 @@ __device__ __forceinline__ void radix4(FrU* x, const FrU* tw) {
     x[2] = fru_normalize(x[2]);
 }
 
+// The LAST step of a transform (stage bits 1, 0 or 2, 1, 0): the twiddle of stage 0 is w^0 = 1 and so is every stage's entry
+// j = 0, i.e. 3 of the 4 (7 of the 12) multiplies of a group would multiply by one.  They are left out: the difference stays a
+// lazy value (no Montgomery product to bring it below 2 r), so ALL outputs are re-normalised instead of half of them, and the
+// bounds become (units of r, KB = bound of the inputs, real inputs <= KB / 2 + 0.1):
+//   radix-4: d02 < 1.5 KB;  x0 < 2 KB;  x1 = s02 - x1 + 2 KB r < 3 KB + 0.2;  x2, x3 < 1.5 KB + 2      -> max 192.2 at KB = 64
+//   radix-8: x1 = x0 - x1 + 4 KB r < 6 KB + 0.1 = 96.1 at KB = 16, everything else below              (< 220: fru_mul's limit
+//   for the post-scale multiply; < 256: fru_canon's).  Limbs stay below 3.5 * 2^30 before the normalisation.
+// tw1 = the stage-1 twiddle of index 1 (the primitive fourth root); tw2[1..4) = stage-2 twiddles of index 1..3.
+template <int KB>
+__device__ __forceinline__ void radix4_last(FrU* x, const FrU& tw1) {
+    const FrU d02 = fru_sub<KB, 1>(x[0], x[2]);
+    const FrU s02 = fru_add(x[0], x[2]);
+    bfly<KB, 1>(x[1], x[3], tw1);
+    x[0] = fru_normalize(fru_add(s02, x[1]));
+    x[1] = fru_normalize(fru_sub<2 * KB, 2>(s02, x[1]));
+    x[2] = fru_normalize(fru_add(d02, x[3]));
+    x[3] = fru_normalize(fru_sub<2, 1>(d02, x[3]));
+}
+template <int KB>
+__device__ __forceinline__ void radix8_last(FrU* x, const FrU* tw2, const FrU& tw1) {
+    const FrU d04 = fru_sub<KB, 1>(x[0], x[4]);
+    x[0] = fru_add(x[0], x[4]);
+#pragma unroll
+    for (int k = 1; k < 4; k++) bfly<KB, 1>(x[k], x[k + 4], tw2[k]);
+    // stage 1: pairs (0, 2) and (4, 6) have the unit twiddle
+    const FrU d = fru_sub<2 * KB, 2>(x[0], x[2]);
+    x[0] = fru_add(x[0], x[2]);
+    x[2] = d;
+    bfly<2 * KB, 2>(x[1], x[3], tw1);
+    const FrU e = fru_sub<2, 1>(d04, x[6]);
+    x[4] = fru_add(d04, x[6]);
+    x[6] = e;
+    bfly<2, 1>(x[5], x[7], tw1);
+    // stage 0: unit twiddles only
+    x[0] = fru_normalize(x[0]);
+    x[1] = fru_normalize(x[1]);
+    const FrU s01 = fru_add(x[0], x[1]);
+    x[1] = fru_normalize(fru_sub<4 * KB, 1>(x[0], x[1]));
+    x[0] = fru_normalize(s01);
+    const FrU s23 = fru_add(x[2], x[3]);
+    x[3] = fru_normalize(fru_sub<2, 1>(x[2], x[3]));
+    x[2] = fru_normalize(s23);
+    const FrU s45 = fru_add(x[4], x[5]);
+    x[5] = fru_normalize(fru_sub<4, 2>(x[4], x[5]));
+    x[4] = fru_normalize(s45);
+    const FrU s67 = fru_add(x[6], x[7]);
+    x[7] = fru_normalize(fru_sub<2, 1>(x[6], x[7]));
+    x[6] = fru_normalize(s67);
+}
+
 constexpr unsigned NTT2_LOGT = 4, NTT2_T = 16;
 
 // LDS: 9 limb planes of NE words
@@ -244,7 +294,17 @@ __device__ __forceinline__ void final_step(const Pass2Args& a, u32* smem, const 
             if constexpr (FROM_GLOBAL) x[k] = load_input<NTT2_LAZY_SCRATCH>(a, in, (h << C) | l);
             else x[k] = lds_get9<NEL>(smem, t * RS + l);
         }
-        if constexpr (RB == 3) {
+        if constexpr (B0 == 0 && !NTT2_LAZY_SCRATCH) {   // the transform's last stages: unit twiddles are not multiplied (radix*_last)
+            const u32* tw_s1 = a.tw + 9 * 1;             // stage 1: entries 1, 2 of the compacted table = w_4^0, w_4^1
+            if constexpr (RB == 3) {
+                FrU tw2[4];
+#pragma unroll
+                for (int k = 1; k < 4; k++) tw2[k] = tab_load(a.tw + 9 * 3, k);
+                radix8_last<KB>(x, tw2, tab_load(tw_s1, 1));
+            } else {
+                radix4_last<KB>(x, tab_load(tw_s1, 1));
+            }
+        } else if constexpr (RB == 3) {
             FrU tw[7];
 #pragma unroll
             for (int k = 0; k < 4; k++) tw[k] = tab_load(a.tw + 9 * (((size_t)1 << (B0 + 2)) - 1), l_below | ((unsigned)k << B0));
