@@ -20,6 +20,7 @@ checked against [sum_i k_i s_i] G computed on the host from the known discrete l
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -320,24 +321,59 @@ def verify_openings(czk, ctx, B, out) -> dict:
             "results_check": "every KZG opening verified on the host against its commitment with the synthetic SRS's known tau"}
 
 
+def _polyiop_party_digests(out, lanes_total: int, parties: int, only=None):
+    """One SHA-256 per party over its lanes of every commitment / evaluation / opening (public, single-lane entries are part
+    of every party's digest): the party-per-rank layout must reproduce the all-lanes-on-one-GPU layout party by party."""
+    per = lanes_total // parties
+
+    def walk(h, x, sel):
+        if isinstance(x, dict):
+            for k in sorted(x):
+                h.update(str(k).encode())
+                walk(h, x[k], sel)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                walk(h, v, sel)
+        elif isinstance(x, np.ndarray):
+            h.update(np.ascontiguousarray(sel(x)).tobytes())
+        else:
+            h.update(repr(x).encode())
+    digests = []
+    for p in (range(parties) if only is None else [only]):
+        h = hashlib.sha256()
+        walk(h, out, (lambda a: a) if only is not None else (lambda a, p=p: a[p * per:(p + 1) * per] if a.ndim and a.shape[0] == lanes_total else a))
+        digests.append(h.hexdigest())
+    return digests
+
+
 def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     import torch
     from czk_amd import polyvm
-    if args.layout != "replica":
-        raise SystemExit("--workload plonk / marlin: replica layout only (all parties' lanes on each GPU; opens are lane-local)")
     plonk = args.workload == "plonk"
+    party = args.layout == "party"
+    per_party = 1 if plonk else 2                                          # GSZ: one lane per party; SPDZ: sh + mac
     if plonk:
-        lanes, lift = args.parties, None                                   # GSZ: one lane per party, public addends on every lane
+        lanes = per_party if party else args.parties
+        lift = None                                                        # public addends on every lane
         max_deg = polyvm.plonk_max_degree(n)
         make_inputs, prove = (lambda B: polyvm.plonk_inputs(B, n)), polyvm.plonk_prove
         scheme, what = "GSZ", f"mpc-plonk Prover::prove, {n} gates (wire domain 3 x {size_txt}, mixed radix)"
     else:
-        lanes, lift = 2 * args.parties, tuple([1, 1] + [0] * (2 * args.parties - 2))   # SPDZ: sh + mac per party; public addends on the king's lanes
+        lanes = per_party if party else 2 * args.parties
+        king = (1, 1) if rank == 0 else (0, 0)                             # public addends on the king's lanes only
+        lift = king if party else tuple([1, 1] + [0] * (2 * args.parties - 2))
         max_deg = polyvm.marlin_max_degree(n)
         make_inputs, prove = (lambda B: polyvm.marlin_inputs(B, n)), polyvm.marlin_prove
         scheme, what = "SPDZ", f"Marlin AHP rounds + commitments + batched openings, {n} constraints"
     t0 = time.time()
     B = polyvm.GpuBackend(czk, ctx, lanes, max_deg, lift=lift)
+    if party:
+        # one party per rank: every batch of evaluations made between two challenges is opened over torch.distributed
+        if plonk:
+            B.opener = lambda bk, v: parallel.gsz_batch_open(ctx, v[:, 0].contiguous(), degree=(args.parties - 1) // 2)   # t = (n - 1) / 2 (share/gsz20/mod.rs:94-96)
+        else:
+            mac_share = polyvm.mont(1 if rank == 0 else 0)
+            B.opener = lambda bk, v: parallel.spdz_batch_open(ctx, v[:, 0].contiguous(), v[:, 1].contiguous(), mac_share, commit=args.commit_opens)
     inp = make_inputs(B)                                            # circuit / index and share lanes: resident in HBM before the timed region
     ctx.sync()
     setup_s = time.time() - t0
@@ -351,6 +387,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     for _ in range(max(0, args.warmup - 1)):
         prove(B, inp)
     B.msm_count = B.ntt_count = B.msm_points = 0
+    B.opened = []
     ctx.profile_reset()
     ctx.profile_enable(True)
     barrier()
@@ -363,24 +400,41 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     ctx.profile_enable(False)
     dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
     checked = {"results_checked": False} if args.no_result_check else verify_openings(czk, ctx, B, out)
+    if party:
+        mine = _polyiop_party_digests(out, lanes, 1, only=0)[0]
+        got = [None] * world
+        torch.distributed.all_gather_object(got, (mine, bool(checked["results_checked"])))
+        digests = [g[0] for g in got]
+        checked["results_checked"] = all(g[1] for g in got) if not args.no_result_check else False
+        opened_batches = len(B.opened) // max(1, args.steps)
+    else:
+        digests = _polyiop_party_digests(out, lanes, args.parties)
+        opened_batches = 0
+    digest = hashlib.sha256("".join(digests).encode()).hexdigest()
+    proofs = args.steps if party else world * args.steps             # party layout: all ranks work on the same proof
     acc_ms, acc_n = ctx.profile_read("msm_accumulate_g1")
     breakdown = {k: ctx.profile_read(k)[0] / max(1, args.steps) for k in ("ntt_pass", "ntt_mixed", "msm_sort", "msm_accumulate_g1", "msm_reduce")}
     pts = B.msm_points / max(1, args.steps)                       # (point, lane) pairs per proof
     alg_bytes = pts * 32 + (B.msm_points / max(1, B.msm_count) * 96) * (B.msm_count / lanes / max(1, args.steps))   # scalars per lane + bases once per MSM
     achieved = alg_bytes * args.steps / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
+    where = (f"one party per GPU ({lanes} share lane{'s' if lanes > 1 else ''} each); evaluations opened over torch.distributed "
+             f"({'GSZ batch_open' if plonk else 'SPDZ two-round batch_open'}, {opened_batches} batches per proof)") if party else \
+            f"{scheme} {args.parties} parties as {lanes} share lanes on one GPU"
     res = {
         "metric": f"collaborative {'Plonk' if plonk else 'Marlin'} proofs/sec (BLS12-377, {size_txt} constraints, {scheme} N={args.parties})",
-        "value": world * args.steps / dt, "unit": "proofs/s", "n_gpus": world, "ranks_seen_by_backend": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "first_proof_ms": first_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "ranks_seen_by_backend": world, "backend": args.backend if world > 1 else None,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "first_proof_ms": first_ms, "higher_is_better": True, "scaling": "strong" if party else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic", **checked,
-        "config": {"workload": f"{what}; {scheme} {args.parties} parties as {lanes} share lanes on one GPU; synthetic circuit / index and SRS, fixed "
-                               "Fiat-Shamir challenges (collaborative-zksnark_amd/polyvm.py)",
-                   "constraints": n, "parties": args.parties, "share_lanes": lanes, "layout": "replica",
+        "config": {"workload": f"{what}; {where}; synthetic circuit / index and SRS, fixed Fiat-Shamir challenges, commitments / evaluations settled at "
+                               "every point where the reference's transcript draws a challenge (collaborative-zksnark_amd/polyvm.py)",
+                   "constraints": n, "parties": args.parties, "share_lanes": lanes, "layout": args.layout, "results_sha256": digest,
                    "ntt_lanes_per_proof": B.ntt_count / max(1, args.steps), "msms_per_proof": B.msm_count / max(1, args.steps),
                    "msm_point_lanes_per_proof": pts},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
-                     "note": "integer-VALU bound; MSMs here are blocking single calls (one per commitment / opening), not the pipelined Groth16 sequence"},
+                     "note": "integer-VALU bound; the commitments between two transcript points are enqueued asynchronously (czk_msm_async), so their sort / "
+                             "accumulate / reduce stages overlap each other and the NTTs that follow"},
         "breakdown_ms_per_step": breakdown, "setup_srs_s": setup_s,
     }
     if rank == 0:

@@ -43,6 +43,27 @@ def challenge(tag: str) -> int:
     return int.from_bytes(hashlib.sha256(tag.encode()).digest(), "little") % R_MOD
 
 
+class Pending:
+    """A commitment or an evaluation whose kernels are still in flight (GpuBackend): `.value` is filled by the next
+    Backend.transcript_point()."""
+    __slots__ = ("value", "_src")
+
+    def __init__(self, src):
+        self.value, self._src = None, src
+
+
+def resolved(x):
+    """x with every Pending replaced by its value (dicts, lists and tuples are walked)."""
+    if isinstance(x, Pending):
+        assert x.value is not None, "Pending read before a transcript_point()"
+        return x.value
+    if isinstance(x, dict):
+        return {k: resolved(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(resolved(v) for v in x)
+    return x
+
+
 class Backend:
     """Arrays are (lanes, n, 4) Fr limbs (Montgomery).  Public data has lanes == 1.  Public * shared scales every lane; public
     +- shared is the reference's `shift`: the public operand is added on the lanes listed in `lift` only (GSZ: every lane, a
@@ -148,6 +169,20 @@ class Backend:
         self.reveal(value)
         return {"value": value, "proof": self.commit(wit), "point": x}
 
+    def quotient(self, a, x: int):
+        """a / (X - x) without the remainder"""
+        return self.div_linear(a, x)[0]
+
+    def evaluate(self, a, x: int):
+        """a(x) per lane, (lanes, 4) -- the remainder of the division by (X - x)"""
+        return self.div_linear(a, x)[1]
+
+    def transcript_point(self):
+        """Called where the reference feeds commitments / evaluations to its Fiat-Shamir transcript before drawing the next
+        challenge (mpc-plonk/src/lib.rs:110-113, 343-369; marlin/src/lib.rs:206-260): everything committed or evaluated so far
+        must be final.  Backends that run asynchronously settle their pending results here."""
+        return None
+
     def reveal(self, value):
         """`y.publicize()` of an evaluation (mpc-plonk/src/lib.rs:362-365; marlin/src/lib.rs:290): with one party per process the
         share of the value is opened over the network; with all lanes on one GPU there is nothing to exchange."""
@@ -188,7 +223,10 @@ class GpuBackend(Backend):
         self.bases_host = (lambda: pts.cpu().numpy().view(np.uint64))      # for the checker-side backend of the tests
         self.base_seed, self.n_bases = base_seed, n
         self.msm_count = self.ntt_count = 0
-        self.opener = None      # party-per-rank layouts: callable(backend, value (lanes, 4) numpy) running the open over torch.distributed
+        self._pending = []      # commitments / evaluations enqueued since the last transcript_point()
+        self._ring, self._ring_at = None, 0
+        self.opener = None      # party-per-rank layouts: callable(backend, (k, lanes, 4) device tensor) -> opened values, run over torch.distributed
+        self.opened = []        # what the opener returned, in order
         self.msm_points = 0
 
     M = 1   # CZK_MEM_DEVICE
@@ -262,12 +300,29 @@ class GpuBackend(Backend):
     def mul(self, a, b):
         return self._vec(2, a, b)
 
+    def _scalar(self, k):
+        """One field element on the device without blocking the host: a pageable host-to-device copy would wait for everything
+        enqueued so far, so the element goes through a ring of pinned staging slots (re-used after the next synchronisation)."""
+        if self._ring is None or self._ring_at == self._ring.shape[0]:
+            if self._ring is not None:
+                self.ctx.sync()
+            else:
+                self._ring = self.torch.empty((1024, 4), dtype=self.torch.int64).pin_memory()
+            self._ring_at = 0
+        slot = self._ring[self._ring_at]
+        self._ring_at += 1
+        slot.copy_(self.torch.from_numpy(mont(k).view(np.int64)))
+        return slot.to(self.dev, non_blocking=True)
+
     def scale(self, a, k):
         a = a.contiguous()
         out = self.torch.empty_like(a)
-        kd = self.torch.from_numpy(mont(k).view(np.int64)).to(self.dev)     # device memory mode: the scalar is read from the device too
+        kd = self._scalar(k)                                                # device memory mode: the scalar is read from the device too
         self.ctx.fr_vec_scale(a.data_ptr(), kd.data_ptr(), out=out.data_ptr(), n=a.shape[0] * a.shape[1], mem=self.M)
         return out
+
+    def const(self, k, n):
+        return self._scalar(k).reshape(1, 1, 4).expand(1, n, 4).contiguous()
 
     def powers(self, g, n):
         out = self.torch.empty((1, n, 4), dtype=self.torch.int64, device=self.dev)
@@ -280,14 +335,26 @@ class GpuBackend(Backend):
         self.ntt_count += buf.shape[0]
         return buf
 
-    def div_linear(self, a, z):
+    def _div_linear_dev(self, a, z):
         a = a.contiguous()
         lanes, n = a.shape[0], a.shape[1]
         q = self.torch.empty((lanes, max(n - 1, 0), 4), dtype=self.torch.int64, device=self.dev)
         rem = self.torch.empty((lanes, 4), dtype=self.torch.int64, device=self.dev)
         self.ctx.poly_div_linear(a.data_ptr(), mont(z), lanes=lanes, n=n, quotient=q.data_ptr(), remainder=rem.data_ptr(), mem=self.M)
+        return q, rem
+
+    def div_linear(self, a, z):
+        q, rem = self._div_linear_dev(a, z)
         self.ctx.sync()
         return q, rem.cpu().numpy().view(np.uint64)
+
+    def quotient(self, a, x):
+        return self._div_linear_dev(a, x)[0]
+
+    def evaluate(self, a, x):
+        p = Pending(("open_value", self._div_linear_dev(a, x)[1]))      # evaluations are publicized too (marlin/src/lib.rs:283-292)
+        self._pending.append(p)
+        return p
 
     def prefix_product(self, a):
         a = a.contiguous()
@@ -312,18 +379,54 @@ class GpuBackend(Backend):
     def root_of_unity(self, size):
         return unmont(self.ctx.mixed_domain_constants(size)["group_gen"])
 
-    def reveal(self, value):
-        if self.opener is not None:
-            self.opener(self, value)
-
     def commit(self, a):
+        """Enqueues the MSM (czk_msm_async: the sort / accumulate / reduce stages of consecutive commitments overlap on the
+        library's streams, and with the NTTs enqueued after them) and returns a Pending; transcript_point() settles it."""
         a = a.contiguous()
         n = a.shape[1]
         assert n <= self.n_bases, "polynomial longer than powers_of_g"
-        jac = self.ctx.msm(self.bases, a.data_ptr(), n_scalars=n, lanes=a.shape[0], scalar_form=self.czk.CZK_SCALAR_MONTGOMERY, mem=self.M)
+        jac = np.zeros((a.shape[0], 18), dtype=np.uint64)
+        self.ctx.msm_async(self.bases, a.data_ptr(), n_scalars=n, lanes=a.shape[0], scalar_form=self.czk.CZK_SCALAR_MONTGOMERY, out=jac)
         self.msm_count += a.shape[0]
         self.msm_points += a.shape[0] * n
-        return self.ctx.jac_to_affine(self.czk.CZK_G1, jac)
+        p = Pending(("commit", jac, a))       # `a` stays referenced until the MSM has read it
+        self._pending.append(p)
+        return p
+
+    def open_at(self, a, x):
+        wit, rem = self._div_linear_dev(a, x)
+        v = Pending(("open_value", rem))
+        self._pending.append(v)
+        return {"value": v, "proof": self.commit(wit), "point": x}
+
+    def transcript_point(self):
+        if not self._pending:
+            return
+        self.ctx.sync()
+        self._ring_at = 0
+        commits = [p for p in self._pending if p._src[0] == "commit"]
+        if commits:                                                    # one conversion to affine for all of them
+            aff, inf = self.ctx.jac_to_affine(self.czk.CZK_G1, np.concatenate([p._src[1] for p in commits]))
+            at = 0
+            for p in commits:
+                k = p._src[1].shape[0]
+                p.value = (aff[at:at + k].copy(), inf[at:at + k].copy())
+                at += k
+        values = [p for p in self._pending if p._src[0] != "commit"]
+        if values:
+            host = self.torch.cat([p._src[1] for p in values]).cpu().numpy().view(np.uint64)
+            at = 0
+            for p in values:
+                k = p._src[1].shape[0]
+                p.value = host[at:at + k].copy()
+                at += k
+            opened = [p._src[1] for p in values if p._src[0] == "open_value"]
+            if opened and self.opener is not None:
+                # `y.publicize()` of every evaluation made since the last challenge, as ONE batch_open over the parties
+                self.opened.append(self.opener(self, self.torch.stack(opened)))       # (k, lanes, 4)
+        for p in self._pending:
+            p._src = None
+        self._pending = []
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -369,8 +472,9 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
 
     commit("p", p)                                                             # :434-441
     # prove_public (:259-292) with one public wire: v = p(x_pub) constant, z = X - x_pub, q = (p - v) / z
-    q_pub, _y = B.div_linear(p, w)
+    q_pub = B.quotient(p, w)
     commit("pub_q", q_pub)
+    B.transcript_point()
     x = challenge("plonk.public.x")
     open_("pub_q_open", q_pub, x, "pub_q")
     open_("pub_p_open", p, x, "p")
@@ -381,6 +485,7 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
     d = B.sub(_padded_add(B, B.poly_mul(s_pub, B.add(p, pw)), B.poly_mul(one_minus_s, B.poly_mul(p, pw))), B.resized(pww, G + 2 * W - 2))
     q_gates, _r = B.div_vanishing(d, G)
     commit("gates_q", q_gates)
+    B.transcript_point()
     x = challenge("plonk.gates.x")
     open_("gates_s_open", s_pub, x)
     open_("gates_p_open", p, x, "p")
@@ -388,6 +493,7 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
     open_("gates_p_w_open", p, w * x % R_MOD, "p")
     open_("gates_p_w2_open", p, w * w % R_MOD * x % R_MOD, "p")
     # prove_wiring (:201-257) over the wire domain
+    B.transcript_point()
     y, z = challenge("plonk.wiring.y"), challenge("plonk.wiring.z")
     p_evals = B.ntt(p, W, FFT)
     w_evals = B.ntt(w_pub, W, FFT)
@@ -405,6 +511,7 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
     tw_c = B.ntt(B.shift(t, w), W, COSET_FFT)
     q_up = B.ntt(B.scale(B.sub(tw_c, B.mul(f_c, t_c)), zinv_w), W, COSET_IFFT)
     commit("q", q_up)
+    B.transcript_point()
     r = challenge("plonk.product.r")
     open_("t_wr_open", t, w * r % R_MOD, "t")
     open_("t_r_open", t, r, "t")
@@ -417,12 +524,14 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
     den_v = B.ntt(B.ntt(den_evals, W, IFFT), W, COSET_FFT)
     l2_q = B.ntt(B.scale(B.sub(B.mul(l1_v, den_v), num_v), zinv_w), W, COSET_IFFT)
     commit("l2_q", l2_q)
+    B.transcript_point()
     x = challenge("plonk.wiring.x")
     open_("l2_q_x_open", l2_q, x, "l2_q")
     open_("w_x_open", w_pub, x)
     open_("l1_x_open", l1, x, "l1")
     open_("p_x_open", p, x, "p")
-    return out
+    B.transcript_point()
+    return resolved(out)
 
 
 def _padded_add(B, a, b):
@@ -472,9 +581,8 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
         """a + rand * v_H: the zk blinding of the first-round polynomials (prover.rs:359-374); the blinding scalar is a fixed
         constant here.  rand * (X^n - 1) is added share-wise like any public polynomial."""
         rr = challenge("marlin.blind." + tag)
-        bump = np.zeros((n_dom + 1, 4), dtype=np.uint64)
-        bump[0], bump[n_dom] = mont(R_MOD - rr), mont(rr)
-        return B.plus(B.resized(a, n_dom + 1), B.upload(bump))
+        bump = B.concat([B.const(R_MOD - rr, 1), B.zeros(1, n_dom - 1), B.const(rr, 1)])      # rr X^n - rr
+        return B.plus(B.resized(a, n_dom + 1), bump)
     # ---- first round (prover.rs:300-398) -------------------------------------------------------------------
     x_poly = B.ntt(inp["x"], X, IFFT)                                            # public input polynomial (:324-330)
     x_evals = B.ntt(x_poly, H, FFT)
@@ -487,6 +595,7 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     for label, a in (("w", w_poly), ("z_a", z_a), ("z_b", z_b), ("mask_poly", mask_poly)):
         commit(label, a)
     # ---- second round (:439-556) ----------------------------------------------------------------------------
+    B.transcript_point()
     alpha, eta_a, eta_b, eta_c = (challenge("marlin." + t) for t in ("alpha", "eta_a", "eta_b", "eta_c"))
     z_c = B.poly_mul(z_a, z_b)                                                    # shared x shared (:466)
     summed = _padded_add(B, B.scale(z_c, eta_c), B.add(B.scale(z_a, eta_a), B.scale(z_b, eta_b)))   # (:468-476)
@@ -506,6 +615,7 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     for label, a in (("t", t_poly), ("g_1", g_1), ("h_1", h_1)):
         commit(label, a)
     # ---- third round (:585-704): everything public ---------------------------------------------------------------
+    B.transcript_point()
     beta = challenge("marlin.beta")
     vh = vanishing(H, alpha) * vanishing(H, beta) % R_MOD
     etas = {"a": eta_a, "b": eta_b, "c": eta_c}
@@ -535,13 +645,14 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     # ---- openings (marlin/src/lib.rs:262-318 -> PC::open_combinations, poly-commit/src/marlin_pc/mod.rs): every oracle is evaluated at
     # its query point (first / second round oracles at beta, third round oracles and the index polynomials at gamma) and all
     # polynomials queried at one point are folded with powers of the opening challenge into ONE witness polynomial = one MSM
+    B.transcript_point()
     ch = challenge("marlin.opening_challenge")
     gamma = challenge("marlin.gamma")
     idx_polys = inp["index_polys"]
     for tag, pt, polys in (("beta", beta, [w_poly, z_a, z_b, mask_poly, t_poly, g_1, h_1]), ("gamma", gamma, [g_2, h_2] + idx_polys)):
         folded, c = None, 1
         for a in polys:
-            out.setdefault("evals_" + tag, []).append(B.div_linear(a, pt)[1])       # get_lc_eval: the polynomial's value at the point
+            out.setdefault("evals_" + tag, []).append(B.evaluate(a, pt))       # get_lc_eval: the polynomial's value at the point
             term = B.scale(a, c)
             folded = term if folded is None else _padded_add(B, folded, term)
             c = c * ch % R_MOD
@@ -551,7 +662,8 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     # bound): the same scalars over the shifted powers -- same work; the stand-in commits over the same prefix of powers
     commit("g_1_shifted", g_1)
     commit("g_2_shifted", g_2)
-    return out
+    B.transcript_point()
+    return resolved(out)
 
 
 def _mul_by_vanishing(B, a, n):

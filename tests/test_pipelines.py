@@ -63,3 +63,30 @@ def test_marlin_spdz_pipeline_matches_checker(orc, n_constraints):
     want = polyvm.marlin_prove(cpu, polyvm.marlin_inputs(cpu, n_constraints))
     _compare(got, want)
     ctx.close()
+
+
+@pytest.mark.parametrize("workload,parties,constraints", [("plonk", 3, 64), ("marlin", 2, 100)])
+def test_party_per_rank_layout_of_the_polynomial_provers_matches_the_one_gpu_layout(workload, parties, constraints):
+    """bench.py --workload plonk|marlin --layout party: one party per rank (its 1 GSZ lane / 2 SPDZ lanes), every batch of
+    evaluations between two challenges opened over torch.distributed (GSZ batch_open / SPDZ two-round batch_open with the MAC
+    check).  Party by party, commitments, evaluations and opening proofs must equal the layout with all parties' lanes on one
+    GPU; the ranks share this box's GPU, so the exchange runs over gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--workload", workload, "--parties", str(parties), "--constraints", str(constraints), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    many = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo", "--device", "0"]
+                          + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert many.returncode == 0, many.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    d2 = json.loads(many.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == parties and d2["ranks_seen_by_backend"] == parties and d2["config"]["layout"] == "party"
+    assert d1["results_checked"] and d2["results_checked"]
+    assert "batches per proof" in d2["config"]["workload"] and ", 0 batches" not in d2["config"]["workload"]
+    assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
