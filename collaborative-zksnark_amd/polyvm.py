@@ -162,9 +162,10 @@ class Backend:
         """mpc-plonk/src/util.rs:11-18: coefficient i times w^i."""
         return self.mul(a, self.powers(w, self.length(a)))
 
-    def open_at(self, a, x: int):
+    def open_at(self, a, x: int, public=None):
         """`Prover::eval` (mpc-plonk/src/lib.rs:343-369) / KZG10::open (poly-commit/src/kzg10/mod.rs:225-265): the witness
-        polynomial a / (X - x), its commitment, and the evaluation."""
+        polynomial a / (X - x), its commitment, and the evaluation.  public: the polynomial is public data (its value needs no
+        opening between the parties); None = infer from the lane count."""
         wit, value = self.div_linear(a, x)
         self.reveal(value)
         return {"value": value, "proof": self.commit(wit), "point": x}
@@ -173,7 +174,7 @@ class Backend:
         """a / (X - x) without the remainder"""
         return self.div_linear(a, x)[0]
 
-    def evaluate(self, a, x: int):
+    def evaluate(self, a, x: int, public=None):
         """a(x) per lane, (lanes, 4) -- the remainder of the division by (X - x)"""
         return self.div_linear(a, x)[1]
 
@@ -351,8 +352,13 @@ class GpuBackend(Backend):
     def quotient(self, a, x):
         return self._div_linear_dev(a, x)[0]
 
-    def evaluate(self, a, x):
-        p = Pending(("open_value", self._div_linear_dev(a, x)[1]))      # evaluations are publicized too (marlin/src/lib.rs:283-292)
+    def _value_kind(self, a, public):
+        if public is None:
+            public = a.shape[0] == 1 and self.lanes > 1
+        return "value" if public else "open_value"      # evaluations of share polynomials are publicized (mpc-plonk/src/lib.rs:362-365, marlin/src/lib.rs:283-292)
+
+    def evaluate(self, a, x, public=None):
+        p = Pending((self._value_kind(a, public), self._div_linear_dev(a, x)[1]))
         self._pending.append(p)
         return p
 
@@ -393,9 +399,9 @@ class GpuBackend(Backend):
         self._pending.append(p)
         return p
 
-    def open_at(self, a, x):
+    def open_at(self, a, x, public=None):
         wit, rem = self._div_linear_dev(a, x)
-        v = Pending(("open_value", rem))
+        v = Pending((self._value_kind(a, public), rem))
         self._pending.append(v)
         return {"value": v, "proof": self.commit(wit), "point": x}
 
@@ -467,7 +473,7 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
         out[label + "_cmt"] = B.commit(a)
 
     def open_(label, a, x, of=None):
-        out[label] = B.open_at(a, x)
+        out[label] = B.open_at(a, x, public=of is None)
         out[label]["of"] = of          # label of the opened polynomial's commitment (None: an index polynomial, committed at setup)
 
     commit("p", p)                                                             # :434-441
