@@ -204,7 +204,7 @@ class GpuBackend(Backend):
     """The product path: device tensors, every operation one or a few C-ABI calls on the context's stream -- which must be
     torch's current stream (shared_stream_context)."""
 
-    def __init__(self, czk, ctx, lanes: int, max_degree: int, base_seed: int = 0xBA5E5 + 77, lift=None):
+    def __init__(self, czk, ctx, lanes: int, max_degree: int, base_seed: int = 0xBA5E5 + 77, lift=None, share_srs=None):
         import torch
         self.czk, self.ctx, self.lanes, self.torch = czk, ctx, lanes, torch
         self.lift = tuple([1] * lanes) if lift is None else tuple(lift)
@@ -213,15 +213,20 @@ class GpuBackend(Backend):
         # host without a pairing: C - [v] G == [tau - x] W).  k_i = tau^i as canonical scalars, computed on the device.
         n = max_degree + 1
         self.tau = challenge("kzg.tau.%x" % base_seed)
-        pw = torch.empty((n, 4), dtype=torch.int64, device=self.dev)
-        ctx.fr_powers(mont(self.tau), n, out=pw.data_ptr(), mem=czk.CZK_MEM_DEVICE)
-        k = torch.empty_like(pw)
-        ctx.fr_into_repr(pw.data_ptr(), out=k.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
-        pts = torch.empty((n, 12), dtype=torch.int64, device=self.dev)
-        ctx.fixed_base_points(czk.CZK_G1, k.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
-        self.bases = ctx.register_bases(czk.CZK_G1, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
-        ctx.sync()
-        self.bases_host = (lambda: pts.cpu().numpy().view(np.uint64))      # for the checker-side backend of the tests
+        if share_srs is not None:
+            # a second prover on the same GPU (its own context and stream): registered bases are plain device data, shared
+            assert share_srs.n_bases == n and share_srs.base_seed == base_seed
+            self.bases, self.bases_host = share_srs.bases, share_srs.bases_host
+        else:
+            pw = torch.empty((n, 4), dtype=torch.int64, device=self.dev)
+            ctx.fr_powers(mont(self.tau), n, out=pw.data_ptr(), mem=czk.CZK_MEM_DEVICE)
+            k = torch.empty_like(pw)
+            ctx.fr_into_repr(pw.data_ptr(), out=k.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+            pts = torch.empty((n, 12), dtype=torch.int64, device=self.dev)
+            ctx.fixed_base_points(czk.CZK_G1, k.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+            self.bases = ctx.register_bases(czk.CZK_G1, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
+            ctx.sync()
+            self.bases_host = (lambda: pts.cpu().numpy().view(np.uint64))      # for the checker-side backend of the tests
         self.base_seed, self.n_bases = base_seed, n
         self.msm_count = self.ntt_count = 0
         self._pending = []      # commitments / evaluations enqueued since the last transcript_point()
