@@ -154,6 +154,25 @@ static void host_jac_add(const u64* a, const u64* b, u64* out) {
     store_jac<F>(jac_add(x, y), out);
 }
 template <class F>
+static void combine_windows_impl(const u64* src, unsigned W, unsigned c, size_t lanes, u64* out) {
+    constexpr int JW = 3 * FieldIO<F>::W64;
+    for (size_t l = 0; l < lanes; l++) {
+        Jac<F> acc;
+        load_jac<F>(src + (l * W + (W - 1)) * JW, acc);
+        for (unsigned w = W - 1; w-- > 0;) {
+            for (unsigned k = 0; k < c; k++) acc = jac_double(acc);   // the Horner step of variable_base.rs:92-105
+            Jac<F> r;
+            load_jac<F>(src + (l * W + w) * JW, r);
+            acc = jac_add(acc, r);
+        }
+        store_jac<F>(acc, out + l * JW);
+    }
+}
+void host_combine_windows(int group, const char* src, unsigned W, unsigned c, size_t lanes, uint64_t* out) {
+    if (group == CZK_G1) combine_windows_impl<Fq>((const u64*)src, W, c, lanes, out);
+    else combine_windows_impl<Fq2>((const u64*)src, W, c, lanes, out);
+}
+template <class F>
 static void host_jac_add_mixed(const u64* a, const u64* b_aff, bool b_inf, u64* out) {
     constexpr int W = FieldIO<F>::W64;
     Jac<F> x;

@@ -67,6 +67,11 @@ struct MsmPending {
     const char* src;
     void* dst;
     size_t bytes;
+    // split-window MSMs (bases registered without tables): `src` holds lanes x split_W per-window results that still have to
+    // be combined as sum_w 2^(c w) R_w (host, a few hundred point operations) into `dst` = lanes results
+    unsigned split_W = 0, c = 0;
+    int group = 0;
+    size_t lanes = 0;
 };
 }  // namespace czk
 
@@ -109,6 +114,8 @@ struct czk_bases {
     unsigned c = 0;            // signed-digit window width chosen at registration
     unsigned W = 0;            // number of windows = ceil(254 / c)
     bool unsat = false;        // window tables hold coordinates * R' (fqu.h), used by k_accumulate_u / k_accumulate_u2
+    bool split = false;        // CZK_MEM_NO_TABLES: only window 0 is stored; an MSM runs one bucket set per window (windows become
+                               // extra lanes of the same kernels) and the per-window results are combined afterwards
     uint64_t* pts = nullptr;   // device, W x n x (12|24) u64: window w holds 2^(c*w) * P_i, affine Montgomery
     uint8_t* inf = nullptr;    // device, W x n infinity flags (never null)
 };
@@ -175,6 +182,8 @@ int ntt_mixed_device(czk_ctx* ctx, u64* data, unsigned k, size_t lanes, int kind
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
                int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable);
 int msm_pipeline_init(czk_ctx* ctx);
+// sum_w 2^(c w) R[lane][w] on the host (Horner: c doublings per window); src: lanes x W Jacobian triples, out: lanes triples
+void host_combine_windows(int group, const char* src, unsigned W, unsigned c, size_t lanes, uint64_t* out);
 int msm_pipeline_sync(czk_ctx* ctx);
 void msm_pipeline_destroy(czk_ctx* ctx);
 int fixed_base_points_device(czk_ctx* ctx, int group, const u64* k_dev, size_t n, u64* out_dev);

@@ -277,10 +277,13 @@ __global__ void k_scatter(const u32* digits, const u32* ranks, size_t size, unsi
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned PART_LOG = 10, PART_BUCKETS = 1u << PART_LOG, MAX_PARTS = 2048;
 
+// split != 0 (bases without window tables): every window is its own bucket set, i.e. window w of lane l is virtual lane l W + w of
+// everything downstream (the `digits` layout is the same either way); partition counts are then kept per window.
 __global__ __launch_bounds__(256) void k_digits_part(const u64* scalars, size_t n_scalars, size_t size, int montgomery, unsigned c, unsigned W,
-                                                     const uint8_t* inf, size_t n_bases, u32* digits, u32* part_counts, unsigned n_parts) {
+                                                     const uint8_t* inf, size_t n_bases, u32* digits, u32* part_counts, unsigned n_parts, int split) {
     __shared__ u32 h[MAX_PARTS];
-    for (unsigned t = threadIdx.x; t < n_parts; t += 256) h[t] = 0;
+    const unsigned n_hist = split ? W * n_parts : n_parts;
+    for (unsigned t = threadIdx.x; t < n_hist; t += 256) h[t] = 0;
     __syncthreads();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const unsigned lane = blockIdx.y;
@@ -306,15 +309,15 @@ __global__ __launch_bounds__(256) void k_digits_part(const u64* scalars, size_t 
                 code = v;
                 carry = 0;
             }
-            if (inf[(size_t)w * n_bases + i]) code = 0;   // add_assign_mixed skips infinity (short_weierstrass_jacobian.rs:571-573)
+            if (inf[(split ? 0 : (size_t)w * n_bases) + i]) code = 0;   // add_assign_mixed skips infinity (short_weierstrass_jacobian.rs:571-573)
             if ((code & 0x7fffffffu) == 0) code = 0;
             digits[((size_t)lane * W + w) * size + i] = code;
-            if (code) atomicAdd(&h[((code & 0x7fffffffu) - 1) & (n_parts - 1)], 1u);
+            if (code) atomicAdd(&h[(split ? w * n_parts : 0) + (((code & 0x7fffffffu) - 1) & (n_parts - 1))], 1u);
         }
     }
     __syncthreads();
-    for (unsigned t = threadIdx.x; t < n_parts; t += 256)
-        if (h[t]) atomicAdd(&part_counts[(size_t)lane * n_parts + t], h[t]);
+    for (unsigned t = threadIdx.x; t < n_hist; t += 256)
+        if (h[t]) atomicAdd(&part_counts[(size_t)lane * n_hist + t], h[t]);   // split: (lane W + w) n_parts + part
 }
 // part_base[lane][0 .. n_parts] = exclusive scan of part_counts; cursors cleared.  One block per lane.
 __global__ __launch_bounds__(1024) void k_part_scan(const u32* part_counts, u32* part_base, u32* part_cursor, unsigned n_parts) {
@@ -507,11 +510,30 @@ static unsigned choose_c(size_t n) {
     return best;
 }
 
+// Without window tables every window has its own bucket set: W(c) * n mixed additions + W(c) bucket reductions of 2^(c-1) buckets
+// (~4 mixed additions' worth of instructions per bucket).  The per-window partition histograms of k_digits_part must fit its LDS array.
+static unsigned choose_c_split(size_t n) {
+    unsigned best = 2;
+    double best_cost = 1e300;
+    for (unsigned c = 2; c <= 20; c++) {
+        const unsigned W = num_windows(c), top_bits = 254 - (W - 1) * c;
+        const size_t B = (size_t)1 << (c - 1), n_parts = (B + PART_BUCKETS - 1) >> PART_LOG;
+        if ((size_t)W * n_parts > MAX_PARTS) continue;
+        if (n >= 16384 && top_bits < 10) continue;   // a narrow top window piles n / 2^bits points on each of its few buckets
+        double cost = (double)W * (double)(n ? n : 1) + 4.0 * (double)W * (double)B;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = c;
+        }
+    }
+    return best;
+}
+
 template <class F>
 static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const uint8_t* inf_dev) {
     constexpr int AW = GT<F>::AW, JW = GT<F>::JW, FW = GT<F>::FW;
     const size_t n = b->n;
-    const unsigned W = b->W;
+    const unsigned W = b->split ? 1 : b->W;   // windows held as tables
     CZK_HIP(ctx, hipMalloc(&b->pts, (size_t)W * (n ? n : 1) * AW * 8));
     CZK_HIP(ctx, hipMalloc(&b->inf, (size_t)W * (n ? n : 1)));
     if (!n) return CZK_OK;
@@ -558,7 +580,13 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                        bool scalars_stable) {
     constexpr int JW = GT<F>::JW, XW = GT<F>::XW;   // results leave as Jacobian; buckets are XYZZ internally
     const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
-    const unsigned c = b->c, W = b->W;
+    // Bases without window tables (b->split): the W digit windows of every scalar lane become W "virtual lanes", each a
+    // one-window MSM over the same n points with its own bucket set; everything after the digit extraction simply runs with
+    // lanes * W lanes and one window, and the per-window results are combined on the host when they are collected.
+    const unsigned c = b->c, Wd = b->W, W = b->split ? 1 : b->W;
+    const size_t real_lanes = lanes;
+    if (b->split) lanes *= Wd;
+    if (lanes > 65535) return set_err(ctx, CZK_ERR_SIZE, "too many MSM lanes");
     const size_t B = (size_t)1 << (c - 1);
     const unsigned L = 8, logL = 3;
     if ((size_t)W * b->n >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
@@ -576,7 +604,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B + (size_t)12 * 513 * XW * 8) + (size_t)heavy_cap * (XW * 8 + 32) + (1 << 17);
     // batched-affine pre-reduction (G1, unsaturated tables): records, two level arrays, per-level bucket offsets / counts
     AffArgs aff;
-    const bool one_pass_sort = ctx->msm_sort_onepass || n_parts > MAX_PARTS;
+    const bool one_pass_sort = !b->split && (ctx->msm_sort_onepass || n_parts > MAX_PARTS);   // (choose_c_split keeps Wd * n_parts <= MAX_PARTS)
     size_t need_aff = 0;
     if (GT<F>::AW == 12 && b->unsat && ctx->msm_affine_rounds > 0 && size > 0) {
         aff.rounds = ctx->msm_affine_rounds;
@@ -671,8 +699,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             const size_t total = (size_t)W * size;
             CZK_HIP(ctx, hipMemsetAsync(part_counts, 0, lanes * n_parts * 4, ss));
             if (size) {
-                hipLaunchKernelGGL(k_digits_part, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
-                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, part_counts, n_parts);
+                hipLaunchKernelGGL(k_digits_part, dim3((unsigned)((size + 255) / 256), (unsigned)real_lanes), dim3(256), 0, ss, scalars, n_scalars, size,
+                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, Wd, b->inf, b->n, digits, part_counts, n_parts, b->split ? 1 : 0);
             }
             hipLaunchKernelGGL(k_part_scan, dim3((unsigned)lanes), dim3(1024), 0, ss, part_counts, part_base, part_cursor, n_parts);
             if (size) {
@@ -763,7 +791,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipMemcpyAsync(pinned, result, out_bytes, hipMemcpyDeviceToHost, sr));
     CZK_HIP(ctx, hipEventRecord(slot.ev_red, sr));
     slot.used = true;
-    ctx->msm_pending.push_back(MsmPending{pinned, out_host, out_bytes});
+    MsmPending pend{pinned, out_host, out_bytes};
+    if (b->split) {
+        pend.split_W = Wd;
+        pend.c = c;
+        pend.group = b->group;
+        pend.lanes = real_lanes;
+    }
+    ctx->msm_pending.push_back(pend);
     return CZK_OK;
 }
 
@@ -800,7 +835,10 @@ int msm_pipeline_sync(czk_ctx* ctx) {
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_sort));
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_acc));
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_red));
-    for (auto& p : ctx->msm_pending) memcpy(p.dst, p.src, p.bytes);
+    for (auto& p : ctx->msm_pending) {
+        if (p.split_W) host_combine_windows(p.group, p.src, p.split_W, p.c, p.lanes, (uint64_t*)p.dst);
+        else memcpy(p.dst, p.src, p.bytes);
+    }
     ctx->msm_pending.clear();
     ctx->msm_pinned_used = 0;
     return CZK_OK;
@@ -877,14 +915,17 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     *out = nullptr;
     if (group != CZK_G1 && group != CZK_G2) return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
     if (n && !bases) return set_err(ctx, CZK_ERR_ARG, "null bases");
-    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
+    const bool no_tables = (mem & CZK_MEM_NO_TABLES) != 0;
+    mem &= ~CZK_MEM_NO_TABLES;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (optionally | CZK_MEM_NO_TABLES)");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t aw = group == CZK_G1 ? 12 : 24;
     czk_bases* b = new czk_bases();
     b->device = ctx->device;
     b->group = group;
     b->n = n;
-    b->c = choose_c(n);
+    b->split = no_tables;
+    b->c = no_tables ? choose_c_split(n) : choose_c(n);
     b->W = num_windows(b->c);
     const u64* pts_dev = bases;
     const uint8_t* inf_dev = inf;
@@ -968,7 +1009,8 @@ extern "C" int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_
 static int msm_oneshot(czk_ctx* ctx, int group, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t lanes,
                        int scalar_form, uint64_t* out_jac) {
     czk_bases* b = nullptr;
-    CZK_TRY(czk_bases_register(ctx, group, bases_xy, inf, n, CZK_MEM_HOST, &b));
+    // used once: no window tables (building them costs ~20 point doublings per point and window -- more than the MSM itself)
+    CZK_TRY(czk_bases_register(ctx, group, bases_xy, inf, n, CZK_MEM_HOST | CZK_MEM_NO_TABLES, &b));
     int rc = czk_msm(ctx, b, scalars, n, lanes, scalar_form, CZK_MEM_HOST, out_jac);
     czk_bases_release(b);
     return rc;

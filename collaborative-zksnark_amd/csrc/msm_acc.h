@@ -2,6 +2,11 @@
 // Included by msm_acc_g1.hip (F = Fq) and msm_acc_g2.hip (F = Fq2); those translation units are built with
 // the Montgomery multiply inlined.  See msm.hip for the surrounding algorithm.
 #pragma once
+#ifdef CZK_FIX_NARROW   // A/B builds only: the fix-up kernels limited to 128 VGPRs (see k_accumulate_u_fix)
+#define CZK_FIX_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define CZK_FIX_ATTR
+#endif
 #include "czk_internal.h"
 
 namespace czk {
@@ -270,10 +275,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // recomputes the buckets k_accumulate_u gave up on, in the saturated residue system (points converted on the fly).
-// (<= 128 VGPRs like the over-full-bucket kernels: normally no bucket is dirty and every block returns at once, but at ~250 VGPRs
-// each of its blocks had to wait for a drained SIMD next to the accumulate kernels -- 2.3 ms on average, 11.6 ms worst case, per
-// empty launch in the pipeline: profiles/r02_kernel_trace_stats.txt)
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_u_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+// (Normally no bucket is dirty and every block returns at once; at ~250 VGPRs each block still has to wait for a drained SIMD
+// next to the accumulate kernels -- 2.3 ms on average per empty launch in the pipeline, profiles/r02_kernel_trace_stats.txt.
+// Limiting it to 128 VGPRs (-DCZK_FIX_NARROW) removes that wait and shortens one proof's latency by ~1 ms, but the blocks then
+// run BESIDE the accumulate waves and cost 0.8 % of throughput (A/B on one box: 89.8 vs 89.1 ms per proof): not adopted.)
+__global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                          size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     xyzz_store<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), out);
 }
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
+__global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                           size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;

@@ -64,10 +64,11 @@ class Groth16Local:
     """Device-resident state + the per-proof pipeline for `n_constraints` constraints of the reference's benchmark
     circuit (squaring chain, mpc-snarks/src/proof.rs:304-344), SPDZ shares of `parties` parties."""
 
-    def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None):
+    def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None, no_tables: bool = False):
         """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
         configs[1]); with one party per rank the two opens of the witness map run the reference's two broadcast rounds
-        over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused."""
+        over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused.  no_tables:
+        register the proving key with CZK_MEM_NO_TABLES (what a prover that runs once should do)."""
         self.czk, self.ctx = czk, ctx
         self.N = int(n_constraints)
         self.P = parties
@@ -91,9 +92,13 @@ class Groth16Local:
             inf = torch.zeros(n, dtype=torch.uint8, device=dev)
             if inf_first:
                 inf[0] = 1   # b_query[1] (the public output has no B entry) is infinity in the real key
-            b = ctx.register_bases(group, pts.data_ptr(), inf.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+            ctx.sync()
+            t_reg = time.time()
+            b = ctx.register_bases(group, pts.data_ptr(), inf.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE | (czk.CZK_MEM_NO_TABLES if no_tables else 0))
+            self.register_s += time.time() - t_reg     # czk_bases_register returns when the tables are built
             del pts, k
             return b
+        self.register_s = 0.0                           # czk_bases_register alone; setup_key_s also counts the synthetic key generation
         t0 = time.time()
         self.query_len = {"h": D - 1, "l": N, "a": N + 1, "b_g1": N + 1, "b_g2": N + 1}   # groth16/src/generator.rs:156-163
         self.h_query = mk_bases(czk.CZK_G1, D - 1, 1)

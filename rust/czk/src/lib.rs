@@ -210,12 +210,19 @@ pub mod msm {
     use std::collections::HashMap;
     use std::sync::Mutex;
 
-    struct Registered(*mut sys::czk_bases);
+    /// A registered base slice: the library handle, whether it carries window tables, and how often it has been used.
+    struct Registered {
+        handle: *mut sys::czk_bases,
+        tables: bool,
+        uses: u32,
+    }
     unsafe impl Send for Registered {}
 
     lazy_static::lazy_static! {
-        // Proving-key queries are reused across proofs (groth16/src/data_structures.rs:132-149): the window tables of a base
-        // slice are built once and found again by (address, length, group).
+        // Base slices are found again by (address, length, group).  The first MSM over a slice registers it WITHOUT window
+        // tables (CZK_MEM_NO_TABLES: a copy, no precomputation -- right for the reference's prove-once binaries and for
+        // one-off commitments); a slice that comes back (proving-key queries are reused across proofs,
+        // groth16/src/data_structures.rs:132-149) is re-registered with tables, which makes every later MSM ~1.4x cheaper.
         static ref BASES: Mutex<HashMap<(usize, usize, i32), Registered>> = Mutex::new(HashMap::new());
     }
 
@@ -227,21 +234,31 @@ pub mod msm {
         s
     }
 
-    fn run(group: i32, key: (usize, usize, i32), xy: impl FnOnce() -> (Vec<u64>, Vec<u8>), scalars: &[Fr], out: &mut [u64]) {
+    fn register(ctx: &super::Context, group: i32, pts: &[u64], inf: &[u8], tables: bool) -> *mut sys::czk_bases {
+        let mut h: *mut sys::czk_bases = std::ptr::null_mut();
+        let mem = if tables { sys::CZK_MEM_HOST } else { sys::CZK_MEM_HOST | sys::CZK_MEM_NO_TABLES };
+        let rc = unsafe { sys::czk_bases_register(ctx.as_ptr(), group, pts.as_ptr(), inf.as_ptr(), inf.len(), mem, &mut h) };
+        ctx.expect(rc, "czk_bases_register");
+        h
+    }
+
+    fn run(group: i32, key: (usize, usize, i32), xy: impl Fn() -> (Vec<u64>, Vec<u8>), scalars: &[Fr], out: &mut [u64]) {
         let ctx = CTX.lock().unwrap();
         let mut map = BASES.lock().unwrap();
-        let handle = map.entry(key).or_insert_with(|| {
+        let entry = map.entry(key).or_insert_with(|| {
             let (pts, inf) = xy();
-            let mut h: *mut sys::czk_bases = std::ptr::null_mut();
-            let rc = unsafe {
-                sys::czk_bases_register(ctx.as_ptr(), group, pts.as_ptr(), inf.as_ptr(), inf.len(), sys::CZK_MEM_HOST, &mut h)
-            };
-            ctx.expect(rc, "czk_bases_register");
-            Registered(h)
+            Registered { handle: register(&ctx, group, &pts, &inf, false), tables: false, uses: 0 }
         });
+        entry.uses += 1;
+        if entry.uses == 2 && !entry.tables {
+            let (pts, inf) = xy();
+            unsafe { sys::czk_bases_release(entry.handle) };
+            entry.handle = register(&ctx, group, &pts, &inf, true);
+            entry.tables = true;
+        }
         let s = scalars_to_limbs(scalars);
         let rc = unsafe {
-            sys::czk_msm(ctx.as_ptr(), handle.0, s.as_ptr(), scalars.len(), 1, sys::CZK_SCALAR_MONTGOMERY, sys::CZK_MEM_HOST, out.as_mut_ptr())
+            sys::czk_msm(ctx.as_ptr(), entry.handle, s.as_ptr(), scalars.len(), 1, sys::CZK_SCALAR_MONTGOMERY, sys::CZK_MEM_HOST, out.as_mut_ptr())
         };
         ctx.expect(rc, "czk_msm");
     }

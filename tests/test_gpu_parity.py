@@ -771,3 +771,78 @@ def test_ntt_first_generation_passes_still_match(czk, orc, monkeypatch):
             for ln in range(2):
                 assert np.array_equal(buf[ln], orc.ntt_fr(x[ln], log_d, kind)), (log_d, kind, ln)
     c.close()
+
+
+@pytest.mark.parametrize("g,n", [(1, 1), (1, 7), (1, 33), (1, 300), (1, 4096), (1, 70001), (2, 1), (2, 33), (2, 700)])
+def test_msm_without_window_tables_matches_reference_pippenger(ctx, czk, orc, g, n):
+    """CZK_MEM_NO_TABLES: the points are registered as they are and every window runs as its own bucket set (the windows are
+    extra lanes of the same kernels), then sum_w 2^(c w) R_w like the reference's final loop (variable_base.rs:92-105).  Same
+    special cases as the table form: zero / unit scalars, infinity bases, equal and opposite points, both scalar forms,
+    fewer scalars than bases; two lanes."""
+    _, bases = _bases(ctx, g, n, 900 + n)
+    inf = np.zeros(n, dtype=np.uint8)
+    sc = rand_fr_canonical(901 + n, 2 * n).reshape(2, n, 4)
+    if n >= 10:
+        bases[3] = bases[2]
+        aw = bases.shape[1] // 2
+        neg = bases[4].copy()
+        if g == 1:
+            neg[aw:] = orc.fq_neg(bases[4][aw:])
+        else:
+            neg[aw:] = np.concatenate([orc.fq_neg(bases[4][aw:aw + 6]), orc.fq_neg(bases[4][aw + 6:])])
+        bases[5] = neg
+        inf[7] = 1
+        sc[:, 0] = 0
+        sc[:, 1] = ints_to_limbs([1], 4)[0]
+        sc[:, 2] = sc[:, 3] = ints_to_limbs([5], 4)[0]
+        sc[:, 4] = sc[:, 5] = ints_to_limbs([R_MOD - 3], 4)[0]
+        sc[1, 8] = ints_to_limbs([R_MOD - 1], 4)[0]                     # every signed digit carries
+    b = ctx.register_bases(g, bases, inf, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_NO_TABLES)
+    assert len(b) == n
+    got = ctx.msm(b, sc, lanes=2)
+    for ln in range(2):
+        assert _same_point(ctx, orc, g, got[ln], orc.msm(g, bases, inf, sc[ln])), (g, n, ln)
+    scm = orc.fr_from_repr(np.vstack([sc[0], ints_to_limbs([77], 4)]))
+    got_m = ctx.msm(b, scm, lanes=1, scalar_form=czk.CZK_SCALAR_MONTGOMERY)
+    assert _same_point(ctx, orc, g, got_m[0], orc.multi_scalar_mul(g, bases, inf, scm))
+    if n > 2:
+        got_s = ctx.msm(b, sc[0, : n - 1], lanes=1)
+        assert _same_point(ctx, orc, g, got_s[0], orc.msm(g, bases[: n - 1], inf[: n - 1], sc[0, : n - 1]))
+    # the same handle through the asynchronous entry point, two MSMs in flight
+    import torch
+    sd = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+    o1, o2 = np.zeros((2, 18 * g), dtype=np.uint64), np.zeros((1, 18 * g), dtype=np.uint64)
+    torch.cuda.synchronize()
+    ctx.msm_async(b, sd.data_ptr(), n, 2, czk.CZK_SCALAR_CANONICAL, o1)
+    ctx.msm_async(b, sd[1].data_ptr(), n, 1, czk.CZK_SCALAR_CANONICAL, o2)
+    ctx.sync()
+    assert _same_point(ctx, orc, g, o1[1], orc.msm(g, bases, inf, sc[1])) and _same_point(ctx, orc, g, o2[0], orc.msm(g, bases, inf, sc[1]))
+    b.release()
+
+
+@pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (2, (1 << 18) + 1)])
+def test_msm_without_window_tables_full_size(ctx, czk, orc, g, n):
+    """The a-query size of BASELINE configs[1] without window tables, 4 share lanes, by known discrete logs and against the
+    table form of the same bases."""
+    import torch
+    lanes = 4
+    k = rand_fr_canonical(0xBA5E5 + 9, n)
+    aw = 12 if g == 1 else 24
+    kd = torch.from_numpy(k.view(np.int64)).cuda()
+    pts = torch.empty((n, aw), dtype=torch.int64, device="cuda")
+    ctx.fixed_base_points(g, kd.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+    b = ctx.register_bases(g, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE | czk.CZK_MEM_NO_TABLES)
+    bt = ctx.register_bases(g, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
+    del pts
+    s = rand_fr_canonical(0xC0FFEE + 9, lanes * n).reshape(lanes, n, 4)
+    s[3, : n // 2] = ints_to_limbs([1], 4)[0]                            # half of one lane's scalars are 1: over-full buckets in window 0
+    sd = torch.from_numpy(s.view(np.int64)).cuda()
+    out = ctx.msm(b, sd.data_ptr(), n_scalars=n, lanes=lanes, mem=czk.CZK_MEM_DEVICE)
+    out_t = ctx.msm(bt, sd.data_ptr(), n_scalars=n, lanes=lanes, mem=czk.CZK_MEM_DEVICE)
+    gen = ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
+    for ln in range(lanes):
+        e = dot_mod_r(k, s[ln])
+        assert _same_point(ctx, orc, g, out[ln], orc.scalar_mul(g, gen, False, ints_to_limbs([e], 4)[0])), (g, ln)
+        assert _same_point(ctx, orc, g, out[ln], out_t[ln])
+    b.release()
+    bt.release()
