@@ -52,7 +52,7 @@ typedef enum {
      * enqueued afterwards on that stream -- e.g. the witness-map NTTs -- overlap with the MSM). */
     CZK_MEM_STABLE = 16,
     /* czk_bases_register only, OR-ed with CZK_MEM_HOST / CZK_MEM_DEVICE: keep the points only, no precomputed window
-     * multiples.  Registration is then a copy (instead of ~240 point doublings per point: 0.4 s per 2^20 G1 points), and
+     * multiples.  Registration is then a copy (instead of ~240 point doublings per point: 65 ms per 2^20 G1 points), and
      * each MSM runs one bucket set per window plus the Horner combination of variable_base.rs:92-105 -- about 1.4x the
      * arithmetic of the table form.  For callers that use a set of bases once or a few times; czk_msm_g1 / czk_msm_g2 use it. */
     CZK_MEM_NO_TABLES = 32
