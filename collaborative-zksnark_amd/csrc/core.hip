@@ -38,12 +38,55 @@ int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes) {
     return CZK_OK;
 }
 
+int stage_take(czk_ctx* ctx, size_t bytes, DeviceBuf* out) {
+    if (!bytes) bytes = 1;
+    int best = -1;
+    for (size_t i = 0; i < ctx->stage_pool.size(); i++)
+        if (ctx->stage_pool[i].bytes >= bytes && (best < 0 || ctx->stage_pool[i].bytes < ctx->stage_pool[best].bytes)) best = (int)i;
+    if (best >= 0 && ctx->stage_pool[best].bytes <= 2 * bytes + (1 << 20)) {   // do not pin a huge buffer under a small request
+        *out = ctx->stage_pool[best];
+        ctx->stage_pool.erase(ctx->stage_pool.begin() + best);
+        return CZK_OK;
+    }
+    out->p = nullptr;
+    out->bytes = bytes;
+    if (hipMalloc(&out->p, bytes) != hipSuccess) {
+        // memory pressure: drop the idle buffers and try once more
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& b : ctx->stage_pool) (void)hipFree(b.p);
+        ctx->stage_pool.clear();
+        CZK_HIP(ctx, hipMalloc(&out->p, bytes));
+    }
+    return CZK_OK;
+}
+void stage_give(czk_ctx* ctx, const DeviceBuf& b) {
+    if (!b.p) return;
+    constexpr size_t MAX_IDLE = 6;
+    if (ctx->stage_pool.size() >= MAX_IDLE) {   // keep the larger ones: evict the smallest
+        size_t small = 0;
+        for (size_t i = 1; i < ctx->stage_pool.size(); i++)
+            if (ctx->stage_pool[i].bytes < ctx->stage_pool[small].bytes) small = i;
+        if (ctx->stage_pool[small].bytes >= b.bytes) {
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(b.p);
+            return;
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(ctx->stage_pool[small].p);
+        ctx->stage_pool.erase(ctx->stage_pool.begin() + small);
+    }
+    ctx->stage_pool.push_back(b);
+}
+
 int Staged::to_device(const void* host, size_t bytes, int mem) {
     if (mem == CZK_MEM_DEVICE) {
         dev = const_cast<void*>(host);
         return CZK_OK;
     }
-    CZK_HIP(ctx, hipMalloc(&dev, bytes ? bytes : 1));
+    DeviceBuf b;
+    CZK_TRY(stage_take(ctx, bytes, &b));
+    dev = b.p;
+    cap = b.bytes;
     owned = true;
     if (host) CZK_HIP(ctx, hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     return CZK_OK;
@@ -55,7 +98,7 @@ int Staged::to_host(void* host, size_t bytes) {
     return CZK_OK;
 }
 Staged::~Staged() {
-    if (owned && dev) (void)hipFree(dev);
+    if (owned && dev) stage_give(ctx, DeviceBuf{dev, cap});
 }
 
 static hipEvent_t take_event(czk_ctx* ctx) {
@@ -257,6 +300,8 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     if (ctx->ntt_scratch.p) (void)hipFree(ctx->ntt_scratch.p);
     if (ctx->poly_scratch.p) (void)hipFree(ctx->poly_scratch.p);
     if (ctx->open_bad) (void)hipFree(ctx->open_bad);
+    for (auto& b : ctx->stage_pool) (void)hipFree(b.p);
+    ctx->stage_pool.clear();
     if (ctx->share_tab.p) (void)hipFree(ctx->share_tab.p);
     msm_pipeline_destroy(ctx);
     prof_resolve(ctx);

@@ -76,6 +76,7 @@ struct MsmPending {
 }  // namespace czk
 
 struct czk_ctx {
+    std::vector<czk::DeviceBuf> stage_pool;   // idle staging buffers of host-memory callers (core.hip)
     // MSM pipeline (msm.hip)
     hipStream_t s_sort = nullptr, s_acc = nullptr, s_red = nullptr;
     hipEvent_t ev_in = nullptr;
@@ -139,15 +140,22 @@ inline Fr host_fr(const uint64_t* p) {
 }
 
 // host <-> device staging for CZK_MEM_HOST callers of the vector entry points
+// (device buffers come from a small per-context pool -- stage_take / stage_give -- instead of hipMalloc / hipFree per call:
+// a 2^21 x 4-lane NTT from host memory stages 256 MiB, and hipFree alone synchronises the device)
 struct Staged {
     czk_ctx* ctx;
     void* dev = nullptr;
     bool owned = false;
+    size_t cap = 0;
     int to_device(const void* host, size_t bytes, int mem);
     int to_host(void* host, size_t bytes);
     ~Staged();
 };
 int ensure_buf(czk_ctx* ctx, DeviceBuf& b, size_t bytes);
+// staging pool: a buffer of at least `bytes` (smallest fitting pooled one, else a fresh allocation); give it back when the work
+// that uses it has been ENQUEUED on ctx->stream -- every later user enqueues on the same stream, so re-use is ordered
+int stage_take(czk_ctx* ctx, size_t bytes, DeviceBuf* out);
+void stage_give(czk_ctx* ctx, const DeviceBuf& b);
 int get_domain(czk_ctx* ctx, unsigned log_d, DomainTables** out);
 
 // RAII bracket: records an event pair around the launches issued in its scope (no-op unless profiling)

@@ -983,18 +983,19 @@ static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scal
     if (!valid_mem(mem) || (stable && (blocking || mem != CZK_MEM_DEVICE)))
         return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (CZK_MEM_STABLE: czk_msm_async with device scalars only)");
     const u64* sdev = scalars;
-    void* tmp = nullptr;
+    DeviceBuf tmp;
     if (mem == CZK_MEM_HOST && n_scalars) {
-        CZK_HIP(ctx, hipMalloc(&tmp, lanes * n_scalars * 32));
-        hipError_t e = hipMemcpyAsync(tmp, scalars, lanes * n_scalars * 32, hipMemcpyHostToDevice, ctx->stream);
+        CZK_TRY(stage_take(ctx, lanes * n_scalars * 32, &tmp));   // pooled: hipMalloc / hipFree per call cost more than the copy
+        hipError_t e = hipMemcpyAsync(tmp.p, scalars, lanes * n_scalars * 32, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) {
-            (void)hipFree(tmp);
+            stage_give(ctx, tmp);
             return set_err(ctx, CZK_ERR_HIP, "H2D scalars");
         }
-        sdev = (const u64*)tmp;
+        sdev = (const u64*)tmp.p;
     }
-    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp != nullptr, stable && !blocking);
-    if (tmp) (void)hipFree(tmp);
+    // host scalars: always blocking (the digits have been extracted from the staging buffer by the time this returns)
+    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp.p != nullptr, stable && !blocking);
+    if (tmp.p) stage_give(ctx, tmp);
     return rc;
 }
 extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,

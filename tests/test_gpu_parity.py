@@ -58,7 +58,7 @@ def test_domain_constants_match_reference_rule(ctx, orc):
     assert e.value.code == 1
 
 
-@pytest.mark.parametrize("log_d", [0, 1, 2, 3, 4, 6, 7, 8, 10, 13, 14, 15, 16])
+@pytest.mark.parametrize("log_d", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
 def test_ntt_all_kinds_bit_exact(ctx, czk, orc, log_d):
     d = 1 << log_d
     for in_len in sorted({d, max(1, d - 3), (d + 1) // 2}):
@@ -846,3 +846,31 @@ def test_msm_without_window_tables_full_size(ctx, czk, orc, g, n):
         assert _same_point(ctx, orc, g, out[ln], out_t[ln])
     b.release()
     bt.release()
+
+
+def test_many_share_lanes(ctx, czk, orc):
+    """8 SPDZ parties on one GPU are 16 share lanes (lanes ride on gridDim.y of every kernel): NTT with 7 and 16 lanes incl. an
+    all-zero and a one-element input, G1 MSM with 16 lanes, G2 with 6."""
+    for log_d, lanes in ((12, 7), (11, 16)):
+        d = 1 << log_d
+        x = orc.fr_from_repr(rand_fr_canonical(7700 + log_d, lanes * d)).reshape(lanes, d, 4)
+        for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+            buf = x.copy()
+            ctx.ntt_fr(buf, log_d, kind, lanes=lanes)
+            for ln in range(lanes):
+                assert np.array_equal(buf[ln], orc.ntt_fr(x[ln], log_d, kind, d)), (log_d, kind, ln)
+            for in_len in (0, 1):
+                buf = np.full((2, d, 4), 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+                buf[:, :in_len] = x[:2, :in_len]
+                ctx.ntt_fr(buf, log_d, kind, lanes=2, in_len=in_len)
+                for ln in range(2):
+                    assert np.array_equal(buf[ln], orc.ntt_fr(x[ln, :in_len], log_d, kind, in_len)), (log_d, kind, in_len)
+    for g, n, lanes in ((1, 5000, 16), (2, 300, 6)):
+        _, bases = _bases(ctx, g, n, 8800 + n)
+        sc = rand_fr_canonical(8801 + n, lanes * n).reshape(lanes, n, 4)
+        for no_tables in (0, czk.CZK_MEM_NO_TABLES):
+            b = ctx.register_bases(g, bases, None, mem=czk.CZK_MEM_HOST | no_tables)
+            got = ctx.msm(b, sc, lanes=lanes)
+            for ln in range(lanes):
+                assert _same_point(ctx, orc, g, got[ln], orc.msm(g, bases, np.zeros(n, dtype=np.uint8), sc[ln])), (g, ln, no_tables)
+            b.release()
