@@ -292,6 +292,233 @@ struct MadU<14> {
             : "vcc");
     }
 };
+// first product of a multiply: acc = x * y (the zero addend is the instruction's inline constant: no register pair to clear)
+__device__ __forceinline__ u64 mad_first(u32 x, u32 y) {
+    u64 a;
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(a) : "v"(x), "v"(y) : "vcc");
+    return a;
+}
+// Same with the second operand of every product in a SCALAR register (VOP3 takes one SGPR per instruction): for products with the
+// modulus, whose limbs are wave-uniform constants -- they then occupy no vector registers and are never re-materialised with v_mov.
+template <int CNT>
+struct MadUS;
+template <>
+struct MadUS<1> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<2> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<3> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<4> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<5> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<6> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<7> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<8> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<9> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<10> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<11> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<12> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %23, %24, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<13> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %23, %24, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %25, %26, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]), "v"(x[12]), "s"(y[12])
+            : "vcc");
+    }
+};
+template <>
+struct MadUS<14> {
+    static __device__ __forceinline__ void run(u64& a, const u32* x, const u32* y) {
+        asm("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %3, %4, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %5, %6, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %7, %8, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %9, %10, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %11, %12, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %13, %14, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %15, %16, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %17, %18, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %19, %20, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %21, %22, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %23, %24, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %25, %26, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, %27, %28, %0"
+            : "+v"(a)
+            : "v"(x[0]), "s"(y[0]), "v"(x[1]), "s"(y[1]), "v"(x[2]), "s"(y[2]), "v"(x[3]), "s"(y[3]), "v"(x[4]), "s"(y[4]), "v"(x[5]), "s"(y[5]), "v"(x[6]), "s"(y[6]), "v"(x[7]), "s"(y[7]), "v"(x[8]), "s"(y[8]), "v"(x[9]), "s"(y[9]), "v"(x[10]), "s"(y[10]), "v"(x[11]), "s"(y[11]), "v"(x[12]), "s"(y[12]), "v"(x[13]), "s"(y[13])
+            : "vcc");
+    }
+};
 
 // a * b / R' mod p (+ possibly p): operands may be lazy (limbs < 2^30, value < 2^7 p); result limbs normalised
 // (< 2^28, top limb small), value < 1.01 p.
@@ -299,7 +526,7 @@ __device__ __forceinline__ FqU fqu_mul(const FqU& a, const FqU& b) {
     constexpr int N = 14;
     u32 m[N];
     FqU r;
-    u64 acc = 0;
+    u64 acc;   // set by the first product (mad_first)
     static_for<0, 2 * N - 1>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int i0 = k < N ? 0 : k - N + 1;
@@ -311,7 +538,8 @@ __device__ __forceinline__ FqU fqu_mul(const FqU& a, const FqU& b) {
                 xs[t] = a.l[i0 + t];
                 ys[t] = b.l[k - i0 - t];
             }
-            MadU<cab>::run(acc, xs, ys);
+            if constexpr (k == 0) acc = mad_first(xs[0], ys[0]);
+            else MadU<cab>::run(acc, xs, ys);
         }
         constexpr int cmp = (k < N ? k - 1 : N - 1) - i0 + 1;
         if constexpr (cmp > 0) {
@@ -321,11 +549,12 @@ __device__ __forceinline__ FqU fqu_mul(const FqU& a, const FqU& b) {
                 xs[t] = m[i0 + t];
                 ys[t] = fqu_p(k - i0 - t);
             }
-            MadU<cmp>::run(acc, xs, ys);
+            MadUS<cmp>::run(acc, xs, ys);   // p's limbs from scalar registers
         }
         if constexpr (k < N) {
             m[k] = (0u - (u32)acc) & FQU_MASK;   // -p^-1 == -1 mod 2^28
-            acc += m[k];                         // + m[k] * p[0]: the low 28 bits become 0
+            acc += FQU_MASK;                     // == (acc + m[k] * p[0]) after the shift below: carries out of the low 28 bits iff they are non-zero
+                                                 // (and needs no zero-extended copy of m[k]: one v_mov per column less)
         } else {
             r.l[k - N] = (u32)acc & FQU_MASK;
         }
@@ -344,7 +573,7 @@ __device__ __forceinline__ FqU fqu_sqr(const FqU& a) {
 #pragma unroll
     for (int i = 0; i < N; i++) a2[i] = a.l[i] << 1;
     FqU r;
-    u64 acc = 0;
+    u64 acc;   // set by the first product (mad_first)
     static_for<0, 2 * N - 1>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int i0 = k < N ? 0 : k - N + 1;
@@ -361,7 +590,8 @@ __device__ __forceinline__ FqU fqu_sqr(const FqU& a) {
         }
         if constexpr (k % 2 == 0) {
             u32 xs[1] = {a.l[k / 2]}, ys[1] = {a.l[k / 2]};
-            MadU<1>::run(acc, xs, ys);
+            if constexpr (k == 0) acc = mad_first(xs[0], ys[0]);
+            else MadU<1>::run(acc, xs, ys);
         }
         constexpr int cmp = (k < N ? k - 1 : N - 1) - i0 + 1;
         if constexpr (cmp > 0) {
@@ -371,11 +601,11 @@ __device__ __forceinline__ FqU fqu_sqr(const FqU& a) {
                 xs[t] = m[i0 + t];
                 ys[t] = fqu_p(k - i0 - t);
             }
-            MadU<cmp>::run(acc, xs, ys);
+            MadUS<cmp>::run(acc, xs, ys);   // p's limbs from scalar registers
         }
         if constexpr (k < N) {
             m[k] = (0u - (u32)acc) & FQU_MASK;
-            acc += m[k];
+            acc += FQU_MASK;                     // see fqu_mul
         } else {
             r.l[k - N] = (u32)acc & FQU_MASK;
         }
@@ -392,7 +622,7 @@ __device__ __forceinline__ FqU fqu_mul_add(const FqU& a, const FqU& b, const FqU
     constexpr int N = 14;
     u32 m[N];
     FqU r;
-    u64 acc = 0;
+    u64 acc;   // set by the first product (mad_first)
     static_for<0, 2 * N - 1>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int i0 = k < N ? 0 : k - N + 1;
@@ -404,7 +634,8 @@ __device__ __forceinline__ FqU fqu_mul_add(const FqU& a, const FqU& b, const FqU
                 xs[t] = a.l[i0 + t];
                 ys[t] = b.l[k - i0 - t];
             }
-            MadU<cab>::run(acc, xs, ys);
+            if constexpr (k == 0) acc = mad_first(xs[0], ys[0]);
+            else MadU<cab>::run(acc, xs, ys);
 #pragma unroll
             for (int t = 0; t < cab; t++) {
                 xs[t] = c.l[i0 + t];
@@ -420,11 +651,11 @@ __device__ __forceinline__ FqU fqu_mul_add(const FqU& a, const FqU& b, const FqU
                 xs[t] = m[i0 + t];
                 ys[t] = fqu_p(k - i0 - t);
             }
-            MadU<cmp>::run(acc, xs, ys);
+            MadUS<cmp>::run(acc, xs, ys);   // p's limbs from scalar registers
         }
         if constexpr (k < N) {
             m[k] = (0u - (u32)acc) & FQU_MASK;
-            acc += m[k];
+            acc += FQU_MASK;                     // see fqu_mul
         } else {
             r.l[k - N] = (u32)acc & FQU_MASK;
         }
@@ -441,7 +672,7 @@ __device__ __forceinline__ FqU fqu_mul_add4(const FqU& a, const FqU& b, const Fq
     constexpr int N = 14;
     u32 m[N];
     FqU r;
-    u64 acc = 0;
+    u64 acc;   // set by the first product (mad_first)
     static_for<0, 2 * N - 1>([&](auto K) {
         constexpr int k = decltype(K)::value;
         constexpr int i0 = k < N ? 0 : k - N + 1;
@@ -453,7 +684,8 @@ __device__ __forceinline__ FqU fqu_mul_add4(const FqU& a, const FqU& b, const Fq
                 xs[t] = a.l[i0 + t];
                 ys[t] = b.l[k - i0 - t];
             }
-            MadU<cab>::run(acc, xs, ys);
+            if constexpr (k == 0) acc = mad_first(xs[0], ys[0]);
+            else MadU<cab>::run(acc, xs, ys);
 #pragma unroll
             for (int t = 0; t < cab; t++) {
                 xs[t] = c.l[i0 + t];
@@ -481,11 +713,11 @@ __device__ __forceinline__ FqU fqu_mul_add4(const FqU& a, const FqU& b, const Fq
                 xs[t] = m[i0 + t];
                 ys[t] = fqu_p(k - i0 - t);
             }
-            MadU<cmp>::run(acc, xs, ys);
+            MadUS<cmp>::run(acc, xs, ys);   // p's limbs from scalar registers
         }
         if constexpr (k < N) {
             m[k] = (0u - (u32)acc) & FQU_MASK;
-            acc += m[k];
+            acc += FQU_MASK;                     // see fqu_mul
         } else {
             r.l[k - N] = (u32)acc & FQU_MASK;
         }
