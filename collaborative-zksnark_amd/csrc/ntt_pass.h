@@ -5,11 +5,17 @@
 
 namespace czk {
 
-// Format of the scratch lanes between passes.  false (default): canonical elements (8 x u32, < r).  true: LAZY elements (nine
-// 29-bit limbs = 36 bytes, value < 2 r), which saves the pack / conditional subtraction / unpack round trip (-13 instructions
-// per butterfly) but reads and writes 36-byte elements with 4-byte accesses -- measured SLOWER on MI355X (2^21 x 4 lanes:
-// 0.914 ms against 0.881 ms), so it is off; kept because the bound analysis for it is done and tested.
-constexpr bool NTT2_LAZY_SCRATCH = false;
+// Format of the scratch lanes between passes:
+//   0  canonical elements (8 x u32, < r);
+//   1  LAZY elements of nine 29-bit limbs = 36 bytes, value < 2 r: saves the pack / conditional subtraction / unpack round trip but
+//      reads and writes 36-byte elements with 4-byte accesses -- measured SLOWER on MI355X (2^21 x 4 lanes: 0.914 ms against 0.881 ms);
+//   2  (default) values < 2 r PACKED into the same 8 x u32 as format 0 (2 r < 2^254): 16-byte accesses like format 0, but the
+//      conditional subtraction that makes the value canonical is only done by the last pass.
+// In formats 1 and 2 a pass after the first starts from the bound 2 instead of 1.003 and uses the next larger constants (see the
+// bound analysis in ntt_pass.hip).  All three are kept compilable; tests run against whichever is selected.
+constexpr int NTT2_SCRATCH_FORMAT = 2;
+constexpr bool NTT2_LAZY_SCRATCH = NTT2_SCRATCH_FORMAT == 1;
+constexpr bool NTT2_SCRATCH_2R = NTT2_SCRATCH_FORMAT != 0;
 constexpr size_t NTT2_SCRATCH_ELEM_BYTES = NTT2_LAZY_SCRATCH ? 36 : 32;
 
 struct Pass2Args {

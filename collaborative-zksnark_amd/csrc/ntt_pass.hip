@@ -76,9 +76,10 @@ __device__ __forceinline__ void radix4(FrU* x, const FrU* tw) {
 // j = 0, i.e. 3 of the 4 (7 of the 12) multiplies of a group would multiply by one.  They are left out: the difference stays a
 // lazy value (no Montgomery product to bring it below 2 r), so ALL outputs are re-normalised instead of half of them, and the
 // bounds become (units of r, KB = bound of the inputs, real inputs <= KB / 2 + 0.1):
-//   radix-4: d02 < 1.5 KB;  x0 < 2 KB;  x1 = s02 - x1 + 2 KB r < 3 KB + 0.2;  x2, x3 < 1.5 KB + 2      -> max 192.2 at KB = 64
-//   radix-8: x1 = x0 - x1 + 4 KB r < 6 KB + 0.1 = 96.1 at KB = 16, everything else below              (< 220: fru_mul's limit
-//   for the post-scale multiply; < 256: fru_canon's).  Limbs stay below 3.5 * 2^30 before the normalisation.
+//   radix-4: d02 < 1.5 KB;  x0 < 2 KB;  x1 = s02 - x1 + 2 KB r < 3 KB + 0.2;  x2, x3 < 1.5 KB + 2      -> max 192.2 at KB = 64, 384.2 at
+//   KB = 128 (inputs < 2 r: scratch formats 1 and 2);  radix-8: x1 = x0 - x1 + 4 KB r < 6 KB + 0.1 = 96.1 at KB = 16, 192.1 at KB = 32.
+//   Limits: 440 for fru_mul against a canonical factor (the post-scale constants are), 2^261 = 438 r for the limb form and for
+//   fru_canon's quotient estimate.  Limbs stay below 3.5 * 2^30 before the normalisation.
 // tw1 = the stage-1 twiddle of index 1 (the primitive fourth root); tw2[1..4) = stage-2 twiddles of index 1..3.
 template <int KB>
 __device__ __forceinline__ void radix4_last(FrU* x, const FrU& tw1) {
@@ -140,7 +141,8 @@ __device__ __forceinline__ void lds_put9(u32* s, unsigned e, const FrU& v) {
 
 template <bool LAZY_IN>
 __device__ __forceinline__ FrU load_input(const Pass2Args& a, const u64* in, size_t gi) {
-    if constexpr (LAZY_IN) return tab_load((const u32*)in, gi);   // lazy scratch lanes: 9 limbs per element
+    if constexpr (LAZY_IN && NTT2_LAZY_SCRATCH) return tab_load((const u32*)in, gi);   // 36-byte scratch lanes: 9 limbs per element
+    // (scratch format 2: the same 8 x u32 re-slicing as a canonical element, the value is merely < 2 r instead of < r)
     if (a.first && gi >= a.in_len) {
         FrU z;
 #pragma unroll
@@ -152,6 +154,10 @@ __device__ __forceinline__ FrU load_input(const Pass2Args& a, const u64* in, siz
     return v;
 }
 __device__ __forceinline__ void store_output(const Pass2Args& a, u64* out, size_t k, const FrU& v, bool last) {
+    if (!last && NTT2_SCRATCH_2R && !NTT2_LAZY_SCRATCH) {   // scratch format 2: < 2 r, packed; no conditional subtraction
+        fp_store<FrParams>(out + 4 * k, fru_pack(fru_reduce_2r(v)));
+        return;
+    }
     if (!last && NTT2_LAZY_SCRATCH) {   // scratch lanes, lazy format
         const FrU t = fru_reduce_2r(v);
         u32* p = (u32*)out + 9 * k;
@@ -242,7 +248,7 @@ __global__ __launch_bounds__((1 << K) * 2) void k_ntt2_strided(Pass2Args a) {
     const size_t base = (H << (a.s_lo + K)) | ((size_t)Lb << NTT2_LOGT);
     const unsigned low0 = Lb << NTT2_LOGT;
     constexpr int W = LAZY_IN ? 2 : 1;   // inputs < 2 r instead of < 1.003 r: constants one power of two up
-    const u64* in = (const u64*)((const char*)a.in + (LAZY_IN ? 36 : 32) * a.lane_stride * blockIdx.y);
+    const u64* in = (const u64*)((const char*)a.in + (LAZY_IN ? NTT2_SCRATCH_ELEM_BYTES : 32) * a.lane_stride * blockIdx.y);
     u64* out = (u64*)((char*)a.out + NTT2_SCRATCH_ELEM_BYTES * a.lane_stride * blockIdx.y);
     if constexpr (K == 7) {
         strided_step<7, 4, 3, 2 * W, true, false, LAZY_IN>(a, smem2, in, out, base, low0);
@@ -291,10 +297,10 @@ __device__ __forceinline__ void final_step(const Pass2Args& a, u32* smem, const 
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const unsigned l = l0 | ((unsigned)k << B0);
-            if constexpr (FROM_GLOBAL) x[k] = load_input<NTT2_LAZY_SCRATCH>(a, in, (h << C) | l);
+            if constexpr (FROM_GLOBAL) x[k] = load_input<NTT2_SCRATCH_2R>(a, in, (h << C) | l);
             else x[k] = lds_get9<NEL>(smem, t * RS + l);
         }
-        if constexpr (B0 == 0 && !NTT2_LAZY_SCRATCH) {   // the transform's last stages: unit twiddles are not multiplied (radix*_last)
+        if constexpr (B0 == 0) {   // the transform's last stages: unit twiddles are not multiplied (radix*_last)
             const u32* tw_s1 = a.tw + 9 * 1;             // stage 1: entries 1, 2 of the compacted table = w_4^0, w_4^1
             if constexpr (RB == 3) {
                 FrU tw2[4];
@@ -335,7 +341,7 @@ __device__ __forceinline__ void final_step(const Pass2Args& a, u32* smem, const 
 template <int C>
 __global__ __launch_bounds__((1 << C) * 2) void k_ntt2_final(Pass2Args a) {   // input: scratch lanes
     extern __shared__ __attribute__((aligned(16))) u32 smem2[];
-    constexpr int W = NTT2_LAZY_SCRATCH ? 2 : 1;
+    constexpr int W = NTT2_SCRATCH_2R ? 2 : 1;   // inputs < 2 r
     const u64* in = (const u64*)((const char*)a.in + NTT2_SCRATCH_ELEM_BYTES * a.lane_stride * blockIdx.y);
     u64* out = a.out + 4 * a.lane_stride * blockIdx.y;
     if constexpr (C == 7) {
@@ -399,7 +405,7 @@ int launch_ntt2_pass(czk_ctx* ctx, const Pass2Args& a, unsigned K, bool last, si
         return set_err(ctx, CZK_ERR_HIP, "NTT pass needs " + std::to_string(lds_need) + " bytes of LDS per workgroup; this device offers " + std::to_string(ctx->lds_per_block));
     if (!last) {
         const size_t lds = (size_t)9 * ((size_t)1 << (K + NTT2_LOGT)) * 4;
-        if (a.first || !NTT2_LAZY_SCRATCH) {
+        if (a.first || !NTT2_SCRATCH_2R) {
             if (K == 7) hipLaunchKernelGGL((k_ntt2_strided<7, false>), grid, block, lds, ctx->stream, a);
             else if (K == 6) hipLaunchKernelGGL((k_ntt2_strided<6, false>), grid, block, lds, ctx->stream, a);
             else hipLaunchKernelGGL((k_ntt2_strided<5, false>), grid, block, lds, ctx->stream, a);
