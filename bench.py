@@ -512,6 +512,8 @@ def main():
                          "party: ONE proof, party p's lanes on rank p (--gpus == --parties), opens all-gathered over RCCL")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rigs with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for this rank (default LOCAL_RANK)")
+    ap.add_argument("--no-tables", action="store_true", help="groth16: register the proving key with CZK_MEM_NO_TABLES (points only, one bucket set per window): "
+                                                             "1/13 of the key memory -- what lets 8 party ranks of the 2^22 configuration share ONE GPU")
     ap.add_argument("--commit-opens", action="store_true", help="party layout: dx_t goes through atomic_broadcast (SHA-256 commit-then-open, channel.rs:50-75)")
     ap.add_argument("--inflight", type=int, default=None, help="plonk / marlin, replica layout: independent proofs in flight per GPU, each on its own context "
                                                                  "(default: plonk 2 -- measured 203 -> 180 ms per proof --, marlin 1: one proof already saturates the GPU, 259 vs 273 ms)")
@@ -562,10 +564,10 @@ def main():
     if args.workload != "groth16":
         return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)
     if party_layout:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank])
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables)
         prover.commit_opens = args.commit_opens
     else:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties)
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables)
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)
@@ -646,6 +648,8 @@ def main():
                 break
             except Exception:
                 pass
+    if args.no_tables or n_constraints != 1 << 20 or args.parties != 2 or party_layout:
+        traffic, traffic_src = None, None        # the profile is of the default configuration only
 
     out = {
         # BASELINE.json's metric string for the BASELINE configuration; other sizes / party counts say what they are
@@ -681,7 +685,7 @@ def main():
                                   (f"ONE proof over {world} GPUs, party p's two share lanes on rank p; each of the two opens of the witness map is the "
                                    f"reference's two broadcast rounds (sh lanes, then dx_t = mac_share * value - mac) as all-gathers over {args.backend}, "
                                    "sums and the MAC check on device"),
-                   "layout": args.layout, "results_sha256": digest},
+                   "layout": args.layout, "results_sha256": digest, "window_tables": not args.no_tables},
         "roofline": {"bound": "hbm", "kernel": "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
