@@ -26,6 +26,8 @@
 //     then bit-sum tree reductions (msm_acc.h k_reduce_tail_*).
 //   * consecutive MSMs pipeline over three internal streams (msm_enqueue below).
 //   * `lanes` scalar vectors that share the bases (SPDZ sh / mac lanes) ride on gridDim.y.
+//   * bases registered WITHOUT tables (CZK_MEM_NO_TABLES; one-shot callers): the W digit windows of a lane become W virtual lanes
+//     of the same kernels, one bucket set each, and the per-window results are combined on the host (msm_enqueue, b->split).
 // All arithmetic is 32-bit-limb integer VALU (field.h); nothing here is MFMA-shaped.
 #include <stdlib.h>
 #include <string.h>
