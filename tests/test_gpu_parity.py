@@ -874,3 +874,38 @@ def test_many_share_lanes(ctx, czk, orc):
             for ln in range(lanes):
                 assert _same_point(ctx, orc, g, got[ln], orc.msm(g, bases, np.zeros(n, dtype=np.uint8), sc[ln])), (g, ln, no_tables)
             b.release()
+
+
+@pytest.mark.parametrize("case", range(14))
+def test_msm_randomised_shapes_both_table_forms(ctx, czk, orc, case):
+    """Seeded fuzz over the shapes the fixed cases do not hit: sizes around the window-width switches (16 383 / 16 384 points,
+    where narrow top windows stop being allowed), odd lane counts, random infinity patterns, scalar mixes with many zeros, ones,
+    small values, r - small values and repeated bases -- table form and CZK_MEM_NO_TABLES against the checker's Pippenger."""
+    rng = np.random.default_rng(0x5EED + case)
+    g = 1 if case % 4 else 2
+    n = int([1, 2, 3, 17, 255, 1023, 1025, 4097, 16383, 16384, 16385, 40000, 65537, 9][case])
+    if g == 2:
+        n = min(n, 1500)
+    lanes = int(rng.integers(1, 6))
+    _, bases = _bases(ctx, g, n, 12000 + case)
+    if n > 8:                                               # repeated and opposite bases
+        idx = rng.integers(0, n, size=max(2, n // 50))
+        bases[idx[1:]] = bases[idx[0]]
+    inf = (rng.random(n) < 0.1).astype(np.uint8)
+    sc = rand_fr_canonical(13000 + case, lanes * n).reshape(lanes, n, 4)
+    kind = rng.integers(0, 6, size=(lanes, n))
+    small = ints_to_limbs([int(v) for v in rng.integers(0, 1 << 20, size=64)], 4)
+    for ln in range(lanes):
+        sc[ln, kind[ln] == 0] = 0
+        sc[ln, kind[ln] == 1] = ints_to_limbs([1], 4)[0]
+        m2 = np.nonzero(kind[ln] == 2)[0]
+        sc[ln, m2] = small[rng.integers(0, 64, size=m2.size)]
+        m3 = np.nonzero(kind[ln] == 3)[0]
+        sc[ln, m3] = ints_to_limbs([R_MOD - 1 - int(v) for v in rng.integers(0, 1000, size=max(1, m3.size))], 4)[: m3.size]
+    want = [orc.msm(g, bases, inf, sc[ln]) for ln in range(lanes)]
+    for flag in (0, czk.CZK_MEM_NO_TABLES):
+        b = ctx.register_bases(g, bases, inf, mem=czk.CZK_MEM_HOST | flag)
+        got = ctx.msm(b, sc, lanes=lanes)
+        for ln in range(lanes):
+            assert _same_point(ctx, orc, g, got[ln], want[ln]), (case, g, n, lanes, ln, flag)
+        b.release()
