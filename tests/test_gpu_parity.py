@@ -909,3 +909,42 @@ def test_msm_randomised_shapes_both_table_forms(ctx, czk, orc, case):
         for ln in range(lanes):
             assert _same_point(ctx, orc, g, got[ln], want[ln]), (case, g, n, lanes, ln, flag)
         b.release()
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_ntt_randomised_shapes(ctx, czk, orc, case):
+    """Seeded fuzz: domain sizes 2^0 .. 2^18 and 3 * 2^k, any prefix length (0 .. D) with a garbage tail, 1 .. 5 lanes, all four
+    kinds, host and device memory -- every limb against the checker."""
+    import torch
+    rng = np.random.default_rng(0xF17 + case)
+    mixed = case % 4 == 3
+    if mixed:
+        k = int(rng.integers(0, 15))
+        size = 3 << k
+    else:
+        log_d = int(rng.integers(0, 19))
+        size = 1 << log_d
+    lanes = int(rng.integers(1, 6))
+    in_len = int(rng.integers(0, size + 1))
+    x = orc.fr_from_repr(rand_fr_canonical(15000 + case, lanes * max(in_len, 1))).reshape(lanes, max(in_len, 1), 4)[:, :in_len]
+    for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+        buf = np.full((lanes, size, 4), 0xDEADBEEFDEADBEEF, dtype=np.uint64)
+        buf[:, :in_len] = x
+        if case % 2:
+            t = torch.from_numpy(buf.view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            if mixed:
+                ctx.ntt_fr_mixed(t.data_ptr(), size, kind, lanes=lanes, in_len=in_len, mem=czk.CZK_MEM_DEVICE)
+            else:
+                ctx.ntt_fr(t.data_ptr(), log_d, kind, lanes=lanes, in_len=in_len, mem=czk.CZK_MEM_DEVICE)
+            ctx.sync()
+            got = t.cpu().numpy().view(np.uint64)
+        else:
+            if mixed:
+                ctx.ntt_fr_mixed(buf, size, kind, lanes=lanes, in_len=in_len)
+            else:
+                ctx.ntt_fr(buf, log_d, kind, lanes=lanes, in_len=in_len)
+            got = buf
+        for ln in range(lanes):
+            want = orc.ntt_fr_mixed(x[ln], size, kind, in_len) if mixed else orc.ntt_fr(x[ln], log_d, kind, in_len)
+            assert np.array_equal(got[ln], want), (case, size, in_len, lanes, kind, ln)
