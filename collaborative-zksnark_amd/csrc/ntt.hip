@@ -21,6 +21,9 @@
 //     twiddles in LDS.
 //   * lanes (sh / mac share lanes, several parties) ride on gridDim.y.
 // Arithmetic is integer VALU (v_mad_u64_u32); there is no MFMA-shaped work here.
+#include <atomic>
+#include <thread>
+
 #include "czk_internal.h"
 #include "ntt_pass.h"
 
@@ -476,6 +479,60 @@ using namespace czk;
 // ------------------------------------------------------------------------------------------------
 // C ABI (NTT + pointwise part)
 // ------------------------------------------------------------------------------------------------
+// Host-memory callers with several large lanes (the reference's Vec<MpcField> repacked into share lanes): lane k + 1 goes up
+// while lane k comes down -- PCIe is full duplex, but a copy from / to pageable memory blocks its calling thread, so the
+// downloads run on a second host thread and a second stream.  The transform of a lane is a fraction of its transfer time.
+static int ntt_host_lanes_pipelined(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int kind, size_t in_len) {
+    const size_t lane_words = (size_t)4 << log_d, lane_bytes = lane_words * 8;
+    DeviceBuf buf;
+    CZK_TRY(stage_take(ctx, lanes * lane_bytes, &buf));
+    std::vector<hipEvent_t> done(lanes, nullptr);
+    hipStream_t down = nullptr;
+    hipError_t setup = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
+    for (auto& e : done)
+        if (setup == hipSuccess) setup = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    std::atomic<size_t> ready{0};
+    std::atomic<int> failed{0};
+    int rc = CZK_OK;
+    if (setup != hipSuccess) {
+        rc = set_err(ctx, CZK_ERR_HIP, std::string("NTT lane pipeline set-up: ") + hipGetErrorString(setup));
+    } else {
+        const int device = ctx->device;
+        std::thread downloader([&] {
+            (void)hipSetDevice(device);
+            for (size_t k = 0; k < lanes; k++) {
+                while (ready.load(std::memory_order_acquire) <= k && !failed.load()) std::this_thread::yield();
+                if (failed.load()) return;
+                if (hipStreamWaitEvent(down, done[k], 0) != hipSuccess ||
+                    hipMemcpyAsync(data + k * lane_words, (char*)buf.p + k * lane_bytes, lane_bytes, hipMemcpyDeviceToHost, down) != hipSuccess ||
+                    hipStreamSynchronize(down) != hipSuccess) {
+                    failed.store(2);
+                    return;
+                }
+            }
+        });
+        for (size_t k = 0; k < lanes && rc == CZK_OK; k++) {
+            u64* lane = (u64*)((char*)buf.p + k * lane_bytes);
+            // only the first in_len elements are read by the transform (the tail is taken as zero)
+            const size_t up = (in_len < ((size_t)1 << log_d) ? in_len : ((size_t)1 << log_d)) * 32;
+            if (up && hipMemcpyAsync(lane, data + k * lane_words, up, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+                rc = set_err(ctx, CZK_ERR_HIP, "H2D lane");
+            if (rc == CZK_OK) rc = ntt_device(ctx, lane, log_d, 1, kind, in_len);
+            if (rc == CZK_OK && hipEventRecord(done[k], ctx->stream) != hipSuccess) rc = set_err(ctx, CZK_ERR_HIP, "event record");
+            if (rc == CZK_OK) ready.store(k + 1, std::memory_order_release);
+        }
+        if (rc != CZK_OK) failed.store(1);
+        downloader.join();
+        if (rc == CZK_OK && failed.load() == 2) rc = set_err(ctx, CZK_ERR_HIP, "D2H lane");
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : done)
+        if (e) (void)hipEventDestroy(e);
+    if (down) (void)hipStreamDestroy(down);
+    stage_give(ctx, buf);
+    return rc;
+}
+
 extern "C" int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int kind, size_t in_len, int mem) {
     if (!ctx) return CZK_ERR_ARG;
     if (!data && lanes) return set_err(ctx, CZK_ERR_ARG, "null data");
@@ -483,6 +540,7 @@ extern "C" int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t l
     if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     size_t bytes = lanes * ((size_t)32 << log_d);
+    if (mem == CZK_MEM_HOST && lanes > 1 && log_d >= 16) return ntt_host_lanes_pipelined(ctx, data, log_d, lanes, kind, in_len);
     Staged s{ctx};
     CZK_TRY(s.to_device(data, bytes, mem));
     CZK_TRY(ntt_device(ctx, (u64*)s.dev, log_d, lanes, kind, in_len));
