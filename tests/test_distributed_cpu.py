@@ -94,3 +94,35 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120, env=env, cwd=ROOT)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_polyiop_party_digests_agree_between_layouts():
+    """bench.py compares the party-per-rank layout of the Plonk / Marlin provers with the all-lanes-on-one-GPU layout party by
+    party: the digest of party p's lane slice of the one-GPU outputs must equal the digest rank p computes over its own lanes;
+    single-lane (public) entries belong to every party."""
+    import importlib.util
+    import os
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rng = np.random.default_rng(5)
+    parties, per = 2, 2
+    lanes = parties * per
+    full = {"w_cmt": (rng.integers(0, 1 << 63, size=(lanes, 12), dtype=np.uint64), np.zeros(lanes, dtype=np.uint8)),
+            "t_cmt": (rng.integers(0, 1 << 63, size=(1, 12), dtype=np.uint64), np.zeros(1, dtype=np.uint8)),       # a public polynomial
+            "evals_beta": [rng.integers(0, 1 << 63, size=(lanes, 4), dtype=np.uint64), rng.integers(0, 1 << 63, size=(1, 4), dtype=np.uint64)],
+            "open_beta": {"value": rng.integers(0, 1 << 63, size=(lanes, 4), dtype=np.uint64), "point": 12345, "fold": 7,
+                          "proof": (rng.integers(0, 1 << 63, size=(lanes, 12), dtype=np.uint64), np.zeros(lanes, dtype=np.uint8))}}
+
+    def mine(x, p):
+        if isinstance(x, dict):
+            return {k: mine(v, p) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return type(x)(mine(v, p) for v in x)
+        if isinstance(x, np.ndarray) and x.shape[0] == lanes:
+            return x[p * per:(p + 1) * per].copy()
+        return x
+    replica = bench._polyiop_party_digests(full, lanes, parties)
+    ranks = [bench._polyiop_party_digests(mine(full, p), per, 1, only=0)[0] for p in range(parties)]
+    assert replica == ranks and replica[0] != replica[1]
