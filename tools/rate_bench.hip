@@ -63,6 +63,20 @@ __global__ void k_rate(u32* out, int iters) {
             M(b0, c0) M(b1, c1) M(b2, c2) M(b3, c3)
 #undef M
             a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = c0; a5 = c1; a6 = c2; a7 = c3;
+        } else if (MODE == 10) {   // v_sad_u32 d = |s - b| + a with the constant in an SGPR: the one-instruction form of a + (C - b)
+            u32 b0 = (u32)a0, b1 = (u32)a1, b2 = (u32)a2, b3 = (u32)a3, b4 = (u32)a4, b5 = (u32)a5, b6 = (u32)a6, b7 = (u32)a7;
+            const u32 cst = 0x40000000u + (u32)iters;
+#define M(B) asm volatile("v_sad_u32 %0, %1, %2, %0" : "+v"(B) : "s"(cst), "v"(x));
+            M(b0) M(b1) M(b2) M(b3) M(b4) M(b5) M(b6) M(b7)
+#undef M
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+        } else if (MODE == 11) {   // the two-instruction form it would replace
+            u32 b0 = (u32)a0, b1 = (u32)a1, b2 = (u32)a2, b3 = (u32)a3, b4 = (u32)a4, b5 = (u32)a5, b6 = (u32)a6, b7 = (u32)a7;
+            const u32 cst = 0x40000000u + (u32)iters;
+#define M(B) asm volatile("v_sub_u32 %1, %2, %1\n v_add_u32 %0, %0, %1" : "+v"(B), "+v"(y) : "s"(cst));
+            M(b0) M(b1) M(b2) M(b3) M(b4) M(b5) M(b6) M(b7)
+#undef M
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
         }
     }
     out[t] = (u32)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7) + (u32)((a0 ^ a5) >> 32);
@@ -78,10 +92,10 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const char* names[] = {"v_mad_u64_u32", "v_lshrrev_b64", "v_lshl_add_u64", "v_alignbit_b32 + v_lshrrev_b32 (2 instr)", "v_ashrrev_i64", "v_mad_i64_i32", "v_and_b32", "v_add3_u32",
-                           "v_mad_u64_u32 + s_nop 0 (2 slots)", "v_mul_u32_u24 + v_mul_hi_u32_u24 (2 instr)"};
+                           "v_mad_u64_u32 + s_nop 0 (2 slots)", "v_mul_u32_u24 + v_mul_hi_u32_u24 (2 instr)", "v_sad_u32 (sgpr, v, v)", "v_sub_u32 + v_add_u32 (2 instr)"};
 #define RUN(MODE) { hipLaunchKernelGGL(k_rate<MODE>, dim3(blocks), dim3(threads), 0, 0, out, 10); CK(hipDeviceSynchronize()); CK(hipEventRecord(e0)); \
     hipLaunchKernelGGL(k_rate<MODE>, dim3(blocks), dim3(threads), 0, 0, out, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); \
     double ops = (double)blocks * threads * iters * 8; printf("%-44s %8.3f ms  %9.1f G lane-ops/s (8 per loop iteration)\n", names[MODE], ms, ops / ms / 1e6); }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11)
     return 0;
 }
