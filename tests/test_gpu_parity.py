@@ -948,3 +948,18 @@ def test_ntt_randomised_shapes(ctx, czk, orc, case):
         for ln in range(lanes):
             want = orc.ntt_fr_mixed(x[ln], size, kind, in_len) if mixed else orc.ntt_fr(x[ln], log_d, kind, in_len)
             assert np.array_equal(got[ln], want), (case, size, in_len, lanes, kind, ln)
+
+
+def test_msm_without_window_tables_empty_and_all_zero(ctx, czk, orc):
+    """zero() for empty inputs, all-zero scalars and all-infinity bases in the table-free form as well (variable_base.rs:16-19)."""
+    _, bases = _bases(ctx, 1, 8, 5)
+    for n in (8, 0):
+        b = ctx.register_bases(1, bases[:n] if n else np.zeros((0, 12), dtype=np.uint64), None, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_NO_TABLES)
+        out = ctx.msm(b, np.zeros((max(n, 1), 4), dtype=np.uint64)[:n] if n else rand_fr_canonical(1, 4), n_scalars=n if n else 4)
+        assert ctx.jac_to_affine(1, out[0])[1][0] == 1
+        b.release()
+    b = ctx.register_bases(1, bases, np.ones(8, dtype=np.uint8), mem=czk.CZK_MEM_HOST | czk.CZK_MEM_NO_TABLES)
+    assert ctx.jac_to_affine(1, ctx.msm(b, rand_fr_canonical(2, 8))[0])[1][0] == 1
+    b.release()
+    one = ctx.msm_oneshot(2, np.zeros((0, 24), dtype=np.uint64), None, np.zeros((0, 4), dtype=np.uint64))
+    assert ctx.jac_to_affine(2, one[0])[1][0] == 1
