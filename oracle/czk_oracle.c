@@ -1,16 +1,19 @@
 /* czk_oracle.c -- TEST INFRASTRUCTURE ONLY.
  *
- * Plain-C, single-threaded CPU restatement of the reference's hot path, limb-exact:
+ * Plain-C CPU restatement of the reference's hot path, limb-exact:
  * Fp256/Fp384 Montgomery arithmetic, Fp2, short-Weierstrass Jacobian group law, Pippenger
  * VariableBaseMSM with the reference window rule, the fffft-style in-order radix-2 FFT with the
  * reference's root selection (LARGE_SUBGROUP_ROOT_OF_UNITY^3) and coset shift (22), and the Groth16
- * witness-map / MSM sequence.  It is the checker for tests/, __graft_entry__.smoke() and the timed
+ * witness-map / MSM sequence, the mixed-radix (3 * 2^k) FFT and the GSZ share / open arithmetic.  Single-threaded like the
+ * reference's build, plus an OpenMP task-parallel variant of the same code (orc_groth16_local_par) used only by the all-core
+ * `cpu_baseline` leg.  It is the checker for tests/, __graft_entry__.smoke() and the timed
  * `cpu_baseline` leg of bench.py; the product library (collaborative-zksnark_amd/csrc) never links,
  * loads or calls it.
  *
  * Pinning: the reference cannot be built here (Rust nightly + crates.io, no cargo in the image) and holds
- * no golden NTT/MSM vectors, so this restatement is pinned against (a) the reference's constant KATs and
- * (b) the independent Python big-int oracle oracle/pyref.py, via tests/test_oracle_*.py and the
+ * no golden NTT/MSM vectors, so this restatement is pinned against (a) the reference's constant KATs, with every constant
+ * compared against the reference's source text (tools/check_constants_vs_reference.py -> tests/golden/reference_constants.json),
+ * and (b) the independent Python big-int oracle oracle/pyref.py, via tests/test_oracle_*.py and the
  * fixtures under tests/golden/.  Beyond those it is "parity unpinned" (see DESIGN.md).
  *
  * Paths in comments are relative to /root/reference.
