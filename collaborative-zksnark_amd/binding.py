@@ -53,6 +53,9 @@ def lib():
         _lib.czk_last_error.restype = C.c_char_p
         _lib.czk_version.restype = C.c_char_p
         _lib.czk_bases_len.restype = C.c_size_t
+        _lib.czk_lanes_count.restype = C.c_size_t
+        _lib.czk_lanes_len.restype = C.c_size_t
+        _lib.czk_lanes_data.restype = C.c_void_p
     return _lib
 
 
@@ -108,6 +111,13 @@ class Context:
 
     def sync(self):
         self._ck(lib().czk_ctx_sync(self._h))
+
+    # ---- device-resident share lanes ---------------------------------------------------------------
+    def lanes_alloc(self, lanes: int, length: int) -> "Lanes":
+        """czk_lanes_alloc: `lanes` x `length` Fr in HBM, zero-filled; the handle a caller without a HIP allocator uses."""
+        h = C.c_void_p(0)
+        self._ck(lib().czk_lanes_alloc(self._h, C.c_size_t(lanes), C.c_size_t(length), C.byref(h)))
+        return Lanes(self, h)
 
     # ---- NTT ------------------------------------------------------------------------------------
     def ntt_fr(self, data, log_d: int, kind: int, lanes: int = 1, in_len: int | None = None, mem: int = CZK_MEM_HOST):
@@ -374,6 +384,45 @@ class Context:
     def witness_map_post(self, ab_ptr, c_ptr, log_d, lanes, c_len=None):
         self._ck(lib().czk_witness_map_post(self._h, _ptr(ab_ptr), _ptr(c_ptr), C.c_size_t((1 << log_d) if c_len is None else c_len),
                                             C.c_uint(log_d), C.c_size_t(lanes)))
+
+
+class Lanes:
+    """czk_lanes: share lanes resident on the GPU (lane-major, 4 u64 per element)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self._h = ctx, handle
+        self.lanes, self.len = int(lib().czk_lanes_count(handle)), int(lib().czk_lanes_len(handle))
+
+    def ptr(self, lane: int = 0, elem: int = 0) -> int:
+        """Device address of one element (0 when outside the allocation): use with CZK_MEM_DEVICE."""
+        return lib().czk_lanes_data(self._h, C.c_size_t(lane), C.c_size_t(elem)) or 0
+
+    def upload(self, host, lane: int = 0, elem: int = 0):
+        host = np.ascontiguousarray(host, np.uint64)
+        self.ctx._ck(lib().czk_lanes_upload(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(host if host.size else None), C.c_size_t(host.size // 4)))
+
+    def download(self, lane: int = 0, elem: int = 0, n: int | None = None) -> np.ndarray:
+        n = self.len - elem if n is None else n
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self.ctx._ck(lib().czk_lanes_download(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(out if n else None), C.c_size_t(n)))
+        return out
+
+    def copy_from(self, src: "Lanes", n: int, lane: int = 0, elem: int = 0, src_lane: int = 0, src_elem: int = 0):
+        self.ctx._ck(lib().czk_lanes_copy(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), src._h, C.c_size_t(src_lane), C.c_size_t(src_elem), C.c_size_t(n)))
+
+    def zero(self, n: int, lane: int = 0, elem: int = 0):
+        self.ctx._ck(lib().czk_lanes_zero(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), C.c_size_t(n)))
+
+    def free(self):
+        if self._h:
+            lib().czk_lanes_free(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class R1csMatrix:

@@ -304,6 +304,7 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     ctx->stage_pool.clear();
     if (ctx->share_tab.p) (void)hipFree(ctx->share_tab.p);
     msm_pipeline_destroy(ctx);
+    xfer_destroy(ctx);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -77,6 +77,10 @@ struct MsmPending {
 
 struct czk_ctx {
     std::vector<czk::DeviceBuf> stage_pool;   // idle staging buffers of host-memory callers (core.hip)
+    // pinned double buffer of czk_lanes_upload / czk_lanes_download (lanes.hip)
+    char* xfer_pinned[2] = {nullptr, nullptr};
+    hipEvent_t xfer_ev[2] = {nullptr, nullptr};
+    bool xfer_busy[2] = {false, false};
     // MSM pipeline (msm.hip)
     hipStream_t s_sort = nullptr, s_acc = nullptr, s_red = nullptr;
     hipEvent_t ev_in = nullptr;
@@ -181,6 +185,10 @@ struct ProfScope {
         if (rc__ != CZK_OK) return rc__; \
     } while (0)
 
+// implemented in lanes.hip
+void xfer_destroy(czk_ctx* ctx);
+int upload_pageable(czk_ctx* ctx, void* dev, const void* host, size_t bytes);
+int download_pageable(czk_ctx* ctx, void* host, const void* dev, size_t bytes);
 // implemented in ntt.hip
 int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len);
 // implemented in ntt_mixed.hip

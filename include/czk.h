@@ -77,6 +77,31 @@ int czk_ctx_sync(czk_ctx* ctx);
 const char* czk_last_error(const czk_ctx* ctx);
 const char* czk_version(void);
 
+/* ---- device-resident share lanes ---------------------------------------------------------------------- */
+/* A caller without a HIP allocator of its own (the Rust shim, a C++ host) keeps share vectors on the GPU between calls through
+ * these handles: R1CStoQAP::witness_map holds `a`, `b`, `c` across seven transforms and hands `h` straight to the MSM
+ * (mpc-snarks/src/groth/r1cs_to_qap.rs:85-110, mpc-snarks/src/groth/prover.rs:104) -- with a handle none of that crosses PCIe.
+ * A czk_lanes is `lanes` x `len` Fr (lane-major, 4 u64 per element: the layout every `lanes x D x 4 u64` argument of this
+ * header has), allocated zero-filled (`vec![T::zero(); domain_size]`, r1cs_to_qap.rs:66-67) on the context's GPU.
+ * czk_lanes_data(l, lane, elem) is the address of one element: pass it wherever a buffer argument is taken with
+ * CZK_MEM_DEVICE (czk_ntt_fr, czk_fr_vec_op, czk_witness_map_pre/post, czk_r1cs_matvec, czk_msm(_async), ...).  NULL when
+ * (lane, elem) is outside the allocation.  The handle must be freed before its context is destroyed.
+ * czk_lanes_upload: n Fr from pageable HOST memory (a Rust Vec) into lane `lane` at element `elem`, staged through the context's
+ * pinned buffers; returns once `host` has been read (the caller may drop the Vec), the last DMA completes in stream order
+ * before any later call on the context (a run may continue into the following lanes: the array is contiguous).  czk_lanes_download: the reverse, blocking (the values are in `host` on return).
+ * czk_lanes_copy: device-to-device, in stream order (`let mut ab = a.clone()`).  CZK_ERR_ARG when a range leaves the lanes. */
+typedef struct czk_lanes czk_lanes;
+int czk_lanes_alloc(czk_ctx* ctx, size_t lanes, size_t len, czk_lanes** out);
+void czk_lanes_free(czk_lanes* l);
+size_t czk_lanes_count(const czk_lanes* l);
+size_t czk_lanes_len(const czk_lanes* l);
+uint64_t* czk_lanes_data(const czk_lanes* l, size_t lane, size_t elem);
+int czk_lanes_upload(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t elem, const uint64_t* host, size_t n);
+int czk_lanes_download(czk_ctx* ctx, const czk_lanes* src, size_t lane, size_t elem, uint64_t* host, size_t n);
+int czk_lanes_copy(czk_ctx* ctx, czk_lanes* dst, size_t dst_lane, size_t dst_elem, const czk_lanes* src, size_t src_lane, size_t src_elem,
+                   size_t n);
+int czk_lanes_zero(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t elem, size_t n);
+
 /* ---- NTT ---------------------------------------------------------------------------------------- */
 /* Replaces Radix2EvaluationDomain<Fr>::{fft,ifft,coset_ifft}_in_place (algebra/poly/src/domain/radix2/mod.rs:99-117)
  * and the trait-default coset_fft_in_place (domain/mod.rs:139-142) for T = Fr lanes (an MpcField<Fr, SpdzFieldShare>

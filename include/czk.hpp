@@ -16,7 +16,9 @@
 //     (mpc-algebra/src/wire/field.rs:27-30, share/spdz.rs:50-53)
 //   GroupShare::multi_scale_pub_group(bases, &[share]) (SPDZ)                SpdzGroupShare::multi_scale_pub_group
 //     (mpc-algebra/src/share/spdz.rs:440-446)
-//   R1CStoQAP::witness_map (mpc-snarks/src/groth/r1cs_to_qap.rs:47-113)      R1CStoQAP::witness_map(domain, a, b, c, batch_product)
+//   R1CStoQAP::witness_map (mpc-snarks/src/groth/r1cs_to_qap.rs:47-113)      R1CStoQAP::witness_map(domain, a, b, c [, batch_product])
+//   Vec<T> that stays alive across the witness map and feeds the h MSM        DeviceLanes (czk_lanes: the vector lives in HBM; every
+//     (r1cs_to_qap.rs:66-110, groth/prover.rs:104)                            domain / MSM / pointwise call below has a DeviceLanes form)
 //
 // Error behaviour: where the reference returns None the mirror returns std::nullopt; where it `assert!`s /
 // `unwrap()`s the mirror throws czk::Panic carrying czk_last_error() (a Rust shim would `expect()` the status).
@@ -64,6 +66,49 @@ class Context {
 
   private:
     czk_ctx* ctx_ = nullptr;
+};
+
+// `lanes` share-vector components of `capacity` Fr each, resident on the context's GPU (czk_lanes).  `len` plays the role of
+// Vec::len(): elements [len, capacity) are the zero padding `resize(size, T::zero())` would append (radix2/mod.rs:100-101) and
+// are never read -- the transforms zero-extend.  Uploads come from pageable host memory (a Rust Vec); nothing else moves.
+class DeviceLanes {
+  public:
+    DeviceLanes(const Context& ctx, size_t lanes, size_t capacity) : ctx_(&ctx), len(capacity) {
+        ctx.check(czk_lanes_alloc(ctx.raw(), lanes, capacity, &h_));
+    }
+    ~DeviceLanes() { czk_lanes_free(h_); }
+    DeviceLanes(DeviceLanes&& o) noexcept : ctx_(o.ctx_), h_(o.h_), len(o.len) { o.h_ = nullptr; }
+    DeviceLanes(const DeviceLanes&) = delete;
+    DeviceLanes& operator=(const DeviceLanes&) = delete;
+    size_t lanes() const { return czk_lanes_count(h_); }
+    size_t capacity() const { return czk_lanes_len(h_); }
+    uint64_t* data(size_t lane = 0, size_t elem = 0) const { return czk_lanes_data(h_, lane, elem); }
+    czk_lanes* raw() const { return h_; }
+    const Context& ctx() const { return *ctx_; }
+    void upload(size_t lane, size_t elem, const Fr* host, size_t n) { ctx_->check(czk_lanes_upload(ctx_->raw(), h_, lane, elem, n ? host->l : nullptr, n)); }
+    void upload(size_t lane, const std::vector<Fr>& v) { upload(lane, 0, v.data(), v.size()); }
+    void download(size_t lane, size_t elem, Fr* host, size_t n) const { ctx_->check(czk_lanes_download(ctx_->raw(), h_, lane, elem, n ? host->l : nullptr, n)); }
+    std::vector<Fr> to_host(size_t lane) const {
+        std::vector<Fr> v(len);
+        download(lane, 0, v.data(), len);
+        return v;
+    }
+    void copy_from(size_t lane, size_t elem, const DeviceLanes& src, size_t src_lane, size_t src_elem, size_t n) {
+        ctx_->check(czk_lanes_copy(ctx_->raw(), h_, lane, elem, src.h_, src_lane, src_elem, n));
+    }
+    DeviceLanes clone() const {   // `let mut ab = a.clone()`
+        DeviceLanes c(*ctx_, lanes(), capacity());
+        c.len = len;
+        c.copy_from(0, 0, *this, 0, 0, lanes() * capacity());
+        return c;
+    }
+
+  private:
+    const Context* ctx_;
+    czk_lanes* h_ = nullptr;
+
+  public:
+    size_t len;   // logical Vec length of every lane (<= capacity)
 };
 
 // mpc-algebra/src/wire/field.rs:27-30 -- MpcField<Fr, SpdzFieldShare<Fr>>: Public(x) or Shared{sh, mac}
@@ -136,6 +181,17 @@ class Radix2EvaluationDomain {
     void coset_fft_in_place(std::vector<MpcField>& v) const { run_shared(v, CZK_COSET_FFT); }
     void coset_ifft_in_place(std::vector<MpcField>& v) const { run_shared(v, CZK_COSET_IFFT); }
 
+    // T = share lanes resident on the GPU: every lane of `v` is transformed in place, nothing crosses PCIe
+    void fft_in_place(DeviceLanes& v) const { run_device(v, CZK_FFT); }
+    void ifft_in_place(DeviceLanes& v) const { run_device(v, CZK_IFFT); }
+    void coset_fft_in_place(DeviceLanes& v) const { run_device(v, CZK_COSET_FFT); }
+    void coset_ifft_in_place(DeviceLanes& v) const { run_device(v, CZK_COSET_IFFT); }
+    void divide_by_vanishing_poly_on_coset_in_place(DeviceLanes& evals) const {
+        const size_t n = evals.lanes() * evals.capacity();
+        ctx_->check(czk_fr_vec_scale(ctx_->raw(), evals.data(), vanishing_inv_.l, evals.data(), n, CZK_MEM_DEVICE));
+    }
+    const Context& ctx() const { return *ctx_; }
+
     // domain/mod.rs:184-191
     void divide_by_vanishing_poly_on_coset_in_place(std::vector<Fr>& evals) const {
         ctx_->check(czk_fr_vec_scale(ctx_->raw(), evals[0].l, vanishing_inv_.l, evals[0].l, evals.size(), CZK_MEM_HOST));
@@ -151,6 +207,11 @@ class Radix2EvaluationDomain {
         size_t in_len = v.size();
         v.resize(size_, Fr{});                                                                              // :101
         ctx_->check(czk_ntt_fr(ctx_->raw(), v[0].l, log_size_of_group, 1, kind, in_len, CZK_MEM_HOST));
+    }
+    void run_device(DeviceLanes& v, int kind) const {
+        if (v.len > size_ || v.capacity() != size_) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");   // radix2/mod.rs:100
+        ctx_->check(czk_ntt_fr(ctx_->raw(), v.data(), log_size_of_group, v.lanes(), kind, v.len, CZK_MEM_DEVICE));
+        v.len = size_;                                                                                                              // :101
     }
     void run_shared(std::vector<MpcField>& v, int kind) const {
         if (v.size() > size_) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");
@@ -168,8 +229,9 @@ class Radix2EvaluationDomain {
 template <int GROUP>
 class Bases {
   public:
-    Bases(const Context& ctx, const uint64_t* xy, const uint8_t* inf, size_t n) : ctx_(&ctx) {
-        ctx.check(czk_bases_register(ctx.raw(), GROUP, xy, inf, n, CZK_MEM_HOST, &b_));
+    // mem_flags: 0, or CZK_MEM_NO_TABLES for a key that is used once (see czk.h)
+    Bases(const Context& ctx, const uint64_t* xy, const uint8_t* inf, size_t n, int mem_flags = 0) : ctx_(&ctx) {
+        ctx.check(czk_bases_register(ctx.raw(), GROUP, xy, inf, n, CZK_MEM_HOST | mem_flags, &b_));
     }
     ~Bases() { czk_bases_release(b_); }
     Bases(const Bases&) = delete;
@@ -218,6 +280,17 @@ struct G2Affine {
         return out;
     }
 };
+
+// The same call on share lanes that are already on the GPU (the `h` vector out of the witness map, prover.rs:104; the witness /
+// assignment lanes, :108-156): `lanes` scalar vectors of `n_scalars` Fr starting at scalars.data(lane0), one result per lane.
+// Enqueue-only (czk_msm_async): consecutive MSMs pipeline; `out` is valid after ctx.sync().  stable = the caller will not
+// overwrite the scalars before that sync (CZK_MEM_STABLE).
+template <int GROUP, class Projective>
+inline void multi_scalar_mul_async(const Bases<GROUP>& bases, const DeviceLanes& scalars, size_t n_scalars, Projective* out, bool stable = false) {
+    static_assert(sizeof(Projective) == (GROUP == CZK_G1 ? 18 : 36) * 8, "Projective does not match the group");
+    bases.ctx().check(czk_msm_async(bases.ctx().raw(), bases.raw(), scalars.data(), n_scalars, scalars.lanes(), CZK_SCALAR_MONTGOMERY,
+                                    CZK_MEM_DEVICE | (stable ? CZK_MEM_STABLE : 0), reinterpret_cast<uint64_t*>(out)));
+}
 
 // mpc-algebra/src/share/spdz.rs:440-446 -- SPDZ multi_scale_pub_group: two MSMs over the same bases.
 // Like the reference (line 442 re-reads `.sh.val`), BOTH results are computed from the sh values; they are
@@ -304,6 +377,11 @@ struct ConstraintMatrix {
         ctx.check(czk_r1cs_matrix_register(ctx.raw(), row_ptr.data(), col.data(), coeff.empty() ? nullptr : coeff[0].l, rows.size(), col.size(), n_vars,
                                            CZK_MEM_HOST, &h_));
     }
+    // the same from CSR arrays (row_ptr: rows + 1 offsets, col / coeff: nnz entries), for callers that already hold the matrix flat
+    ConstraintMatrix(const Context& ctx, const uint64_t* row_ptr, const uint32_t* col, const Fr* coeff, size_t rows, size_t nnz, size_t n_vars)
+        : ctx_(&ctx), rows_(rows) {
+        ctx.check(czk_r1cs_matrix_register(ctx.raw(), row_ptr, col, nnz ? coeff->l : nullptr, rows, nnz, n_vars, CZK_MEM_HOST, &h_));
+    }
     ConstraintMatrix(const ConstraintMatrix&) = delete;
     ConstraintMatrix& operator=(const ConstraintMatrix&) = delete;
     ~ConstraintMatrix() { czk_r1cs_matrix_release(h_); }
@@ -314,26 +392,49 @@ struct ConstraintMatrix {
                                     out[0].l, out.size(), CZK_MEM_HOST));
         return out;
     }
+    // the same over share lanes on the GPU: z = lanes x z.capacity() full-assignment lanes, out[lane][0..rows) written, the
+    // rest of `out` (the zero padding up to the domain size) untouched; out.len = rows afterwards
+    void evaluate(const DeviceLanes& z, DeviceLanes& out) const {
+        ctx_->check(czk_r1cs_matvec(ctx_->raw(), h_, z.data(), z.capacity(), z.lanes(), out.data(), out.capacity(), CZK_MEM_DEVICE));
+        out.len = rows_;
+    }
 };
 
 // mpc-snarks/src/groth/r1cs_to_qap.rs:47-113 -- the NTT / pointwise sequence of witness_map for a single prover
 // (T = Fr).  `a`, `b`, `c` are the evaluated constraint rows (a[0..N), then the instance copy; :67-83, :95-100).
 // `batch_product` is F::batch_product_in_place (:92) -- a plain product here, the Beaver protocol for shares.
 struct R1CStoQAP {
-    static std::vector<Fr> witness_map(const Context& ctx, const Radix2EvaluationDomain& domain, std::vector<Fr> a, std::vector<Fr> b,
-                                       std::vector<Fr> c) {
-        domain.ifft_in_place(a);
-        domain.ifft_in_place(b);
-        domain.coset_fft_in_place(a);
-        domain.coset_fft_in_place(b);
-        std::vector<Fr> ab = a;
-        ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_MUL, ab[0].l, b[0].l, ab[0].l, ab.size(), CZK_MEM_HOST));
-        domain.ifft_in_place(c);
-        domain.coset_fft_in_place(c);
-        ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_SUB, ab[0].l, c[0].l, ab[0].l, ab.size(), CZK_MEM_HOST));
-        domain.divide_by_vanishing_poly_on_coset_in_place(ab);
-        domain.coset_ifft_in_place(ab);
-        return ab;
+    static std::vector<Fr> witness_map(const Context& ctx, const Radix2EvaluationDomain& domain, const std::vector<Fr>& a, const std::vector<Fr>& b,
+                                       const std::vector<Fr>& c) {
+        // the three vectors go up once, h comes down once: the seven transforms and the pointwise steps run on the resident lanes
+        const size_t D = domain.size();
+        if (a.size() > D || b.size() > D || c.size() > D) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");
+        DeviceLanes da(ctx, 1, D), db(ctx, 1, D), dc(ctx, 1, D), dab(ctx, 1, D);
+        da.upload(0, a); da.len = a.size();
+        db.upload(0, b); db.len = b.size();
+        dc.upload(0, c); dc.len = c.size();
+        witness_map(domain, da, db, dc, dab, [&](DeviceLanes& x, DeviceLanes& y, DeviceLanes& xy) {
+            ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_MUL, x.data(), y.data(), xy.data(), D, CZK_MEM_DEVICE));   // T = Fr: a plain product (:92)
+        });
+        return dab.to_host(0);
+    }
+
+    // T = share lanes resident on the GPU (DeviceLanes of capacity domain.size(); a.len / b.len / c.len = evaluated rows):
+    // the same sequence with the fused entry points -- czk_witness_map_pre = :85-89, batch_product = :92 (the caller's Beaver
+    // protocol writes a (*) b into `ab`), czk_witness_map_post = :102-110.  `ab` = h on return; nothing leaves HBM.
+    template <class BatchProduct>
+    static void witness_map(const Radix2EvaluationDomain& domain, DeviceLanes& a, DeviceLanes& b, DeviceLanes& c, DeviceLanes& ab,
+                            BatchProduct&& batch_product) {
+        const Context& ctx = domain.ctx();
+        const size_t lanes = a.lanes();
+        if (a.capacity() != domain.size() || b.capacity() != domain.size() || c.capacity() != domain.size() || ab.capacity() != domain.size() ||
+            b.lanes() != lanes || c.lanes() != lanes || ab.lanes() != lanes)
+            throw Panic(CZK_ERR_SIZE, "witness_map: lanes must have the domain's size");
+        ctx.check(czk_witness_map_pre(ctx.raw(), a.data(), a.len, b.data(), b.len, domain.log_size_of_group, lanes));
+        a.len = b.len = domain.size();
+        batch_product(a, b, ab);
+        ctx.check(czk_witness_map_post(ctx.raw(), ab.data(), c.data(), c.len, domain.log_size_of_group, lanes));
+        ab.len = c.len = domain.size();
     }
 };
 

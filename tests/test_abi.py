@@ -45,7 +45,7 @@ def _build_host_demo():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "tools", "host_demo.bin")
     pkg = os.path.join(root, "collaborative-zksnark_amd")
-    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "host_demo.cpp"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "host_demo.cpp"),
                            "-L" + pkg, "-lczk_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", out])
     return out
 

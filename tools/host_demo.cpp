@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "czk.hpp"
+#include "groth16_host.hpp"
 
 using namespace czk;
 
@@ -45,9 +46,119 @@ static int dump_lift(const Context& ctx) {
     return 0;
 }
 
+// `host_demo.bin bench [--log-n K | --constraints N] [--parties P] [--steps K] [--warmup W] [--no-tables] [--dump FILE]`:
+// BASELINE configs[1] (Groth16, SPDZ, both parties' lanes on one GPU) driven from this process alone -- no torch, no Python in
+// the timed loop: host vectors -> share lanes up once -> K pipelined proofs -> 20 group elements per proof down.  Prints one JSON
+// line; bench.py reports it as `seam_device_handles`.  --dump writes the h lanes and the proof elements of the last proof for
+// tests/test_gpu_parity.py to compare with the checker: u64 header {N, D, lanes}, lanes x D Fr, then per query (h, l, a, b_g1:
+// lanes x 12 u64 affine + lanes flag bytes; b_g2: lanes x 24 u64 + flags).
+static int bench(const Context& ctx, int argc, char** argv) {
+    size_t n = (size_t)1 << 20, parties = 2, steps = 20, warmup = 2;
+    bool no_tables = false;
+    const char* dump = nullptr;
+    for (int i = 2; i < argc; i++) {
+        auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
+        if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
+        else if (!strcmp(argv[i], "--constraints")) n = (size_t)atoll(val());
+        else if (!strcmp(argv[i], "--parties")) parties = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--steps")) steps = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--warmup")) warmup = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--no-tables")) no_tables = true;
+        else if (!strcmp(argv[i], "--dump")) dump = val();
+        else { printf("unknown argument %s\n", argv[i]); return 2; }
+    }
+    if (n < 2 || parties < 2 || steps < 1) { printf("bench: need --constraints >= 2, --parties >= 2, --steps >= 1\n"); return 2; }
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    g16::Groth16Host prover(ctx, n, parties, 0xC0FFEE, no_tables);
+    auto t0 = clk::now();
+    prover.step();                                            // first proof: also builds the NTT tables and sizes the workspaces
+    const double first_ms = secs(t0, clk::now()) * 1e3;
+    for (size_t i = 1; i < warmup; i++) prover.step();
+    t0 = clk::now();
+    prover.step();                                            // one proof alone: enqueue -> results on the host
+    const double latency_ms = secs(t0, clk::now()) * 1e3;
+    prover.results.clear();
+    ctx.sync();
+    t0 = clk::now();
+    for (size_t i = 0; i < steps; i++) prover.step(false);    // consecutive proofs pipeline on the context's streams
+    ctx.sync();
+    const double dt = secs(t0, clk::now());
+    // every pipelined proof has the same inputs: all must yield the same group elements (affine: Jacobian triples differ)
+    const size_t L = prover.L;
+    std::vector<uint64_t> ref_aff, aff;
+    std::vector<uint8_t> ref_inf, inf;
+    auto affine = [&](const g16::ProofElements& r, std::vector<uint64_t>& a, std::vector<uint8_t>& f) {
+        a.assign(L * (4 * 12 + 24), 0);
+        f.assign(L * 5, 0);
+        const G1Projective* g1[4] = {r.h.data(), r.l.data(), r.a.data(), r.b_g1.data()};
+        for (int q = 0; q < 4; q++) ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, g1[q]->x.l, L, &a[q * L * 12], &f[q * L]));
+        ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G2, r.b_g2.data()->x.c0.l, L, &a[4 * L * 12], &f[4 * L]));
+    };
+    REQUIRE(prover.results.size() == steps);
+    for (size_t k = 0; k < steps; k++) {
+        affine(prover.results[k], aff, inf);
+        if (k == 0) { ref_aff = aff; ref_inf = inf; }
+        REQUIRE(aff == ref_aff && inf == ref_inf);
+    }
+    const uint64_t bad = prover.mac_check_failures();
+    REQUIRE(bad == 0);
+    if (dump) {
+        FILE* f = fopen(dump, "wb");
+        REQUIRE(f != nullptr);
+        const uint64_t hdr[3] = {prover.N, prover.D, L};
+        fwrite(hdr, 8, 3, f);
+        std::vector<Fr> h(prover.D);
+        for (size_t ln = 0; ln < L; ln++) {
+            prover.h_lanes().download(ln, 0, h.data(), prover.D);
+            fwrite(h.data(), 32, prover.D, f);
+        }
+        for (int q = 0; q < 5; q++) {
+            const size_t aw = q < 4 ? 12 : 24;
+            fwrite(&ref_aff[q * L * 12], 8, L * aw, f);
+            fwrite(&ref_inf[q * L], 1, L, f);
+        }
+        fclose(f);
+    }
+    printf("{\"harness\": \"tools/host_demo.cpp bench (C++ over include/czk.hpp; no torch, no Python)\", \"constraints\": %zu, \"parties\": %zu, "
+           "\"share_lanes\": %zu, \"steps\": %zu, \"warmup\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, \"latency_ms_single_proof\": %.3f, "
+           "\"first_proof_ms\": %.3f, \"register_key_s\": %.4f, \"setup_s\": %.3f, \"window_tables\": %s, \"pipelined_proofs_equal\": true, "
+           "\"mac_check_failures\": %llu}\n",
+           prover.N, prover.P, L, steps, warmup, dt / steps * 1e3, steps / dt, latency_ms, first_ms, prover.register_s, prover.setup_s,
+           no_tables ? "false" : "true", (unsigned long long)bad);
+    return 0;
+}
+
+// `host_demo.bin inputs SEED N` (no GPU needed): the harness's own input generation -- SplitMix64 stream -> canonical values,
+// their Montgomery form, the square and the difference of neighbours with the harness's host field code -- for
+// tests/test_device_handles.py to compare with tests/util.py and the checker.
+static int dump_inputs(int argc, char** argv) {
+    const uint64_t seed = argc > 2 ? strtoull(argv[2], nullptr, 0) : 1;
+    const size_t n = argc > 3 ? (size_t)atoll(argv[3]) : 8;
+    std::vector<Fr> c = g16::rand_fr_canonical(seed, n);
+    for (size_t i = 0; i < n; i++) {
+        const Fr m = g16::hostfr::from_repr(c[i]), m2 = g16::hostfr::from_repr(c[(i + 1) % n]);
+        print_fr("canonical", c[i]);
+        print_fr("mont", m);
+        print_fr("square", g16::hostfr::mont_mul(m, m));
+        print_fr("sub", g16::hostfr::sub(m, m2));
+        print_fr("add", g16::hostfr::add(m, m2));
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && strcmp(argv[1], "inputs") == 0) return dump_inputs(argc, argv);
     Context ctx(0);
     if (argc > 1 && strcmp(argv[1], "dump-lift") == 0) return dump_lift(ctx);
+    if (argc > 1 && strcmp(argv[1], "bench") == 0) {
+        try {
+            return bench(ctx, argc, argv);
+        } catch (const Panic& p) {
+            printf("FAILED: czk::Panic %d: %s\n", p.code, p.what());
+            return 1;
+        }
+    }
     // EvaluationDomain::new -> None beyond 2^47 (radix2/mod.rs:61-63)
     REQUIRE(!Radix2EvaluationDomain::create(ctx, (size_t)1 << 48).has_value());
     auto dom = Radix2EvaluationDomain::create(ctx, 13);
