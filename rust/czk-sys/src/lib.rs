@@ -12,6 +12,10 @@ pub struct czk_bases {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct czk_lanes {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct czk_r1cs_matrix {
     _private: [u8; 0],
 }
@@ -44,6 +48,15 @@ extern "C" {
     pub fn czk_ctx_sync(ctx: *mut czk_ctx) -> c_int;
     pub fn czk_last_error(ctx: *const czk_ctx) -> *const c_char;
     pub fn czk_version() -> *const c_char;
+    pub fn czk_lanes_alloc(ctx: *mut czk_ctx, lanes: usize, len: usize, out: *mut *mut czk_lanes) -> c_int;
+    pub fn czk_lanes_free(l: *mut czk_lanes);
+    pub fn czk_lanes_count(l: *const czk_lanes) -> usize;
+    pub fn czk_lanes_len(l: *const czk_lanes) -> usize;
+    pub fn czk_lanes_data(l: *const czk_lanes, lane: usize, elem: usize) -> *mut u64;
+    pub fn czk_lanes_upload(ctx: *mut czk_ctx, dst: *mut czk_lanes, lane: usize, elem: usize, host: *const u64, n: usize) -> c_int;
+    pub fn czk_lanes_download(ctx: *mut czk_ctx, src: *const czk_lanes, lane: usize, elem: usize, host: *mut u64, n: usize) -> c_int;
+    pub fn czk_lanes_copy(ctx: *mut czk_ctx, dst: *mut czk_lanes, dst_lane: usize, dst_elem: usize, src: *const czk_lanes, src_lane: usize, src_elem: usize, n: usize) -> c_int;
+    pub fn czk_lanes_zero(ctx: *mut czk_ctx, dst: *mut czk_lanes, lane: usize, elem: usize, n: usize) -> c_int;
     pub fn czk_ntt_fr(ctx: *mut czk_ctx, data: *mut u64, log_d: c_uint, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
     pub fn czk_domain_constants(ctx: *mut czk_ctx, log_d: c_uint, out24: *mut u64) -> c_int;
     pub fn czk_ntt_fr_mixed(ctx: *mut czk_ctx, data: *mut u64, size: usize, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;

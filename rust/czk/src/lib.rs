@@ -6,6 +6,9 @@
 //!   (algebra/ec/src/lib.rs:300-311, algebra/ec/src/msm/variable_base.rs:12-106): [`msm::g1`], [`msm::g2`]
 //! * share seam -- `MpcField::{Public, Shared}` vectors as Fr lanes (mpc-algebra/src/wire/field.rs:27-30, 89-105;
 //!   share/spdz.rs:31-37, 186-208): [`share::SpdzLanes`]
+//! * resident path -- share vectors that stay on the GPU across the witness map and feed the `h` MSM
+//!   (mpc-snarks/src/groth/r1cs_to_qap.rs:85-110, mpc-snarks/src/groth/prover.rs:104): [`resident::DeviceLanes`],
+//!   [`resident::witness_map`], [`msm::Pinned::msm_resident`] -- `czk_lanes_*` handles, no HIP allocator on the Rust side
 //!
 //! Error convention: the reference panics (`assert!`, `unwrap()`, `None.unwrap()`); every wrapper here `expect()`s the C
 //! status with the library's error text, so behaviour at the seams is unchanged.
@@ -210,20 +213,74 @@ pub mod msm {
     use std::collections::HashMap;
     use std::sync::Mutex;
 
-    /// A registered base slice: the library handle, whether it carries window tables, and how often it has been used.
-    struct Registered {
+    /// A base slice pinned on the GPU with its window tables: proving-key queries and SRS powers, which outlive many MSMs
+    /// (groth16/src/data_structures.rs:132-149, poly-commit/src/kzg10/data_structures.rs).  Created ONCE where the key is loaded
+    /// (`Pinned::g1(&pk.a_query[1..])`, rust/PATCHES.md patch 1) and kept next to it; dropping it releases the device copy.
+    /// Nothing else is ever cached: a slice that was not pinned runs through the one-shot entry points (no window tables,
+    /// bases not kept), so a temporary `Vec` of bases -- `MpcG1Affine::multi_scalar_mul` builds one per call,
+    /// mpc-algebra/src/wire/pairing.rs:746-775 -- can neither hit a stale device copy nor leak one.
+    pub struct Pinned {
         handle: *mut sys::czk_bases,
-        tables: bool,
-        uses: u32,
+        group: i32,
+        key: (usize, usize, i32),
+        fingerprint: u64,
     }
-    unsafe impl Send for Registered {}
+    unsafe impl Send for Pinned {}
+
+    struct Entry {
+        handle: *mut sys::czk_bases,
+        fingerprint: u64,
+    }
+    unsafe impl Send for Entry {}
 
     lazy_static::lazy_static! {
-        // Base slices are found again by (address, length, group).  The first MSM over a slice registers it WITHOUT window
-        // tables (CZK_MEM_NO_TABLES: a copy, no precomputation -- right for the reference's prove-once binaries and for
-        // one-off commitments); a slice that comes back (proving-key queries are reused across proofs,
-        // groth16/src/data_structures.rs:132-149) is re-registered with tables, which makes every later MSM ~1.4x cheaper.
-        static ref BASES: Mutex<HashMap<(usize, usize, i32), Registered>> = Mutex::new(HashMap::new());
+        // pinned slices by (address, length, group); an entry exists exactly as long as its `Pinned` guard
+        static ref PINNED: Mutex<HashMap<(usize, usize, i32), Entry>> = Mutex::new(HashMap::new());
+    }
+
+    /// FNV-1a over the limbs of up to 32 evenly spaced points (and the length): a hit on (address, length) is only trusted
+    /// when the slice still holds what was pinned -- a guard that outlived its key, or a key mutated in place, falls back to
+    /// the one-shot path instead of multiplying with stale bases.
+    fn fingerprint(xy: &[u64], words_per_point: usize) -> u64 {
+        let n = xy.len() / words_per_point;
+        let mut h: u64 = 0xcbf29ce484222325 ^ (n as u64);
+        let step = if n > 32 { n / 32 } else { 1 };
+        let mut i = 0;
+        while i < n {
+            for w in &xy[i * words_per_point..(i + 1) * words_per_point] {
+                h = (h ^ *w).wrapping_mul(0x100000001b3);
+            }
+            i += step;
+        }
+        if n > 0 {
+            for w in &xy[(n - 1) * words_per_point..n * words_per_point] {
+                h = (h ^ *w).wrapping_mul(0x100000001b3);
+            }
+        }
+        h
+    }
+
+    fn sample_g1(bases: &[G1Affine]) -> u64 {
+        let n = bases.len();
+        let step = if n > 32 { n / 32 } else { 1 };
+        let mut idx: Vec<usize> = (0..n).step_by(step).collect();
+        if n > 0 {
+            idx.push(n - 1);
+        }
+        let pts: Vec<G1Affine> = idx.iter().map(|&i| bases[i]).collect();
+        let (xy, _) = limbs::g1_bases(&pts);
+        fingerprint(&xy, 12) ^ (n as u64).rotate_left(17)
+    }
+    fn sample_g2(bases: &[G2Affine]) -> u64 {
+        let n = bases.len();
+        let step = if n > 32 { n / 32 } else { 1 };
+        let mut idx: Vec<usize> = (0..n).step_by(step).collect();
+        if n > 0 {
+            idx.push(n - 1);
+        }
+        let pts: Vec<G2Affine> = idx.iter().map(|&i| bases[i]).collect();
+        let (xy, _) = limbs::g2_bases(&pts);
+        fingerprint(&xy, 24) ^ (n as u64).rotate_left(17)
     }
 
     fn scalars_to_limbs(scalars: &[Fr]) -> Vec<u64> {
@@ -234,45 +291,103 @@ pub mod msm {
         s
     }
 
-    fn register(ctx: &super::Context, group: i32, pts: &[u64], inf: &[u8], tables: bool) -> *mut sys::czk_bases {
-        let mut h: *mut sys::czk_bases = std::ptr::null_mut();
-        let mem = if tables { sys::CZK_MEM_HOST } else { sys::CZK_MEM_HOST | sys::CZK_MEM_NO_TABLES };
-        let rc = unsafe { sys::czk_bases_register(ctx.as_ptr(), group, pts.as_ptr(), inf.as_ptr(), inf.len(), mem, &mut h) };
-        ctx.expect(rc, "czk_bases_register");
-        h
-    }
-
-    fn run(group: i32, key: (usize, usize, i32), xy: impl Fn() -> (Vec<u64>, Vec<u8>), scalars: &[Fr], out: &mut [u64]) {
-        let ctx = CTX.lock().unwrap();
-        let mut map = BASES.lock().unwrap();
-        let entry = map.entry(key).or_insert_with(|| {
-            let (pts, inf) = xy();
-            Registered { handle: register(&ctx, group, &pts, &inf, false), tables: false, uses: 0 }
-        });
-        entry.uses += 1;
-        if entry.uses == 2 && !entry.tables {
-            let (pts, inf) = xy();
-            unsafe { sys::czk_bases_release(entry.handle) };
-            entry.handle = register(&ctx, group, &pts, &inf, true);
-            entry.tables = true;
+    impl Pinned {
+        fn new(group: i32, key: (usize, usize, i32), fp: u64, pts: &[u64], inf: &[u8]) -> Pinned {
+            let ctx = CTX.lock().unwrap();
+            let mut h: *mut sys::czk_bases = std::ptr::null_mut();
+            let rc = unsafe { sys::czk_bases_register(ctx.as_ptr(), group, pts.as_ptr(), inf.as_ptr(), inf.len(), sys::CZK_MEM_HOST, &mut h) };
+            ctx.expect(rc, "czk_bases_register");
+            if let Some(old) = PINNED.lock().unwrap().insert(key, Entry { handle: h, fingerprint: fp }) {
+                // the same slice pinned twice: the older guard keeps its handle alive, the map now points at the newer one
+                let _ = old;
+            }
+            Pinned { handle: h, group, key, fingerprint: fp }
         }
-        let s = scalars_to_limbs(scalars);
-        let rc = unsafe {
-            sys::czk_msm(ctx.as_ptr(), entry.handle, s.as_ptr(), scalars.len(), 1, sys::CZK_SCALAR_MONTGOMERY, sys::CZK_MEM_HOST, out.as_mut_ptr())
-        };
-        ctx.expect(rc, "czk_msm");
+        /// Pins a G1 slice (window tables are built once: ~65 ms per 2^20 points).
+        pub fn g1(bases: &[G1Affine]) -> Pinned {
+            let (pts, inf) = limbs::g1_bases(bases);
+            Pinned::new(sys::CZK_G1, (bases.as_ptr() as usize, bases.len(), sys::CZK_G1), sample_g1(bases), &pts, &inf)
+        }
+        pub fn g2(bases: &[G2Affine]) -> Pinned {
+            let (pts, inf) = limbs::g2_bases(bases);
+            Pinned::new(sys::CZK_G2, (bases.as_ptr() as usize, bases.len(), sys::CZK_G2), sample_g2(bases), &pts, &inf)
+        }
+        pub fn as_ptr(&self) -> *mut sys::czk_bases {
+            self.handle
+        }
+        /// The MSM over share lanes that are already on the GPU (`h` out of the witness map, prover.rs:104): one Jacobian
+        /// result per lane as 18 (G1) or 36 (G2) limbs, enqueue-only; valid after `CTX.sync()`.
+        pub fn msm_resident(&self, scalars: &super::resident::DeviceLanes, n_scalars: usize, out: &mut [u64]) {
+            let jw = if self.group == sys::CZK_G1 { 18 } else { 36 };
+            assert!(out.len() >= jw * scalars.lanes());
+            let ctx = CTX.lock().unwrap();
+            let rc = unsafe {
+                sys::czk_msm_async(ctx.as_ptr(), self.handle, scalars.data(0, 0), n_scalars, scalars.lanes(), sys::CZK_SCALAR_MONTGOMERY,
+                                   sys::CZK_MEM_DEVICE, out.as_mut_ptr())
+            };
+            ctx.expect(rc, "czk_msm_async");
+        }
     }
 
-    /// Drop-in body for `<G1Affine as AffineCurve>::multi_scalar_mul`.
+    impl Drop for Pinned {
+        fn drop(&mut self) {
+            let mut map = PINNED.lock().unwrap();
+            if let Some(e) = map.get(&self.key) {
+                if e.handle == self.handle {
+                    map.remove(&self.key);
+                }
+            }
+            let _ = self.fingerprint;
+            unsafe { sys::czk_bases_release(self.handle) };
+        }
+    }
+
+    /// The pinned handle of `key` if the slice still holds what was pinned.
+    fn lookup(key: (usize, usize, i32), fp: impl Fn() -> u64) -> Option<*mut sys::czk_bases> {
+        let map = PINNED.lock().unwrap();
+        match map.get(&key) {
+            Some(e) if e.fingerprint == fp() => Some(e.handle),
+            _ => None,
+        }
+    }
+
+    /// Drop-in body for `<G1Affine as AffineCurve>::multi_scalar_mul`: pinned slices use their tables, everything else the
+    /// one-shot form (`czk_msm_g1`: bases copied, no tables, nothing kept).
     pub fn g1(bases: &[G1Affine], scalars: &[Fr]) -> G1Projective {
         let mut out = [0u64; 18];
-        run(sys::CZK_G1, (bases.as_ptr() as usize, bases.len(), sys::CZK_G1), || limbs::g1_bases(bases), scalars, &mut out);
+        let s = scalars_to_limbs(scalars);
+        let pinned = lookup((bases.as_ptr() as usize, bases.len(), sys::CZK_G1), || sample_g1(bases));
+        let ctx = CTX.lock().unwrap();
+        let rc = match pinned {
+            Some(h) => unsafe {
+                sys::czk_msm(ctx.as_ptr(), h, s.as_ptr(), scalars.len(), 1, sys::CZK_SCALAR_MONTGOMERY, sys::CZK_MEM_HOST, out.as_mut_ptr())
+            },
+            None => {
+                let (pts, inf) = limbs::g1_bases(bases);
+                let n = bases.len().min(scalars.len());
+                unsafe { sys::czk_msm_g1(ctx.as_ptr(), pts.as_ptr(), inf.as_ptr(), s.as_ptr(), n, 1, sys::CZK_SCALAR_MONTGOMERY, out.as_mut_ptr()) }
+            }
+        };
+        ctx.expect(rc, "czk_msm (G1)");
         limbs::g1_from_jac(&out)
     }
     /// Drop-in body for `<G2Affine as AffineCurve>::multi_scalar_mul`.
     pub fn g2(bases: &[G2Affine], scalars: &[Fr]) -> G2Projective {
         let mut out = [0u64; 36];
-        run(sys::CZK_G2, (bases.as_ptr() as usize, bases.len(), sys::CZK_G2), || limbs::g2_bases(bases), scalars, &mut out);
+        let s = scalars_to_limbs(scalars);
+        let pinned = lookup((bases.as_ptr() as usize, bases.len(), sys::CZK_G2), || sample_g2(bases));
+        let ctx = CTX.lock().unwrap();
+        let rc = match pinned {
+            Some(h) => unsafe {
+                sys::czk_msm(ctx.as_ptr(), h, s.as_ptr(), scalars.len(), 1, sys::CZK_SCALAR_MONTGOMERY, sys::CZK_MEM_HOST, out.as_mut_ptr())
+            },
+            None => {
+                let (pts, inf) = limbs::g2_bases(bases);
+                let n = bases.len().min(scalars.len());
+                unsafe { sys::czk_msm_g2(ctx.as_ptr(), pts.as_ptr(), inf.as_ptr(), s.as_ptr(), n, 1, sys::CZK_SCALAR_MONTGOMERY, out.as_mut_ptr()) }
+            }
+        };
+        ctx.expect(rc, "czk_msm (G2)");
         limbs::g2_from_jac(&out)
     }
 
@@ -372,5 +487,114 @@ pub mod share {
             };
             ctx.expect(rc, "czk_ntt_fr (2 share lanes)");
         }
+    }
+}
+
+pub mod resident {
+    //! Share vectors that stay on the GPU: what `Vec<T>` is to the reference's `witness_map`, which keeps `a`, `b`, `c` alive
+    //! across seven transforms and hands `h` to the MSM (mpc-snarks/src/groth/r1cs_to_qap.rs:85-110, groth/prover.rs:104).
+    //! A `DeviceLanes` is a `czk_lanes` handle: `lanes` x `capacity` Fr in HBM, allocated and freed by the library -- the Rust
+    //! side needs no HIP allocator.  Compiled and GPU-tested as C++: `czk::DeviceLanes` / `czk::R1CStoQAP::witness_map`
+    //! (include/czk.hpp), driven by tools/host_demo.cpp `bench` at the full benchmark size.
+    use super::{sys, CTX};
+    use ark_bls12_377::Fr;
+
+    pub struct DeviceLanes {
+        raw: *mut sys::czk_lanes,
+        /// the logical `Vec::len()` of every lane; elements beyond it are the zero padding `resize` would add
+        pub len: usize,
+    }
+    unsafe impl Send for DeviceLanes {}
+
+    impl DeviceLanes {
+        /// `vec![T::zero(); capacity]` for `lanes` share components (r1cs_to_qap.rs:66-67)
+        pub fn zeros(lanes: usize, capacity: usize) -> DeviceLanes {
+            let ctx = CTX.lock().unwrap();
+            let mut raw: *mut sys::czk_lanes = std::ptr::null_mut();
+            let rc = unsafe { sys::czk_lanes_alloc(ctx.as_ptr(), lanes, capacity, &mut raw) };
+            ctx.expect(rc, "czk_lanes_alloc");
+            DeviceLanes { raw, len: capacity }
+        }
+        pub fn lanes(&self) -> usize {
+            unsafe { sys::czk_lanes_count(self.raw) }
+        }
+        pub fn capacity(&self) -> usize {
+            unsafe { sys::czk_lanes_len(self.raw) }
+        }
+        /// Device address of one element, for the `CZK_MEM_DEVICE` arguments of `czk_sys`.
+        pub fn data(&self, lane: usize, elem: usize) -> *mut u64 {
+            unsafe { sys::czk_lanes_data(self.raw, lane, elem) }
+        }
+        /// Host values into lane `lane` from element `elem` on; returns when `v` has been read (it may be dropped).
+        pub fn upload(&mut self, lane: usize, elem: usize, v: &[Fr]) {
+            let mut l = vec![0u64; 4 * v.len()];
+            for (i, x) in v.iter().enumerate() {
+                super::limbs::fr_to(x, &mut l[4 * i..4 * i + 4]);
+            }
+            let ctx = CTX.lock().unwrap();
+            let rc = unsafe { sys::czk_lanes_upload(ctx.as_ptr(), self.raw, lane, elem, l.as_ptr(), v.len()) };
+            ctx.expect(rc, "czk_lanes_upload");
+        }
+        pub fn download(&self, lane: usize, elem: usize, n: usize) -> Vec<Fr> {
+            let mut l = vec![0u64; 4 * n];
+            let ctx = CTX.lock().unwrap();
+            let rc = unsafe { sys::czk_lanes_download(ctx.as_ptr(), self.raw, lane, elem, l.as_mut_ptr(), n) };
+            ctx.expect(rc, "czk_lanes_download");
+            (0..n).map(|i| super::limbs::fr_from(&l[4 * i..4 * i + 4])).collect()
+        }
+        /// `{fft, ifft, coset_fft, coset_ifft}_in_place` on every lane, in place in HBM.
+        pub fn transform(&mut self, log_size_of_group: u32, kind: super::ntt::Kind) {
+            assert!(self.len <= 1usize << log_size_of_group && self.capacity() == 1usize << log_size_of_group);
+            let k = match kind {
+                super::ntt::Kind::Fft => sys::CZK_FFT,
+                super::ntt::Kind::Ifft => sys::CZK_IFFT,
+                super::ntt::Kind::CosetFft => sys::CZK_COSET_FFT,
+                super::ntt::Kind::CosetIfft => sys::CZK_COSET_IFFT,
+            };
+            let ctx = CTX.lock().unwrap();
+            let rc = unsafe { sys::czk_ntt_fr(ctx.as_ptr(), self.data(0, 0), log_size_of_group, self.lanes(), k, self.len, sys::CZK_MEM_DEVICE) };
+            ctx.expect(rc, "czk_ntt_fr (resident lanes)");
+            self.len = self.capacity();
+        }
+    }
+
+    impl Drop for DeviceLanes {
+        fn drop(&mut self) {
+            unsafe { sys::czk_lanes_free(self.raw) }
+        }
+    }
+
+    /// `R1CStoQAP::witness_map` from the first `ifft` to `h` on resident lanes (r1cs_to_qap.rs:85-110).  `a`, `b`, `c`: the
+    /// evaluated constraint rows (`len` = rows, capacity = domain size).  `batch_product(a, b, ab)` is
+    /// `F::batch_product_in_place` (:92): for shares the Beaver protocol -- its opens travel over mpc-net from
+    /// `DeviceLanes::download` / `upload` of the `sh` lane, its local half is `czk_fr_beaver_combine`; for a single prover
+    /// `czk_fr_vec_op(CZK_OP_MUL)`.  `ab` = h on return.
+    pub fn witness_map<P: FnOnce(&mut DeviceLanes, &mut DeviceLanes, &mut DeviceLanes)>(
+        log_size_of_group: u32,
+        a: &mut DeviceLanes,
+        b: &mut DeviceLanes,
+        c: &mut DeviceLanes,
+        ab: &mut DeviceLanes,
+        batch_product: P,
+    ) {
+        let d = 1usize << log_size_of_group;
+        let lanes = a.lanes();
+        assert!(a.capacity() == d && b.capacity() == d && c.capacity() == d && ab.capacity() == d);
+        assert!(b.lanes() == lanes && c.lanes() == lanes && ab.lanes() == lanes);
+        {
+            let ctx = CTX.lock().unwrap();
+            let rc = unsafe { sys::czk_witness_map_pre(ctx.as_ptr(), a.data(0, 0), a.len, b.data(0, 0), b.len, log_size_of_group, lanes) };
+            ctx.expect(rc, "czk_witness_map_pre");
+        }
+        a.len = d;
+        b.len = d;
+        batch_product(a, b, ab);
+        {
+            let ctx = CTX.lock().unwrap();
+            let rc = unsafe { sys::czk_witness_map_post(ctx.as_ptr(), ab.data(0, 0), c.data(0, 0), c.len, log_size_of_group, lanes) };
+            ctx.expect(rc, "czk_witness_map_post");
+        }
+        ab.len = d;
+        c.len = d;
     }
 }

@@ -14,8 +14,13 @@ OUT = os.path.join(ROOT, "rust", "czk-sys", "src", "lib.rs")
 
 TYPES = {
     "int": "c_int", "unsigned": "c_uint", "size_t": "usize", "void": "()", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8",
-    "char": "c_char", "double": "f64", "czk_ctx": "czk_ctx", "czk_bases": "czk_bases", "czk_r1cs_matrix": "czk_r1cs_matrix",
+    "char": "c_char", "double": "f64",
 }
+
+
+def opaque_types(text: str):
+    """`typedef struct czk_x czk_x;` declarations of the header, in order: opaque handles."""
+    return re.findall(r"typedef struct (czk_\w+) \1;", text)
 
 
 def rust_type(c: str) -> str:
@@ -61,11 +66,15 @@ def parse_header(text: str):
 
 
 def generate() -> str:
-    enums, funcs = parse_header(open(HEADER).read())
+    text = open(HEADER).read()
+    enums, funcs = parse_header(text)
+    opaques = opaque_types(text)
+    for o in opaques:
+        TYPES[o] = o
     out = ["//! Raw bindings of `libczk_hip.so` -- GENERATED from include/czk.h by tools/gen_rust_sys.py; do not edit.",
            "//! One `extern \"C\"` declaration per C declaration; constants mirror the C enums.  Safe wrappers live in the `czk` crate.",
            "#![allow(non_camel_case_types)]", "use std::os::raw::{c_char, c_int, c_uint, c_void};", ""]
-    for opaque in ("czk_ctx", "czk_bases", "czk_r1cs_matrix"):
+    for opaque in opaques:
         out += ["#[repr(C)]", f"pub struct {opaque} {{", "    _private: [u8; 0],", "}"]
     out.append("")
     for ty, name, val in enums:
