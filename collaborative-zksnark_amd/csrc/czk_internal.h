@@ -179,6 +179,30 @@ struct ProfScope {
             return czk::set_err((ctx), CZK_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__)); \
     } while (0)
 
+// Two device tables that are only ever used together (forward / inverse twiddles): both pointers are published only when both
+// allocations succeeded, so a failed second hipMalloc cannot leave a half-initialised pair behind for the next call.
+template <class T>
+inline int alloc_table_pair(czk_ctx* ctx, T** a, T** b, size_t bytes) {
+    void *pa = nullptr, *pb = nullptr;
+    if (hipMalloc(&pa, bytes) != hipSuccess) return czk::set_err(ctx, CZK_ERR_NOMEM, "hipMalloc twiddle table");
+    if (hipMalloc(&pb, bytes) != hipSuccess) {
+        (void)hipFree(pa);
+        return czk::set_err(ctx, CZK_ERR_NOMEM, "hipMalloc twiddle table");
+    }
+    *a = (T*)pa;
+    *b = (T*)pb;
+    return CZK_OK;
+}
+// ... and dropped again when the kernels that fill them could not be launched
+template <class T>
+inline int drop_table_pair(czk_ctx* ctx, T** a, T** b, hipError_t e) {
+    (void)hipFree(*a);
+    (void)hipFree(*b);
+    *a = nullptr;
+    *b = nullptr;
+    return czk::set_err(ctx, CZK_ERR_HIP, std::string("twiddle table kernels: ") + hipGetErrorString(e));
+}
+
 #define CZK_TRY(expr)            \
     do {                         \
         int rc__ = (expr);       \

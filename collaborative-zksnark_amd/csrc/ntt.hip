@@ -22,6 +22,8 @@
 //   * lanes (sh / mac share lanes, several parties) ride on gridDim.y.
 // Arithmetic is integer VALU (v_mad_u64_u32); there is no MFMA-shaped work here.
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 
 #include "czk_internal.h"
@@ -322,7 +324,7 @@ constexpr unsigned NTT2_MIN_LOG = 11;   // domains from 2^11 on run the second-g
 static int ensure_tables(czk_ctx* ctx, DomainTables* d, bool need_coset_fwd, bool need_coset_inv) {
     const unsigned n = d->log_d;
     const size_t D = (size_t)1 << n;
-    if (!d->tw_fwd && n > 0) {
+    if ((!d->tw_fwd || !d->tw_inv) && n > 0) {
         StageRoots hr[2];
         for (unsigned s = 0; s < n; s++) {
             Fr wf = d->group_gen, wi = d->group_gen_inv;
@@ -336,15 +338,18 @@ static int ensure_tables(czk_ctx* ctx, DomainTables* d, bool need_coset_fwd, boo
         StageRoots* dr = nullptr;
         CZK_HIP(ctx, hipMalloc(&dr, sizeof(hr)));
         CZK_HIP(ctx, hipMemcpyAsync(dr, hr, sizeof(hr), hipMemcpyHostToDevice, ctx->stream));
-        CZK_HIP(ctx, hipMalloc(&d->tw_fwd, (D - 1 ? D - 1 : 1) * 32));
-        CZK_HIP(ctx, hipMalloc(&d->tw_inv, (D - 1 ? D - 1 : 1) * 32));
+        if (alloc_table_pair(ctx, &d->tw_fwd, &d->tw_inv, (D - 1 ? D - 1 : 1) * 32) != CZK_OK) {
+            (void)hipFree(dr);
+            return CZK_ERR_NOMEM;
+        }
         size_t chunks = (D - 1 + 63) / 64;
         unsigned blocks = (unsigned)((chunks + 127) / 128);
         hipLaunchKernelGGL(k_twiddle_table, dim3(blocks), dim3(128), 0, ctx->stream, d->tw_fwd, n, dr);
         hipLaunchKernelGGL(k_twiddle_table, dim3(blocks), dim3(128), 0, ctx->stream, d->tw_inv, n, dr + 1);
-        CZK_HIP(ctx, hipGetLastError());
-        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        CZK_HIP(ctx, hipFree(dr));
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        (void)hipFree(dr);
+        if (e != hipSuccess) return drop_table_pair(ctx, &d->tw_fwd, &d->tw_inv, e);
     }
     size_t chunks = (D + 63) / 64;
     unsigned blocks = (unsigned)((chunks + 127) / 128);
@@ -359,12 +364,12 @@ static int ensure_tables(czk_ctx* ctx, DomainTables* d, bool need_coset_fwd, boo
         CZK_HIP(ctx, hipGetLastError());
     }
     if (n >= NTT2_MIN_LOG) {   // second-generation passes: the same tables in the unsaturated residue system (fru.h)
-        if (!d->twu_fwd) {
-            CZK_HIP(ctx, hipMalloc(&d->twu_fwd, (D - 1) * 36));
-            CZK_HIP(ctx, hipMalloc(&d->twu_inv, (D - 1) * 36));
+        if (!d->twu_fwd || !d->twu_inv) {
+            CZK_TRY(alloc_table_pair(ctx, &d->twu_fwd, &d->twu_inv, (D - 1) * 36));
             launch_table_to_u(ctx->stream, d->tw_fwd, D - 1, d->twu_fwd);
             launch_table_to_u(ctx->stream, d->tw_inv, D - 1, d->twu_inv);
-            CZK_HIP(ctx, hipGetLastError());
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return drop_table_pair(ctx, &d->twu_fwd, &d->twu_inv, e);
         }
         if (need_coset_fwd && !d->cosetu_fwd) {
             CZK_HIP(ctx, hipMalloc(&d->cosetu_fwd, D * 36));
@@ -491,8 +496,11 @@ static int ntt_host_lanes_pipelined(czk_ctx* ctx, uint64_t* data, unsigned log_d
     hipError_t setup = hipStreamCreateWithFlags(&down, hipStreamNonBlocking);
     for (auto& e : done)
         if (setup == hipSuccess) setup = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    std::atomic<size_t> ready{0};
-    std::atomic<int> failed{0};
+    // producer -> downloader hand-over: lanes whose transform has been enqueued / a failure flag, under one mutex
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t ready = 0;
+    int failed = 0;
     int rc = CZK_OK;
     if (setup != hipSuccess) {
         rc = set_err(ctx, CZK_ERR_HIP, std::string("NTT lane pipeline set-up: ") + hipGetErrorString(setup));
@@ -501,12 +509,16 @@ static int ntt_host_lanes_pipelined(czk_ctx* ctx, uint64_t* data, unsigned log_d
         std::thread downloader([&] {
             (void)hipSetDevice(device);
             for (size_t k = 0; k < lanes; k++) {
-                while (ready.load(std::memory_order_acquire) <= k && !failed.load()) std::this_thread::yield();
-                if (failed.load()) return;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return ready > k || failed; });   // sleeps; no host core is spun while the GPU works
+                    if (failed) return;
+                }
                 if (hipStreamWaitEvent(down, done[k], 0) != hipSuccess ||
                     hipMemcpyAsync(data + k * lane_words, (char*)buf.p + k * lane_bytes, lane_bytes, hipMemcpyDeviceToHost, down) != hipSuccess ||
                     hipStreamSynchronize(down) != hipSuccess) {
-                    failed.store(2);
+                    std::lock_guard<std::mutex> lk(mu);
+                    failed = 2;
                     return;
                 }
             }
@@ -519,11 +531,23 @@ static int ntt_host_lanes_pipelined(czk_ctx* ctx, uint64_t* data, unsigned log_d
                 rc = set_err(ctx, CZK_ERR_HIP, "H2D lane");
             if (rc == CZK_OK) rc = ntt_device(ctx, lane, log_d, 1, kind, in_len);
             if (rc == CZK_OK && hipEventRecord(done[k], ctx->stream) != hipSuccess) rc = set_err(ctx, CZK_ERR_HIP, "event record");
-            if (rc == CZK_OK) ready.store(k + 1, std::memory_order_release);
+            if (rc == CZK_OK) {
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready = k + 1;
+                }
+                cv.notify_one();
+            }
         }
-        if (rc != CZK_OK) failed.store(1);
+        if (rc != CZK_OK) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!failed) failed = 1;
+            }
+            cv.notify_one();
+        }
         downloader.join();
-        if (rc == CZK_OK && failed.load() == 2) rc = set_err(ctx, CZK_ERR_HIP, "D2H lane");
+        if (rc == CZK_OK && failed == 2) rc = set_err(ctx, CZK_ERR_HIP, "D2H lane");
     }
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& e : done)

@@ -115,12 +115,12 @@ int get_mixed_domain(czk_ctx* ctx, unsigned k, MixedDomain** out) {
 static int ensure_mixed_tables(czk_ctx* ctx, MixedDomain* d, bool coset_fwd, bool coset_inv) {
     const size_t N = (size_t)3 << d->k;
     const unsigned blocks = (unsigned)(((N + 63) / 64 + 127) / 128);
-    if (!d->tw_fwd) {
-        CZK_HIP(ctx, hipMalloc(&d->tw_fwd, N * 32));
-        CZK_HIP(ctx, hipMalloc(&d->tw_inv, N * 32));
+    if (!d->tw_fwd || !d->tw_inv) {
+        CZK_TRY(alloc_table_pair(ctx, &d->tw_fwd, &d->tw_inv, N * 32));
         hipLaunchKernelGGL(k_pow_table_m, dim3(blocks), dim3(128), 0, ctx->stream, d->tw_fwd, N, d->group_gen, Fr::one());
         hipLaunchKernelGGL(k_pow_table_m, dim3(blocks), dim3(128), 0, ctx->stream, d->tw_inv, N, d->group_gen_inv, Fr::one());
-        CZK_HIP(ctx, hipGetLastError());
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return drop_table_pair(ctx, &d->tw_fwd, &d->tw_inv, e);
     }
     if (coset_fwd && !d->coset_fwd) {
         CZK_HIP(ctx, hipMalloc(&d->coset_fwd, N * 32));

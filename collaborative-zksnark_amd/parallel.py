@@ -27,6 +27,20 @@ def init(backend: str | None = None):
     return rank, world, local_rank
 
 
+class MpcCheckError(RuntimeError):
+    """A protocol check of an open failed (SPDZ MAC check, GSZ degree bound, commitment mismatch): the reference `assert!`s these
+    in release builds too (share/spdz.rs:181-184, share/gsz20/mod.rs:452), so they are exceptions here, never Python `assert`s."""
+
+
+def _settle(t: torch.Tensor):
+    """After a collective on a CUDA backend: RCCL enqueues on torch's / its own stream and returns; the library's kernels that
+    read the result run on the czk context's stream, which may be a private non-blocking one.  Wait here so that the result has
+    landed whichever stream the caller's context uses (an open is a synchronisation point of the protocol anyway)."""
+    if t is not None and t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
 def partition_units(n_units: int, world: int, rank: int) -> list[int]:
     """Contiguous block partition of independent units (party-proofs) over ranks; sizes differ by at most one."""
     base, extra = divmod(n_units, world)
@@ -81,7 +95,7 @@ def all_gather_shares(share: torch.Tensor) -> torch.Tensor:
     # RCCL: one all-gather straight into the (world, ...) result
     out = torch.empty((world,) + tuple(share.shape), dtype=share.dtype, device=share.device)
     dist.all_gather_into_tensor(out, share.contiguous())
-    return out
+    return _settle(out)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -104,6 +118,7 @@ def send_to_king(x: torch.Tensor):
         return torch.stack(out).to(x.device) if rank == 0 else None
     out = [torch.empty_like(x) for _ in range(world)] if rank == 0 else None
     dist.gather(x.contiguous(), out, dst=0)
+    _settle(x)
     return torch.stack(out) if rank == 0 else None
 
 
@@ -120,7 +135,7 @@ def recv_from_king(xs, like: torch.Tensor) -> torch.Tensor:
         assert xs.shape[0] == world
         parts = [(xs[p].contiguous().cpu() if gloo else xs[p].contiguous()) for p in range(world)]
     dist.scatter(out, parts, src=0)
-    return out.to(like.device)
+    return _settle(out.to(like.device))
 
 
 def king_compute(x: torch.Tensor, f):
@@ -181,7 +196,7 @@ def atomic_broadcast(ctx, x: torch.Tensor, rand32: bytes | None = None) -> torch
         ctx.sync()
         w = serialize_fr_vec(other.cpu().numpy().view(np.uint64))
         if hashlib.sha256(w + bytes(rnds[p].cpu().numpy())).digest() != bytes(commits[p].cpu().numpy()):
-            raise AssertionError(f"atomic_broadcast: party {p}'s data does not match its commitment")
+            raise MpcCheckError(f"atomic_broadcast: party {p}'s data does not match its commitment")
     return data
 
 
@@ -200,7 +215,8 @@ def spdz_batch_open(ctx, sh: torch.Tensor, mac: torch.Tensor, mac_share, commit:
     ctx.sync()   # the exchange below runs on torch's stream (or through the host): the context's kernels must have finished
     all_dx = atomic_broadcast(ctx, dx) if commit else all_gather_shares(dx)   # Net::atomic_broadcast(&dx_ts)
     bad = ctx.fr_lanes_sum(all_dx.contiguous().data_ptr(), world, n, count_nonzero=True)
-    assert bad == 0, "SPDZ MAC check failed"                              # assert!(sum.is_zero())
+    if bad != 0:                                                            # assert!(sum.is_zero())
+        raise MpcCheckError(f"SPDZ MAC check failed on {bad} of {n} opened values")
     return vals
 
 
@@ -213,5 +229,6 @@ def gsz_batch_open(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
     gathered = all_gather_shares(val)
     out = torch.empty_like(val)
     bad = ctx.fr_gsz_open(gathered.data_ptr(), world, n, out.data_ptr(), degree=degree)
-    assert bad == 0, "GSZ open: a share polynomial exceeds its degree bound"
+    if bad != 0:                                                            # assert!(p.degree() <= d)
+        raise MpcCheckError(f"GSZ open: {bad} of {n} share polynomials exceed their degree bound")
     return out

@@ -109,7 +109,9 @@ int czk_lanes_zero(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t elem, size_
  * data: lanes x D x 4 u64, D = 2^log_d, lane-major, transformed in place, natural order in and out.
  * in_len <= D: entries [in_len, D) of every lane are taken as zero (`resize(size, T::zero())`) whatever they hold.
  * Root of unity = get_root_of_unity(D) = LARGE_SUBGROUP_ROOT_OF_UNITY^3 squared down (ff/src/fields/mod.rs:360-367);
- * coset shift = Fr::multiplicative_generator() = 22. */
+ * coset shift = Fr::multiplicative_generator() = 22.
+ * On an error return `data` is undefined (host memory: lanes are written back as they finish, so some may already hold their
+ * transform); the reference panics at the corresponding points, so no caller continues with the vector. */
 int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int kind, size_t in_len, int mem);
 
 /* Domain constants as the reference's Radix2EvaluationDomain::new computes them (radix2/mod.rs:51-82), Montgomery
@@ -130,7 +132,7 @@ int czk_mixed_domain_constants(czk_ctx* ctx, size_t size, uint64_t* out24);
 /* out[i] = a[i] op b[i], n elements of 4 u64; out may alias a or b.  r1cs_to_qap.rs:92 (plain product), :105-107 (sub). */
 typedef enum { CZK_OP_ADD = 0, CZK_OP_SUB = 1, CZK_OP_MUL = 2 } czk_binop;
 int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int mem);
-/* out[i] = a[i] * k  (k: one Montgomery Fr; domain/mod.rs:184-191) */
+/* out[i] = a[i] * k  (k: one Montgomery Fr in the SAME memory space as a / out; domain/mod.rs:184-191) */
 int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n, int mem);
 /* out[i] = c * g^i for i < n (g, c: one Montgomery Fr each, HOST memory; c NULL = one): the table behind
  * EvaluationDomain::distribute_powers / distribute_powers_and_mul_by_const (algebra/poly/src/domain/mod.rs:93-106) for any g --

@@ -188,7 +188,9 @@ class Radix2EvaluationDomain {
     void coset_ifft_in_place(DeviceLanes& v) const { run_device(v, CZK_COSET_IFFT); }
     void divide_by_vanishing_poly_on_coset_in_place(DeviceLanes& evals) const {
         const size_t n = evals.lanes() * evals.capacity();
-        ctx_->check(czk_fr_vec_scale(ctx_->raw(), evals.data(), vanishing_inv_.l, evals.data(), n, CZK_MEM_DEVICE));
+        DeviceLanes k(*ctx_, 1, 1);                      // czk_fr_vec_scale reads its constant from the vector's memory space
+        k.upload(0, 0, &vanishing_inv_, 1);
+        ctx_->check(czk_fr_vec_scale(ctx_->raw(), evals.data(), k.data(), evals.data(), n, CZK_MEM_DEVICE));
     }
     const Context& ctx() const { return *ctx_; }
 

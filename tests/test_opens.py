@@ -204,7 +204,7 @@ def _open_worker(rank, world, port, q, backend, share_device):
     try:
         parallel.spdz_batch_open(ctx, sh, bad_mac, alpha[rank], commit=False)
         ok = False
-    except AssertionError:
+    except parallel.MpcCheckError:
         pass
     # GSZ: degree-t shares of a vector of secrets
     if world in (2, 3, 4, 6, 8):

@@ -199,6 +199,29 @@ int main(int argc, char** argv) {
     dom->fft_in_place(mv);
     for (size_t i = 0; i < 16; i++) REQUIRE(mv[i].shared && eq(mv[i].sh, plain[i]));
 
+    // the same transforms on lanes that live on the GPU (DeviceLanes): coset FFT of two lanes equals the host-vector path,
+    // divide_by_vanishing_poly_on_coset_in_place likewise; clone() is a device copy
+    {
+        DeviceLanes dl(ctx, 2, 16);
+        dl.upload(0, x);
+        dl.upload(1, x);
+        dl.len = x.size();
+        dom->coset_fft_in_place(dl);
+        REQUIRE(dl.len == 16);
+        std::vector<Fr> want = x;
+        dom->coset_fft_in_place(want);
+        DeviceLanes cp = dl.clone();
+        std::vector<Fr> g0 = dl.to_host(0), g1 = cp.to_host(1);
+        for (size_t i = 0; i < 16; i++) REQUIRE(eq(g0[i], want[i]) && eq(g1[i], want[i]));
+        dom->divide_by_vanishing_poly_on_coset_in_place(dl);
+        dom->divide_by_vanishing_poly_on_coset_in_place(want);
+        g0 = dl.to_host(1);
+        for (size_t i = 0; i < 16; i++) REQUIRE(eq(g0[i], want[i]));
+        dom->coset_ifft_in_place(cp);
+        g1 = cp.to_host(0);
+        for (size_t i = 0; i < 13; i++) REQUIRE(eq(g1[i], x[i]));
+    }
+
     // MSM: P_i = [i] G, scalars all one  =>  [n(n+1)/2] G ; and the two SPDZ lanes agree (spdz.rs:441-442)
     const size_t n = 100;
     std::vector<uint64_t> k(4 * (n + 1), 0);
