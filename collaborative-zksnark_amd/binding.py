@@ -461,6 +461,16 @@ class Bases:
     def windows(self) -> int:
         return self.layout()[1]
 
+    def layout_for(self, n_scalars: int):
+        """(c, windows) an MSM of n_scalars scalars over these bases runs with (czk_bases_layout_for)."""
+        c, w = C.c_uint(0), C.c_uint(0)
+        lib().czk_bases_layout_for(self._h, C.c_size_t(n_scalars), C.byref(c), C.byref(w))
+        return c.value, w.value
+
+    def prepare(self, n_scalars: int):
+        """Builds the table set MSMs of n_scalars scalars will use, up front (czk_bases_prepare)."""
+        self.ctx._ck(lib().czk_bases_prepare(self.ctx._h, self._h, C.c_size_t(n_scalars)))
+
     def release(self):
         if self._h:
             lib().czk_bases_release(self._h)

@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -112,7 +114,22 @@ struct czk_ctx {
     size_t lds_per_block = 64 * 1024;   // hipDeviceProp_t::sharedMemPerBlock (gfx950: 160 KiB)
 };
 
+// A second (third, ...) set of window tables over a PREFIX of a registered base array, at a narrower window width: short MSMs
+// under a long key (KZG commitments of low-degree polynomials under `powers_of_g`, poly-commit/src/kzg10/mod.rs:159-162) would
+// otherwise pay the key's 2^(c-1)-bucket reduction per call.  Built on first use by msm.hip (pick_tables), immutable afterwards.
+struct czk_table_set {
+    unsigned c = 0, W = 0;
+    size_t cover = 0;          // points covered = stride between windows
+    uint64_t* pts = nullptr;   // W x cover x (12|24) u64
+    uint8_t* inf = nullptr;    // W x cover
+};
+
 struct czk_bases {
+    static constexpr int MAX_EXTRA = 6;
+    czk_table_set extra[MAX_EXTRA];
+    std::atomic<int> n_extra{0};      // published count: readers scan [0, n_extra) without the lock
+    std::mutex build_mu;              // serialises builders (contexts of several threads may share one handle)
+    bool per_call_width = true;       // CZK_MSM_FIXED_C=1 at registration turns the secondary sets off (A/B runs)
     int device = 0;            // GPU ordinal the tables live on (the handle may outlive its context: no ctx pointer is kept)
     int group = 1;
     size_t n = 0;
@@ -254,6 +271,7 @@ void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sor
 void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords);
+void launch_convert_from_u(hipStream_t st, u64* pts, size_t n_coords);   // the inverse: table coordinates back to the saturated Montgomery form
 // batched-affine pre-reduction of the bucket lists (msm_aff.h; G1)
 struct AffArgs {
     unsigned rounds = 0, lanes = 0, n_parts = 0, part_shift = 0, part_log = 0;

@@ -570,6 +570,98 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
     return CZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// window width per call.  The reference chooses c from the size of each call (variable_base.rs:21-25); with precomputed window
+// multiples the width is a property of the table, so a key registered for n points carries c(n) -- and a SHORT MSM under it (a KZG
+// commitment of a degree-2^18 polynomial under a 3 * 2^18-point SRS) would still reduce 2^(c(n)-1) buckets per lane: as much
+// work as its whole accumulation.  HBM is plentiful, so such calls get their own, narrower table set over the prefix of the
+// key they use: classes c = 13 / 15 / 17 by call size (cost model: W(c) size mixed additions + ~6 mixed additions' worth of
+// instructions per bucket), covering the next power of two of the call's size, built on first use (or by czk_bases_prepare)
+// and kept with the handle.  A set is only built when the model predicts >= 12 % less work than the key's own tables.
+// ------------------------------------------------------------------------------------------------
+struct TableView {
+    unsigned c, W;
+    const u64* pts;
+    const uint8_t* inf;
+    size_t stride;   // points per window
+};
+constexpr double REDUCE_COST_PER_BUCKET = 6.0;   // in mixed additions (measured: profiles/r03_window_classes.txt)
+static double msm_cost(unsigned c, size_t size) { return (double)num_windows(c) * (double)size + REDUCE_COST_PER_BUCKET * (double)((size_t)1 << (c - 1)); }
+static unsigned width_class(size_t size) { return size < 11586 ? 13u : size < 92682 ? 15u : 17u; }   // boundaries at 2^13.5, 2^16.5
+
+template <class F>
+static int build_secondary(czk_ctx* ctx, const czk_bases* b, unsigned c, size_t cover, czk_table_set* out) {
+    constexpr int AW = GT<F>::AW, JW = GT<F>::JW, FW = GT<F>::FW;
+    const unsigned W = num_windows(c);
+    czk_table_set t;
+    t.c = c;
+    t.W = W;
+    t.cover = cover;
+    u64 *jac = nullptr, *scr = nullptr;
+    hipError_t e = hipMalloc(&t.pts, (size_t)W * cover * AW * 8);
+    if (e == hipSuccess) e = hipMalloc(&t.inf, (size_t)W * cover);
+    if (e == hipSuccess) e = hipMalloc(&jac, cover * JW * 8);
+    if (e == hipSuccess) e = hipMalloc(&scr, cover * FW * 8);
+    if (e == hipSuccess) e = hipMemcpyAsync(t.pts, b->pts, cover * AW * 8, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t.inf, b->inf, cover, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        if (b->unsat) launch_convert_from_u(ctx->stream, t.pts, cover * (AW / 6));   // the key's window 0 back to Montgomery form
+        const unsigned CH = 32;
+        unsigned g1 = (unsigned)((cover + 127) / 128), g2 = (unsigned)(((cover + CH - 1) / CH + 127) / 128);
+        for (unsigned w = 1; w < W; w++) {
+            hipLaunchKernelGGL(k_dbl_c<F>, dim3(g1), dim3(128), 0, ctx->stream, t.pts + (size_t)(w - 1) * cover * AW, t.inf + (size_t)(w - 1) * cover, cover, c, jac);
+            hipLaunchKernelGGL(k_batch_to_affine<F>, dim3(g2), dim3(128), 0, ctx->stream, jac, cover, CH, scr, t.pts + (size_t)w * cover * AW,
+                               t.inf + (size_t)w * cover);
+        }
+        if (b->unsat) launch_convert_to_u(ctx->stream, t.pts, (size_t)W * cover * (AW / 6));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (jac) (void)hipFree(jac);
+    if (scr) (void)hipFree(scr);
+    if (e != hipSuccess) {
+        if (t.pts) (void)hipFree(t.pts);
+        if (t.inf) (void)hipFree(t.inf);
+        return set_err(ctx, e == hipErrorOutOfMemory ? CZK_ERR_NOMEM : CZK_ERR_HIP, std::string("secondary window tables: ") + hipGetErrorString(e));
+    }
+    *out = t;
+    return CZK_OK;
+}
+
+// the table set an MSM of `size` pairs runs on (builds a secondary set when the model asks for one and none fits)
+template <class F>
+static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView* tv, bool build) {
+    czk_bases* b = const_cast<czk_bases*>(cb);   // the secondary sets are a cache behind the const handle
+    *tv = TableView{b->c, b->W, b->pts, b->inf, b->n};
+    if (b->split || !b->per_call_width || size == 0) return CZK_OK;
+    const unsigned cc = width_class(size);
+    if (cc >= b->c || msm_cost(b->c, size) < 1.12 * msm_cost(cc, size)) return CZK_OK;
+    auto find = [&]() -> const czk_table_set* {
+        const int n = b->n_extra.load(std::memory_order_acquire);
+        const czk_table_set* best = nullptr;
+        for (int i = 0; i < n; i++)
+            if (b->extra[i].c == cc && b->extra[i].cover >= size && (!best || b->extra[i].cover < best->cover)) best = &b->extra[i];
+        return best;
+    };
+    const czk_table_set* t = find();
+    if (!t && build) {
+        std::lock_guard<std::mutex> lk(b->build_mu);
+        t = find();   // another context may have built it meanwhile
+        const int n = b->n_extra.load(std::memory_order_acquire);
+        if (!t && n < czk_bases::MAX_EXTRA) {
+            size_t cover = 1;
+            while (cover < size) cover <<= 1;
+            if (cover > b->n) cover = b->n;
+            CZK_TRY(msm_pipeline_sync(ctx));   // (the build synchronises ctx->stream; drain the MSM streams too so that timing stays attributable)
+            CZK_TRY(build_secondary<F>(ctx, b, cc, cover, &b->extra[n]));
+            b->n_extra.store(n + 1, std::memory_order_release);
+            t = &b->extra[n];
+        }
+    }
+    if (t) *tv = TableView{t->c, t->W, t->pts, t->inf, t->cover};
+    return CZK_OK;
+}
+
 // Enqueue one MSM on the context's three-stage pipeline:
 //   s_sort : digits -> partition -> per-partition sort -> population order; flag clearing  (memory bound)
 //   s_acc  : the bucket accumulation kernel, nothing else                            (integer-VALU bound, fills the chip)
@@ -585,13 +677,21 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     // Bases without window tables (b->split): the W digit windows of every scalar lane become W "virtual lanes", each a
     // one-window MSM over the same n points with its own bucket set; everything after the digit extraction simply runs with
     // lanes * W lanes and one window, and the per-window results are combined on the host when they are collected.
-    const unsigned c = b->c, Wd = b->W, W = b->split ? 1 : b->W;
+    TableView tv;
+    CZK_TRY(pick_tables<F>(ctx, b, size, &tv, true));
+    unsigned c = tv.c, Wd = tv.W;
+    if (b->split) {   // no tables to honour: the width follows the call, as in the reference (variable_base.rs:21-25)
+        c = choose_c_split(size);
+        Wd = num_windows(c);
+    }
+    const unsigned W = b->split ? 1 : Wd;
+    const size_t nb = tv.stride;   // points per window of the table in use
     const size_t real_lanes = lanes;
     if (b->split) lanes *= Wd;
     if (lanes > 65535) return set_err(ctx, CZK_ERR_SIZE, "too many MSM lanes");
     const size_t B = (size_t)1 << (c - 1);
     const unsigned L = 8, logL = 3;
-    if ((size_t)W * b->n >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
+    if ((size_t)W * nb >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
     CZK_TRY(msm_pipeline_init(ctx));
     MsmSlot& slot = ctx->msm_slots[ctx->msm_next_slot];
     ctx->msm_next_slot = (ctx->msm_next_slot + 1) % ctx->msm_slots_in_use;
@@ -688,26 +788,26 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
             if (size) {
                 hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
-                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, b->inf, b->n, digits, ranks, counts, B);
+                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, W, tv.inf, nb, digits, ranks, counts, B);
             }
             hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, B, tile_sums, n_tiles);
             hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)lanes), dim3(1024), 0, ss, tile_sums, n_tiles);
             hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)n_tiles, (unsigned)lanes), dim3(256), 0, ss, counts, offsets, B, tile_sums, n_tiles);
             if (size) {
                 hipLaunchKernelGGL(k_scatter, dim3((unsigned)(((size_t)W * size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, digits, ranks, size, W,
-                                   b->n, offsets, B, sorted);
+                                   nb, offsets, B, sorted);
             }
         } else {
             const size_t total = (size_t)W * size;
             CZK_HIP(ctx, hipMemsetAsync(part_counts, 0, lanes * n_parts * 4, ss));
             if (size) {
                 hipLaunchKernelGGL(k_digits_part, dim3((unsigned)((size + 255) / 256), (unsigned)real_lanes), dim3(256), 0, ss, scalars, n_scalars, size,
-                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, Wd, b->inf, b->n, digits, part_counts, n_parts, b->split ? 1 : 0);
+                                   form == CZK_SCALAR_MONTGOMERY ? 1 : 0, c, Wd, tv.inf, nb, digits, part_counts, n_parts, b->split ? 1 : 0);
             }
             hipLaunchKernelGGL(k_part_scan, dim3((unsigned)lanes), dim3(1024), 0, ss, part_counts, part_base, part_cursor, n_parts);
             if (size) {
                 hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((total + 256 * PS_TILE - 1) / (256 * PS_TILE)), (unsigned)lanes), dim3(256), 0, ss, digits,
-                                   size, W, b->n, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
+                                   size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
             }
             hipLaunchKernelGGL(k_part_sort, dim3(n_parts, (unsigned)lanes), dim3(256), 0, ss, ranks, part_lb, part_base, n_parts, part_shift, total, B, sorted,
                                offsets, counts);
@@ -737,28 +837,28 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     if (b->unsat) {
         // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
-        if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, b->pts, perm, buckets, dirty);
-        else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
-        else launch_accumulate_g2_u(ctx, sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, tv.pts, perm, buckets, dirty);
+        else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else launch_accumulate_g2_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
     } else {
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
-        if (GT<F>::AW == 12) launch_accumulate_g1(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
-        else launch_accumulate_g2(sa, b->pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+        if (GT<F>::AW == 12) launch_accumulate_g1(sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+        else launch_accumulate_g2(sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     }
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
     CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
     // work items beyond the first 1024 entries of over-full buckets (none with uniformly random scalars): reduce stream
-    if (GT<F>::AW == 12) launch_heavy_g1(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr,
+    if (GT<F>::AW == 12) launch_heavy_g1(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr,
                                          heavy_items, heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
-    else launch_heavy_g2(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr, heavy_items,
+    else launch_heavy_g2(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr, heavy_items,
                          heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
     if (b->unsat) {
         // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
         if (aff.rounds)
-            launch_accumulate_g1_u_fixup_lvl(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, aff.lvl[(aff.rounds - 1) & 1]);
-        else if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
-        else launch_accumulate_g2_u_fixup(sr, b->pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+            launch_accumulate_g1_u_fixup_lvl(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, aff.lvl[(aff.rounds - 1) & 1]);
+        else if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else launch_accumulate_g2_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
     {
@@ -927,6 +1027,7 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     b->group = group;
     b->n = n;
     b->split = no_tables;
+    b->per_call_width = getenv("CZK_MSM_FIXED_C") == nullptr;
     b->c = no_tables ? choose_c_split(n) : choose_c(n);
     b->W = num_windows(b->c);
     const u64* pts_dev = bases;
@@ -962,6 +1063,10 @@ extern "C" void czk_bases_release(czk_bases* b) {
     (void)hipSetDevice(b->device);
     if (b->pts) (void)hipFree(b->pts);
     if (b->inf) (void)hipFree(b->inf);
+    for (int i = 0; i < b->n_extra.load(); i++) {
+        if (b->extra[i].pts) (void)hipFree(b->extra[i].pts);
+        if (b->extra[i].inf) (void)hipFree(b->extra[i].inf);
+    }
     delete b;
 }
 
@@ -971,6 +1076,28 @@ extern "C" int czk_bases_layout(const czk_bases* b, unsigned* c, unsigned* windo
     if (c) *c = b->c;
     if (windows) *windows = b->W;
     return CZK_OK;
+}
+
+extern "C" int czk_bases_layout_for(const czk_bases* b, size_t n_scalars, unsigned* c, unsigned* windows) {
+    if (!b) return CZK_ERR_ARG;
+    const size_t size = b->n < n_scalars ? b->n : n_scalars;
+    unsigned cc = b->c;
+    if (b->split) {
+        cc = choose_c_split(size);
+    } else if (b->per_call_width && size) {
+        const unsigned k = width_class(size);
+        if (k < b->c && msm_cost(b->c, size) >= 1.12 * msm_cost(k, size)) cc = k;
+    }
+    if (c) *c = cc;
+    if (windows) *windows = num_windows(cc);
+    return CZK_OK;
+}
+extern "C" int czk_bases_prepare(czk_ctx* ctx, const czk_bases* b, size_t n_scalars) {
+    if (!ctx || !b) return ctx ? set_err(ctx, CZK_ERR_ARG, "null bases") : CZK_ERR_ARG;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t size = b->n < n_scalars ? b->n : n_scalars;
+    TableView tv;
+    return b->group == CZK_G1 ? pick_tables<Fq>(ctx, b, size, &tv, true) : pick_tables<Fq2>(ctx, b, size, &tv, true);
 }
 
 static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,

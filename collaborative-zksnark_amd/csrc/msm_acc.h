@@ -326,6 +326,11 @@ __global__ void k_convert_to_u(u64* pts, size_t n_coords) {
     if (i >= n_coords) return;
     fp_store<FqParams>(pts + 6 * i, fp_mul(fp_load<FqParams>(pts + 6 * i), fqu_k_to_u()));
 }
+__global__ void k_convert_from_u(u64* pts, size_t n_coords) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_coords) return;
+    fp_store<FqParams>(pts + 6 * i, fp_mul(fp_load<FqParams>(pts + 6 * i), fqu_k_from_u()));
+}
 #endif
 #ifdef CZK_FQU_G2
 // ---- G2: the same three kernels over Fq2U / Fq2 ---------------------------------------------------------------

@@ -92,6 +92,9 @@ void launch_accumulate_g1_u_fixup_lvl(hipStream_t st, const u64* pts, const u32*
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords) {
     hipLaunchKernelGGL(k_convert_to_u, dim3((unsigned)((n_coords + 255) / 256)), dim3(256), 0, st, pts, n_coords);
 }
+void launch_convert_from_u(hipStream_t st, u64* pts, size_t n_coords) {
+    hipLaunchKernelGGL(k_convert_from_u, dim3((unsigned)((n_coords + 255) / 256)), dim3(256), 0, st, pts, n_coords);
+}
 void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
                             unsigned lanes) {
     hipLaunchKernelGGL((k_reduce_level<Fq, 24, 0>), dim3((unsigned)(((n_out << 0) + 127) / 128), lanes), dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);

@@ -225,6 +225,15 @@ size_t czk_bases_len(const czk_bases* b);
 /* Pippenger layout chosen at registration (reporting only): *c = signed-digit window width, *windows = ceil(254 / c) =
  * mixed additions per (point, lane) of an MSM over this array. */
 int czk_bases_layout(const czk_bases* b, unsigned* c, unsigned* windows);
+/* Window width per CALL.  The reference derives c from the size of each MSM (variable_base.rs:21-25); a precomputed table fixes
+ * it per key, so a short MSM under a long key (KZG10::commit of a low-degree polynomial under `powers_of_g`,
+ * poly-commit/src/kzg10/mod.rs:159-162) would reduce the key's 2^(c-1) buckets on every call.  MSMs that use a short prefix of
+ * the array therefore run on a second table set at a narrower width (c = 13 / 15 / 17 by size, covering the next power of two of
+ * the call), built on first use and kept with the handle; czk_bases_prepare builds the set for calls of `n_scalars` scalars up
+ * front (e.g. at SRS load), czk_bases_layout_for reports the (c, windows) such a call runs with.  Handles registered with
+ * CZK_MEM_NO_TABLES choose c per call outright. */
+int czk_bases_layout_for(const czk_bases* b, size_t n_scalars, unsigned* c, unsigned* windows);
+int czk_bases_prepare(czk_ctx* ctx, const czk_bases* b, size_t n_scalars);
 
 /* Replaces VariableBaseMSM::multi_scalar_mul (algebra/ec/src/msm/variable_base.rs:12-106) / AffineCurve::
  * multi_scalar_mul (ec/src/lib.rs:300-311) as reached from MpcG{1,2}Affine::multi_scalar_mul

@@ -963,3 +963,45 @@ def test_msm_without_window_tables_empty_and_all_zero(ctx, czk, orc):
     b.release()
     one = ctx.msm_oneshot(2, np.zeros((0, 24), dtype=np.uint64), None, np.zeros((0, 4), dtype=np.uint64))
     assert ctx.jac_to_affine(2, one[0])[1][0] == 1
+
+
+@pytest.mark.parametrize("g", [1, 2])
+def test_msm_short_calls_under_a_long_key_use_narrower_tables(ctx, czk, orc, g):
+    """Window width per call (the reference derives c from each call's size, variable_base.rs:21-25): MSMs that use a short prefix of
+    a long registered key -- KZG commitments of low-degree polynomials under `powers_of_g`, poly-commit/src/kzg10/mod.rs:159-162 --
+    run on secondary table sets (c = 13 / 15 / 17); every size class against the checker's Pippenger on the same prefix, infinity
+    bases included, 2 lanes; the key's own tables still serve the long calls; czk_bases_prepare builds a set up front."""
+    import torch
+    n = (1 << 18) + 3 if g == 1 else (1 << 16) + 3
+    k = rand_fr_canonical(0xBA5E5 + 9, n)
+    aw = 12 if g == 1 else 24
+    kd = torch.from_numpy(k.view(np.int64)).cuda()
+    pts = torch.empty((n, aw), dtype=torch.int64, device="cuda")
+    ctx.fixed_base_points(g, kd.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[0, 17, 4099]] = 1
+    infd = torch.from_numpy(inf).cuda()
+    b = ctx.register_bases(g, pts.data_ptr(), infd.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
+    bases_host = pts.cpu().numpy().view(np.uint64)
+    c_key, w_key = b.layout()
+    assert b.layout_for(n) == (c_key, w_key)
+    sizes = [1, 700, 5000, 20000, 70000] + ([150000] if g == 1 else [])
+    seen = set()
+    b.prepare(5000)                                                  # built up front; the others on first use
+    for m in sizes:
+        c_m, w_m = b.layout_for(m)
+        assert c_m <= c_key and w_m == -(-254 // c_m)
+        seen.add(c_m)
+        s = orc.fr_from_repr(rand_fr_canonical(0xFACE + m, 2 * m)).reshape(2, m, 4)
+        s[1, 0] = 0
+        out = ctx.msm(b, s, n_scalars=m, lanes=2, scalar_form=czk.CZK_SCALAR_MONTGOMERY)
+        for ln in range(2):
+            assert _same_point(ctx, orc, g, out[ln], orc.multi_scalar_mul(g, bases_host[:m], inf[:m], s[ln])), (g, m, ln)
+    assert len(seen) >= 3, seen                                      # several width classes were exercised
+    # and the full-length call afterwards still runs on the key's own tables (checked through the discrete logs)
+    s = rand_fr_canonical(0xC0FFEE + g, n)
+    out = ctx.msm(b, s, lanes=1)
+    k[inf == 1] = 0
+    gen = ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
+    assert _same_point(ctx, orc, g, out[0], orc.scalar_mul(g, gen, False, ints_to_limbs([dot_mod_r(k, s)], 4)[0]))
+    b.release()
