@@ -44,8 +44,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 REF_PROOFS_PER_S = 3.0 / (328.957 + 317.213 + 320.422)   # reference's published 2^20 SPDZ-2pc timings
 # csrc/fqu.h fqu_xyzz_acc_mixed: 6 multiplies (378 v_mad_u64_u32 each), 2 squarings (287), 1 fused two-product multiply (574)
 MADS_PER_MIXED_ADD = 6 * 378 + 2 * 287 + (2 * 196 + 182)
-MAD_PEAK_MEASURED_GOPS = 27100.0     # v_mad_u64_u32 lane-ops/s measured on MI355X (tools/microbench.hip, profiles/)
-MAD_PEAK_THEORETICAL_GOPS = 256 * 4 * 16 * 2.4   # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz, one per lane per cycle
+# csrc/fqu.h fq2u_xyzz_acc_mixed: 6 Fq2 products (2 x (2 x 196 + 182) each), 2 Fq2 squarings (2 Fq multiplies each), Y3 as two four-product sums
+MADS_PER_MIXED_ADD_G2 = 6 * 1148 + 2 * 756 + 2 * (4 * 196 + 182)
+# MI355X_MICROARCH.md: 256 CU x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles -> 256 x 4 x 32 x 2.4 GHz = 78.6 T lane-ops/s
+# for a full-rate instruction.  v_mad_u64_u32 is NOT full rate: measured 26.9 - 27.1 T lane-ops/s (tools/rate_bench.hip,
+# profiles/r02_instruction_rates.txt), i.e. ~1/3 rate (6 cycles per wave64 instruction) -- that measured figure is the peak.
+VALU_FULL_RATE_GOPS = 256 * 4 * 32 * 2.4
+MAD_PEAK_MEASURED_GOPS = 27100.0
+NOMINAL_CLOCK_GHZ = 2.4
 
 
 def _free_port():
@@ -653,6 +659,7 @@ def main():
     digest = hashlib.sha256(mine).hexdigest()
 
     acc_ms, acc_n = ctx.profile_read("msm_accumulate_g1")
+    acc2_ms, acc2_n = ctx.profile_read("msm_accumulate_g2")
     breakdown = {k: ctx.profile_read(k)[0] / max(1, args.steps) for k in
                  ("ntt_pass", "msm_sort", "msm_accumulate_g1", "msm_accumulate_g2", "msm_reduce")}
     alg_bytes, launches = prover.g1_accumulate_algorithmic_bytes()
@@ -660,22 +667,40 @@ def main():
     madds = args.steps * prover.g1_mixed_additions_per_step(W)       # G1 mixed additions in the timed region
     achieved = (alg_bytes * args.steps) / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
     mad_gops = MADS_PER_MIXED_ADD * madds / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure is the
-    # per-launch FETCH_SIZE + WRITE_SIZE of the same command under `rocprofv3 --pmc` (separate passes), stored with its commit
-    traffic, traffic_src = None, None
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    # G2: one launch per step over the b_g2 query (N + 1 points of 192 B, `lanes` scalar vectors of 32 B)
+    n_g2 = prover.query_len["b_g2"]
+    alg2 = n_g2 * 192 + prover.lanes * n_g2 * 32
+    madds2 = args.steps * prover.b_g2_query.windows() * prover.lanes * n_g2
+    achieved2 = alg2 * args.steps / (acc2_ms / 1e3) / 1e9 if acc2_ms > 0 else 0.0
+    mad2_gops = MADS_PER_MIXED_ADD_G2 * madds2 / (acc2_ms / 1e3) / 1e9 if acc2_ms > 0 else 0.0
+    # HBM traffic and the effective clock of the dominant kernels: PMC counters cannot be read from inside this process; the figures
+    # are per-launch averages of the same command under `rocprofv3 --pmc` (separate passes), stored with the commit they were taken at
+    traffic, traffic_src, pmc = None, None, {}
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tf = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tf):
             try:
-                j = json.load(open(tf))
-                traffic = j.get("msm_accumulate_g1_bytes_per_launch")
-                traffic_src = f"profiles/{name}" + (f" @ {j['commit']}" if "commit" in j else "")
+                pmc = json.load(open(tf))
+                traffic = pmc.get("msm_accumulate_g1_bytes_per_launch")
+                traffic_src = f"profiles/{name}" + (f" @ {pmc['commit']}" if "commit" in pmc else "")
                 break
             except Exception:
-                pass
+                pmc = {}
     if args.no_tables or n_constraints != 1 << 20 or args.parties != 2 or party_layout:
-        traffic, traffic_src = None, None        # the profile is of the default configuration only
+        traffic, traffic_src, pmc = None, None, {}        # the profile is of the default configuration only
+    clk1 = pmc.get("k_accumulate_u_effective_clock_ghz")   # GRBM_GUI_ACTIVE / XCDs / duration under the same command
+    clk2 = pmc.get("k_accumulate_u2_effective_clock_ghz")
 
+    def valu_view(gops, per_add, adds, ms, clk, comment):
+        v = {"mixed_adds_per_s": adds / (ms / 1e3) if ms > 0 else 0.0, "mad_u64_u32_per_mixed_add": per_add, "mad_u64_u32_gops": gops,
+             "mad_u64_u32_peak_gops": MAD_PEAK_MEASURED_GOPS, "frac": gops / MAD_PEAK_MEASURED_GOPS,
+             "full_rate_valu_peak_gops": VALU_FULL_RATE_GOPS,
+             "peak_note": "MI355X_MICROARCH.md: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s for a full-rate VALU instruction; v_mad_u64_u32 issues at ~1/3 of "
+                          "that -- 26.9 - 27.1 T measured (tools/rate_bench.hip), which is the peak this kernel is priced against",
+             "effective_clock_ghz": clk, "nominal_clock_ghz": NOMINAL_CLOCK_GHZ,
+             "frac_clock_adjusted": (gops / (MAD_PEAK_MEASURED_GOPS * clk / NOMINAL_CLOCK_GHZ)) if clk else None,
+             "comment": comment}
+        return v
     out = {
         # BASELINE.json's metric string for the BASELINE configuration; other sizes / party counts say what they are
         "metric": f"collaborative Groth16 proofs/sec (BLS12-377, {size_txt} constraints, SPDZ N={args.parties})",
@@ -718,17 +743,16 @@ def main():
                      "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
                      "algorithmic_bytes_per_launch": alg_bytes / launches,
                      "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md",
-                     "valu": {"mixed_adds_per_s": madds / (acc_ms / 1e3) if acc_ms > 0 else 0.0,
-                              "fq_mul_equiv_per_s": 10 * madds / (acc_ms / 1e3) if acc_ms > 0 else 0.0,
-                              "mad_u64_u32_per_mixed_add": MADS_PER_MIXED_ADD,
-                              "mad_u64_u32_gops": mad_gops,
-                              "mad_u64_u32_peak_gops": MAD_PEAK_MEASURED_GOPS,
-                              "frac": mad_gops / MAD_PEAK_MEASURED_GOPS,
-                              "mad_u64_u32_peak_theoretical_gops": MAD_PEAK_THEORETICAL_GOPS,
-                              "frac_of_theoretical": mad_gops / MAD_PEAK_THEORETICAL_GOPS,
-                              "comment": "XYZZ mixed add = 8M+2S; unsaturated 14x28-bit limbs: 6 multiplies x 378 v_mad_u64_u32, 2 squarings x 287, "
-                                         "Y3 as two products under one reduction (574) -> 3416 per mixed addition, no carry instructions "
-                                         "(csrc/fqu.h); peak = measured v_mad_u64_u32 issue rate (tools/microbench.hip) / 256 CU x 4 x 16 x 2.4 GHz"}},
+                     "valu": valu_view(mad_gops, MADS_PER_MIXED_ADD, madds, acc_ms, clk1,
+                                       "XYZZ mixed add = 8M+2S; unsaturated 14x28-bit limbs: 6 multiplies x 378 v_mad_u64_u32, 2 squarings x 287, Y3 as two products "
+                                       "under one reduction (574) -> 3416 per mixed addition, no carry instructions (csrc/fqu.h)")},
+        # the second kernel of the critical stream: the same view for the G2 bucket accumulation (one launch per proof)
+        "roofline_g2": {"bound": "hbm", "kernel": "k_accumulate_u2 (G2 bucket accumulation, Fq2 over unsaturated limbs)", "achieved": achieved2, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved2 / HBM_PEAK_GBS, "traffic": pmc.get("msm_accumulate_g2_bytes_per_launch"), "traffic_source": traffic_src,
+                        "avg_launch_ms": acc2_ms / max(1, acc2_n), "launches": int(acc2_n), "algorithmic_bytes_per_launch": alg2,
+                        "valu": valu_view(mad2_gops, MADS_PER_MIXED_ADD_G2, madds2, acc2_ms, clk2,
+                                          "Fq2 XYZZ mixed add: 6 Fq2 products (schoolbook, one reduction per component: 1148), 2 Fq2 squarings (756), Y3 as two "
+                                          "four-product sums (966 each) -> 10332 v_mad_u64_u32 per mixed addition (csrc/fqu.h)")},
         "breakdown_ms_per_step": breakdown,
         "setup_key_s": prover.setup_key_s,
     }

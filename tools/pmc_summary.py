@@ -27,16 +27,20 @@ def pick(counter, prefix):
     return None
 
 
-f, w = pick("FETCH_SIZE", "czk::k_accumulate_u("), pick("WRITE_SIZE", "czk::k_accumulate_u(")
-if f and w:
-    summary["msm_accumulate_g1_fetch_bytes_per_launch"] = f["avg_per_dispatch"] * 1024
-    summary["msm_accumulate_g1_write_bytes_per_launch"] = w["avg_per_dispatch"] * 1024
-    summary["msm_accumulate_g1_bytes_per_launch"] = (f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024
-v, g = pick("SQ_INSTS_VALU", "czk::k_accumulate_u("), pick("GRBM_GUI_ACTIVE", "czk::k_accumulate_u(")
-wc, wv = pick("SQ_WAVE_CYCLES", "czk::k_accumulate_u("), pick("SQ_WAVES", "czk::k_accumulate_u(")
-if v:
-    summary["k_accumulate_u_sq"] = {"SQ_INSTS_VALU_per_launch": v["avg_per_dispatch"], "avg_duration_ns": v["avg_duration_ns"],
-                                    "GRBM_GUI_ACTIVE": g and g["avg_per_dispatch"], "SQ_WAVE_CYCLES": wc and wc["avg_per_dispatch"],
-                                    "SQ_WAVES": wv and wv["avg_per_dispatch"]}
+XCDS = 8   # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md)
+for tag, key, prefix in (("g1", "k_accumulate_u", "czk::k_accumulate_u("), ("g2", "k_accumulate_u2", "czk::k_accumulate_u2(")):
+    f, w = pick("FETCH_SIZE", prefix), pick("WRITE_SIZE", prefix)
+    if f and w:
+        summary[f"msm_accumulate_{tag}_fetch_bytes_per_launch"] = f["avg_per_dispatch"] * 1024
+        summary[f"msm_accumulate_{tag}_write_bytes_per_launch"] = w["avg_per_dispatch"] * 1024
+        summary[f"msm_accumulate_{tag}_bytes_per_launch"] = (f["avg_per_dispatch"] + w["avg_per_dispatch"]) * 1024
+    v, g = pick("SQ_INSTS_VALU", prefix), pick("GRBM_GUI_ACTIVE", prefix)
+    wc, wv = pick("SQ_WAVE_CYCLES", prefix), pick("SQ_WAVES", prefix)
+    if v:
+        summary[f"{key}_sq"] = {"SQ_INSTS_VALU_per_launch": v["avg_per_dispatch"], "avg_duration_ns": v["avg_duration_ns"],
+                                "GRBM_GUI_ACTIVE": g and g["avg_per_dispatch"], "SQ_WAVE_CYCLES": wc and wc["avg_per_dispatch"],
+                                "SQ_WAVES": wv and wv["avg_per_dispatch"]}
+    if g:
+        summary[f"{key}_effective_clock_ghz"] = g["avg_per_dispatch"] / XCDS / g["avg_duration_ns"]
 json.dump(summary, open(out_path, "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "counters"}, indent=1))
