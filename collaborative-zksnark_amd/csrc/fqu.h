@@ -820,6 +820,136 @@ __device__ __forceinline__ bool fqu_xyzz_acc_mixed(FqU& ax, FqU& ay, FqU& azz, F
 
 
 // ---------------------------------------------------------------------------------------------
+// Full XYZZ addition and doubling in the unsaturated residue system: the bucket REDUCTION (msm_acc.h k_reduce_*_u).  One
+// reduction performs ~2.3 full additions per bucket (12M + 2S each) -- about 15 % of the accumulation's instruction count when it
+// runs in the saturated form (620 instructions per multiply against 486 here).  Buckets then stay in this residue system from the
+// accumulate kernel's store to the reduction's last step ("u-form": each coordinate the canonical-width integer of value * R' + k p,
+// packed 12 x u32); only the final result is converted to the reference's Montgomery form.
+// Value discipline: x < 9.5 p normalised; y, zz, zzz multiply outputs (< 1.01 p, normalised).  The point at infinity is a flag
+// (stored as zz == 0 exactly: a finite point's zz is a non-zero residue below 1.01 p, never the integer 0).
+// ---------------------------------------------------------------------------------------------
+struct XYZZU {
+    FqU x, y, zz, zzz;
+    bool inf;
+};
+__device__ __forceinline__ XYZZU xyzzu_zero() {
+    XYZZU r;
+    r.inf = true;
+#pragma unroll
+    for (int i = 0; i < 14; i++) r.x.l[i] = r.y.l[i] = r.zz.l[i] = r.zzz.l[i] = 0;
+    return r;
+}
+__device__ __forceinline__ XYZZU xyzzu_load(const u64* p) {
+    const Fq x = fp_load<FqParams>(p), y = fp_load<FqParams>(p + 6), zz = fp_load<FqParams>(p + 12), zzz = fp_load<FqParams>(p + 18);
+    XYZZU r;
+    u32 any = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) any |= zz.l[i];
+    r.inf = any == 0;
+    r.x = fqu_unpack(x);
+    r.y = fqu_unpack(y);
+    r.zz = fqu_unpack(zz);
+    r.zzz = fqu_unpack(zzz);
+    return r;
+}
+__device__ __forceinline__ void xyzzu_store(u64* p, const XYZZU& a) {
+    if (a.inf) {
+        const Fq z = Fq::zero();
+        fp_store<FqParams>(p, z);
+        fp_store<FqParams>(p + 6, z);
+        fp_store<FqParams>(p + 12, z);
+        fp_store<FqParams>(p + 18, z);
+        return;
+    }
+    fp_store<FqParams>(p, fqu_pack(a.x));
+    fp_store<FqParams>(p + 6, fqu_pack(a.y));
+    fp_store<FqParams>(p + 12, fqu_pack(a.zz));
+    fp_store<FqParams>(p + 18, fqu_pack(a.zzz));
+}
+// u-form <-> the saturated Montgomery form of curve.h (rare paths and the final result)
+__device__ __forceinline__ XYZZ<Fq> xyzzu_to_sat(const XYZZU& a) {
+    if (a.inf) return XYZZ<Fq>::zero();
+    const Fq kf = fqu_k_from_u();
+    return XYZZ<Fq>{fp_mul(fqu_pack(a.x), kf), fp_mul(fqu_pack(a.y), kf), fp_mul(fqu_pack(a.zz), kf), fp_mul(fqu_pack(a.zzz), kf)};
+}
+__device__ __forceinline__ XYZZU xyzzu_from_sat(const XYZZ<Fq>& s) {
+    XYZZU r;
+    r.inf = s.is_zero();
+    if (r.inf) return xyzzu_zero();
+    const Fq kt = fqu_k_to_u();
+    r.x = fqu_unpack(fp_mul(s.x, kt));
+    r.y = fqu_unpack(fp_mul(s.y, kt));
+    r.zz = fqu_unpack(fp_mul(s.zz, kt));
+    r.zzz = fqu_unpack(fp_mul(s.zzz, kt));
+    return r;
+}
+// the complete formulas of curve.h (P == Q -> doubling, P == -Q -> infinity): taken when the filter below cannot rule out H == 0
+// (by value: taking the accumulator's address would pin it in scratch memory on the fast path as well)
+__device__ __noinline__ XYZZU xyzzu_add_slow(XYZZU a, XYZZU b) { return xyzzu_from_sat(xyzz_add(xyzzu_to_sat(a), xyzzu_to_sat(b))); }
+
+// a += b (add-2008-s, 12M + 2S).  H = U2 - U1 + 4 p lies in (2.99 p, 5.01 p): it is 0 mod p only if it equals j p with j in
+// 3..5, and p == 1 mod 2^28 makes the low 28 bits of j p equal j -- a one-compare filter; the ~1-in-2^26 suspicious additions (and
+// every genuine P == +-Q) go through the saturated complete formulas.
+__device__ __forceinline__ void xyzzu_add(XYZZU& a, const XYZZU& b) {
+    if (b.inf) return;
+    if (a.inf) {
+        a = b;
+        return;
+    }
+    const FqU u1 = fqu_mul(a.x, b.zz);
+    const FqU u2 = fqu_mul(b.x, a.zz);
+    const FqU pp = fqu_sub_lazy<4>(u2, u1);
+    if (((pp.l[0] & FQU_MASK) - 3u) <= 2u) {
+        a = xyzzu_add_slow(a, b);
+        return;
+    }
+    const FqU s1 = fqu_mul(a.y, b.zzz);
+    const FqU s2 = fqu_mul(b.y, a.zzz);
+    const FqU r = fqu_sub_lazy<4>(s2, s1);
+    const FqU p2 = fqu_sqr(pp);
+    const FqU p3 = fqu_mul(pp, p2);
+    const FqU qv = fqu_mul(u1, p2);
+    a.zz = fqu_mul(fqu_mul(a.zz, b.zz), p2);
+    a.zzz = fqu_mul(fqu_mul(a.zzz, b.zzz), p3);
+    const FqU t = fqu_sqr(r);
+    a.x = fqu_sub3_norm(t, p3, qv);                            // R^2 - PPP - 2 Q + 8 p  < 9.01 p
+    const FqU d = fqu_normalize(fqu_sub_lazy<16>(qv, a.x));   // Q - X3 + 16 p
+    FqU ns1;                                                   // 8 p - S1 (lazy): Y3 = R d + (-S1) PPP under one reduction
+#pragma unroll
+    for (int i = 0; i < 14; i++) ns1.l[i] = fqu_8p(i) - s1.l[i];
+    a.y = fqu_mul_add(r, d, ns1, p3);
+}
+// a = 2 a (dbl-2008-s-1, a = 0: 6M + 3S + the fused Y3).  The subgroup has odd order: no point has Y == 0.
+__device__ __forceinline__ void xyzzu_double(XYZZU& a) {
+    if (a.inf) return;
+    FqU u;
+#pragma unroll
+    for (int i = 0; i < 14; i++) u.l[i] = a.y.l[i] + a.y.l[i];            // U = 2 Y1, limbs < 2^29
+    const FqU v = fqu_sqr(u);
+    const FqU w = fqu_mul(u, v);
+    const FqU s = fqu_mul(a.x, v);
+    const FqU xx = fqu_sqr(a.x);
+    FqU m;
+#pragma unroll
+    for (int i = 0; i < 14; i++) m.l[i] = 3u * xx.l[i];                   // M = 3 X1^2, limbs < 2^30, value < 3.03 p
+    const FqU mm = fqu_sqr(m);
+    FqU x3;
+#pragma unroll
+    for (int i = 0; i < 14; i++) x3.l[i] = mm.l[i] + (fqu_8p_wide(i) - s.l[i] - s.l[i]);   // M^2 - 2 S + 8 p
+    x3 = fqu_normalize(x3);
+    const FqU d = fqu_normalize(fqu_sub_lazy<16>(s, x3));                 // S - X3 + 16 p
+    FqU nw;
+#pragma unroll
+    for (int i = 0; i < 14; i++) nw.l[i] = fqu_8p(i) - w.l[i];            // 8 p - W (lazy)
+    const FqU y3 = fqu_mul_add(m, d, nw, a.y);                            // M (S - X3) - W Y1
+    a.zz = fqu_mul(v, a.zz);
+    a.zzz = fqu_mul(w, a.zzz);
+    a.x = x3;
+    a.y = y3;
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Fq2 over the unsaturated residue system (G2 accumulation).  Discipline: every value is re-normalised after every
 // add / sub (limbs < 2^28), so only VALUE bounds need tracking; the lazy-subtraction constants below (K p in
 // redundant limb form, generated) were chosen with an interval analysis of the whole mixed addition -- stable

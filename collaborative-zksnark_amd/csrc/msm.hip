@@ -708,6 +708,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     AffArgs aff;
     const bool one_pass_sort = !b->split && (ctx->msm_sort_onepass || n_parts > MAX_PARTS);   // (choose_c_split keeps Wd * n_parts <= MAX_PARTS)
     size_t need_aff = 0;
+    // G1 buckets stay in the unsaturated residue system through the reduction (k_reduce_*_u) unless the batched-affine rounds
+    // (which finish on saturated level points) or CZK_REDUCE_SAT ask for the saturated form
+    const int ub = (GT<F>::AW == 12 && b->unsat && !ctx->msm_reduce_sat && !(ctx->msm_affine_rounds > 0 && size > 0)) ? 1 : 0;
     if (GT<F>::AW == 12 && b->unsat && ctx->msm_affine_rounds > 0 && size > 0) {
         aff.rounds = ctx->msm_affine_rounds;
         aff.lanes = (unsigned)lanes;
@@ -838,7 +841,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (b->unsat) {
         // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
         if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, tv.pts, perm, buckets, dirty);
-        else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
         else launch_accumulate_g2_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
     } else {
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
@@ -850,14 +853,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
     // work items beyond the first 1024 entries of over-full buckets (none with uniformly random scalars): reduce stream
     if (GT<F>::AW == 12) launch_heavy_g1(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr,
-                                         heavy_items, heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
+                                         heavy_items, heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0, ub);
     else launch_heavy_g2(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr, heavy_items,
                          heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
     if (b->unsat) {
         // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
         if (aff.rounds)
             launch_accumulate_g1_u_fixup_lvl(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, aff.lvl[(aff.rounds - 1) & 1]);
-        else if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
         else launch_accumulate_g2_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
@@ -870,14 +873,16 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         bool finished = false;
         while (n_in > 1) {
             if (n_in <= 1024) {   // latency-bound from here: bit-sum tree reductions instead of more levels
-                if (GT<F>::AW == 12) launch_reduce_tail_g1(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
+                if (ub) launch_reduce_tail_g1_u(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
+                else if (GT<F>::AW == 12) launch_reduce_tail_g1(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
                 else launch_reduce_tail_g2(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
                 finished = true;
                 break;
             }
             size_t n_out = (n_in + L - 1) / L;
             u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
-            if (GT<F>::AW == 12) launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
+            if (ub) launch_reduce_level_g1_u(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
+            else if (GT<F>::AW == 12) launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
             else launch_reduce_level_g2(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
             P = Po;
             E = Eo;
@@ -886,7 +891,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             flip ^= 1;
         }
         if (finished) {
-        } else if (GT<F>::AW == 12) launch_finish_g1(sr, P, E, lanes, result);
+        } else if (ub) launch_finish_g1_u(sr, P, E, lanes, result);
+        else if (GT<F>::AW == 12) launch_finish_g1(sr, P, E, lanes, result);
         else launch_finish_g2(sr, P, E, lanes, result);
     }
     CZK_HIP(ctx, hipGetLastError());
@@ -908,6 +914,7 @@ int msm_pipeline_init(czk_ctx* ctx) {
     if (ctx->s_sort) return CZK_OK;
     // (stream priorities for the short sort / reduce stages were measured: no gain, so all three are equal)
     ctx->msm_sort_onepass = getenv("CZK_SORT_ONEPASS") != nullptr;   // read once, not per enqueue
+    ctx->msm_reduce_sat = getenv("CZK_REDUCE_SAT") != nullptr;
     if (const char* e = getenv("CZK_MSM_AFFINE")) {
         int v = atoi(e);
         if (v >= 0 && v <= 3) ctx->msm_affine_rounds = (unsigned)v;

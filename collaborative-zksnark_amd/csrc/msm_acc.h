@@ -59,6 +59,27 @@ template <>
 __device__ __forceinline__ Fq2 heavy_coord<Fq2>(const u64* p, bool unsat) {
     return Fq2{heavy_coord<Fq>(p, unsat), heavy_coord<Fq>(p + 6, unsat)};
 }
+// A bucket slot <-> the saturated XYZZ form, for the rare-path kernels (over-full buckets, dirty buckets, deferred points): when the
+// reduction runs in the unsaturated residue system (G1, `ubuckets`), slots hold u-form coordinates (fqu.h) and are converted here.
+template <class F>
+__device__ __forceinline__ XYZZ<F> bucket_load_sat(const u64* slot, int ubuckets) {
+    if (!ubuckets) return xyzz_load<F>(slot);
+    constexpr int FW = GT<F>::AW / 2;
+    XYZZ<F> r{heavy_coord<F>(slot, true), heavy_coord<F>(slot + FW, true), heavy_coord<F>(slot + 2 * FW, true), heavy_coord<F>(slot + 3 * FW, true)};
+    return r;   // (a zero zz stays zero: infinity survives the conversion)
+}
+__device__ __forceinline__ Fq coord_to_u(const Fq& v) { return fp_mul(v, fqu_k_to_u()); }
+__device__ __forceinline__ Fq2 coord_to_u(const Fq2& v) { return Fq2{coord_to_u(v.c0), coord_to_u(v.c1)}; }
+template <class F>
+__device__ __forceinline__ void bucket_store_sat(u64* slot, const XYZZ<F>& v, int ubuckets) {
+    if (!ubuckets) {
+        xyzz_store<F>(slot, v);
+        return;
+    }
+    XYZZ<F> u = v.is_zero() ? XYZZ<F>{F::zero(), F::zero(), F::zero(), F::zero()} : XYZZ<F>{coord_to_u(v.x), coord_to_u(v.y), coord_to_u(v.zz), coord_to_u(v.zzz)};
+    xyzz_store<F>(slot, u);
+}
+
 template <class F>
 // (<= 128 VGPRs, spilling: with no work items -- the normal case -- its blocks must slip into the register space the accumulate
 // kernels leave free; at 250 VGPRs each empty block waited for a drained SIMD and the empty launch took 7 ms in the pipeline)
@@ -85,7 +106,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 // one 128-thread block per over-full bucket: strided sums of its partials, tree reduction (in place in `partials`), add to the bucket
 template <class F>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_heavy_combine(const u32* hdr, const u32* heavy, u64* partials, size_t B, u64* buckets, const uint8_t* dirty, u32 cap) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_heavy_combine(const u32* hdr, const u32* heavy, u64* partials, size_t B, u64* buckets, const uint8_t* dirty, u32 cap, int ubuckets) {
     const u32 k = blockIdx.x, tid = threadIdx.x;
     u32 n_heavy = hdr[1] < cap ? hdr[1] : cap;
     if (k >= n_heavy) return;
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     if (tid == 0) {
         u64* slot = buckets + (size_t)XW * ((size_t)lane * B + b);
-        xyzz_store<F>(slot, xyzz_add(xyzz_load<F>(slot), v));
+        bucket_store_sat<F>(slot, xyzz_add(bucket_load_sat<F>(slot, ubuckets), v), ubuckets);
     }
 }
 
@@ -221,7 +242,7 @@ __global__ void k_reduce_tail_finish(const u64* sums, unsigned scale_dbl, size_t
 // 12 x u32 integers (converted at registration).  Buckets leave in the usual saturated XYZZ Montgomery form.
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_u(
     const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets,
-    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap) {
+    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap, int ubuckets) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
     const unsigned lane = blockIdx.y;
@@ -263,6 +284,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             return;
         }
     }
+    u64* slot = buckets + (size_t)24 * ((size_t)lane * B + b);
+    if (ubuckets) {   // the reduction runs in this residue system too (k_reduce_*_u): no conversion, the accumulator is stored as it is
+        XYZZU o;
+        o.inf = inf;
+        o.x = ax;
+        o.y = ay;
+        o.zz = azz;
+        o.zzz = azzz;
+        xyzzu_store(slot, o);
+        return;
+    }
     XYZZ<Fq> out = XYZZ<Fq>::zero();
     if (!inf) {
         const Fq kf = fqu_k_from_u();
@@ -271,7 +303,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         out.zz = fp_mul(fqu_pack(azz), kf);
         out.zzz = fp_mul(fqu_pack(azzz), kf);
     }
-    xyzz_store<Fq>(buckets + (size_t)24 * ((size_t)lane * B + b), out);
+    xyzz_store<Fq>(slot, out);
 }
 
 // recomputes the buckets k_accumulate_u gave up on, in the saturated residue system (points converted on the fly).
@@ -280,7 +312,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // Limiting it to 128 VGPRs (-DCZK_FIX_NARROW) removes that wait and shortens one proof's latency by ~1 ms, but the blocks then
 // run BESIDE the accumulate waves and cost 0.8 % of throughput (A/B on one box: 89.8 vs 89.1 ms per proof): not adopted.)
 __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
-                                                         size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
+                                                         size_t sorted_stride, u64* buckets, const uint8_t* dirty, int ubuckets) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const unsigned lane = blockIdx.y;
@@ -296,13 +328,13 @@ __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u_fix(const u64
         if (code & 0x80000000u) qy = fp_neg(qy);
         xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy);
     }
-    xyzz_store<Fq>(buckets + (size_t)24 * ((size_t)lane * B + b), XYZZ<Fq>{ax, ay, azz, azzz});
+    bucket_store_sat<Fq>(buckets + (size_t)24 * ((size_t)lane * B + b), XYZZ<Fq>{ax, ay, azz, azzz}, ubuckets);
 }
 
 // adds the deferred points into the finished buckets (sequentially: several may hit one bucket); buckets that were
 // recomputed from scratch by k_accumulate_u_fix already contain theirs
 __global__ void k_accumulate_u_cleanup(const u64* pts, size_t B, u64* buckets, const uint8_t* dirty, const u32* exc_count, const u32* exc_list,
-                                       u32 exc_cap) {
+                                       u32 exc_cap, int ubuckets) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     u32 n = *exc_count;
     if (n > exc_cap) n = exc_cap;
@@ -311,12 +343,12 @@ __global__ void k_accumulate_u_cleanup(const u64* pts, size_t B, u64* buckets, c
         u32 lane = exc_list[3 * k], b = exc_list[3 * k + 1], code = exc_list[3 * k + 2];
         if (dirty[(size_t)lane * B + b]) continue;
         u64* slot = buckets + (size_t)24 * ((size_t)lane * B + b);
-        XYZZ<Fq> acc = xyzz_load<Fq>(slot);
+        XYZZ<Fq> acc = bucket_load_sat<Fq>(slot, ubuckets);
         const u64* pp = pts + (size_t)12 * (code & 0x7fffffffu);
         Fq qx = fp_mul(fp_load<FqParams>(pp), kf), qy = fp_mul(fp_load<FqParams>(pp + 6), kf);
         if (code & 0x80000000u) qy = fp_neg(qy);
         xyzz_acc_mixed(acc.x, acc.y, acc.zz, acc.zzz, qx, qy);
-        xyzz_store<Fq>(slot, acc);
+        bucket_store_sat<Fq>(slot, acc, ubuckets);
     }
 }
 
@@ -330,6 +362,72 @@ __global__ void k_convert_from_u(u64* pts, size_t n_coords) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_coords) return;
     fp_store<FqParams>(pts + 6 * i, fp_mul(fp_load<FqParams>(pts + 6 * i), fqu_k_from_u()));
+}
+
+// ---- the bucket reduction in the unsaturated residue system (same algorithm as k_reduce_level / k_reduce_tail_* above; buckets and
+// every intermediate array in u-form, fqu.h XYZZU) --------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level_u(const u64* P_in, const u64* E_in, size_t n_in, unsigned L,
+                                                                                                    unsigned scale_dbl, u64* P_out, u64* E_out, size_t n_out) {
+    size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_out) return;
+    const size_t seg = blockIdx.y;
+    const u64* P = P_in + (size_t)24 * seg * n_in;
+    size_t start = m * L, end = start + L < n_in ? start + L : n_in;
+    XYZZU running = xyzzu_zero(), A = xyzzu_zero();
+    for (size_t t = end; t-- > start;) {
+        xyzzu_add(running, xyzzu_load(P + 24 * t));
+        if (t > start) xyzzu_add(A, running);
+    }
+    for (unsigned k = 0; k < scale_dbl; k++) xyzzu_double(A);
+    if (E_in) {
+        const u64* E = E_in + (size_t)24 * seg * n_in;
+        for (size_t t = start; t < end; t++) xyzzu_add(A, xyzzu_load(E + 24 * t));
+    }
+    xyzzu_store(P_out + (size_t)24 * (seg * n_out + m), running);
+    xyzzu_store(E_out + (size_t)24 * (seg * n_out + m), A);
+}
+__global__ void k_finish_u(const u64* P, const u64* E, size_t segs, u64* out) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= segs) return;
+    XYZZU r = xyzzu_load(P + (size_t)24 * s);
+    if (E) xyzzu_add(r, xyzzu_load(E + (size_t)24 * s));
+    jac_store<Fq>(out + (size_t)18 * s, xyzz_to_jac(xyzzu_to_sat(r)));   // the result leaves in the reference's Montgomery form
+}
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tail_sums_u(const u64* P_in, const u64* E_in, size_t n_in, u64* scratch,
+                                                                                                        u64* sums) {
+    const unsigned which = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
+    const u64* src = which == 10 ? E_in : P_in;
+    XYZZU v = xyzzu_zero();
+    if (src) {
+        src += (size_t)24 * seg * n_in;
+        for (size_t j = tid; j < n_in; j += TAIL_THREADS)
+            if (which >= 10 || ((j >> which) & 1)) xyzzu_add(v, xyzzu_load(src + 24 * j));
+    }
+    u64* sc = scratch + (size_t)24 * ((size_t)(seg * TAIL_BLOCKS + which) * TAIL_THREADS);
+    xyzzu_store(sc + (size_t)24 * tid, v);
+    __syncthreads();
+    for (unsigned stride = TAIL_THREADS / 2; stride > 0; stride >>= 1) {
+        if (tid < stride) {
+            xyzzu_add(v, xyzzu_load(sc + (size_t)24 * (tid + stride)));
+            xyzzu_store(sc + (size_t)24 * tid, v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) xyzzu_store(sums + (size_t)24 * (seg * TAIL_BLOCKS + which), v);
+}
+__global__ void k_reduce_tail_finish_u(const u64* sums, unsigned scale_dbl, size_t segs, u64* out) {
+    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= segs) return;
+    const u64* sm = sums + (size_t)24 * s * TAIL_BLOCKS;
+    XYZZU acc = xyzzu_load(sm + 24 * 9);
+    for (int b = 8; b >= 0; b--) {
+        xyzzu_double(acc);
+        xyzzu_add(acc, xyzzu_load(sm + 24 * b));
+    }
+    for (unsigned k = 0; k < scale_dbl; k++) xyzzu_double(acc);
+    xyzzu_add(acc, xyzzu_load(sm + 24 * 10));
+    xyzzu_add(acc, xyzzu_load(sm + 24 * 11));   // weights are b + 1 (see k_finish)
+    jac_store<Fq>(out + (size_t)18 * s, xyzz_to_jac(xyzzu_to_sat(acc)));
 }
 #endif
 #ifdef CZK_FQU_G2

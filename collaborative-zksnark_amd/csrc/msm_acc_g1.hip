@@ -19,21 +19,21 @@ void launch_accumulate_g1_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, un
     (void)hipMemsetAsync(dirty, 0, flags + 16, st);
 }
 void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
-                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty) {
+                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets) {
     // workspace behind the dirty flags: [count][list of EXC_CAP x 3 u32]
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
     ProfScope ps(ctx, "msm_accumulate_g1", st);   // brackets the dominant kernel only
     hipLaunchKernelGGL(k_accumulate_u, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                       sorted_stride, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
+                       sorted_stride, buckets, dirty, exc, exc + 4, G1_EXC_CAP, ubuckets);
 }
 void launch_accumulate_g1_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
-                                  u64* buckets, unsigned lanes, uint8_t* dirty) {
+                                  u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets) {
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
     hipLaunchKernelGGL(k_accumulate_u_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
-                       sorted_stride, buckets, dirty);
-    hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
+                       sorted_stride, buckets, dirty, ubuckets);
+    hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP, ubuckets);
 }
 // ---- batched-affine pre-reduction (msm_aff.h) ----------------------------------------------------------------------------
 // Slot counts of the levels: S_r = round_up_64((S_{r-1} + B + 1) / 2 + 1) with S_0 = entries per lane.
@@ -86,7 +86,7 @@ void launch_accumulate_g1_u_fixup_lvl(hipStream_t st, const u64* pts, const u32*
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
     hipLaunchKernelGGL(k_accumulate_u_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
-                       sorted_stride, buckets, dirty);
+                       sorted_stride, buckets, dirty, 0);
     hipLaunchKernelGGL(k_accumulate_u_lvl_cleanup, dim3(1), dim3(64), 0, st, (const uint4*)lvl, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
 }
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords) {
@@ -107,13 +107,25 @@ void launch_reduce_tail_g1(hipStream_t st, const u64* P, const u64* E, size_t n_
     hipLaunchKernelGGL((k_reduce_tail_sums<Fq, 24, 0>), dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
     hipLaunchKernelGGL((k_reduce_tail_finish<Fq, 24, 0>), dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
 }
+// the same three steps of the bucket reduction on u-form buckets (msm_acc.h k_reduce_*_u)
+void launch_reduce_level_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
+                              unsigned lanes) {
+    hipLaunchKernelGGL(k_reduce_level_u, dim3((unsigned)((n_out + 127) / 128), lanes), dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
+}
+void launch_finish_g1_u(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out) {
+    hipLaunchKernelGGL(k_finish_u, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, st, P, E, segs, out);
+}
+void launch_reduce_tail_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out, unsigned lanes) {
+    hipLaunchKernelGGL(k_reduce_tail_sums_u, dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
+    hipLaunchKernelGGL(k_reduce_tail_finish_u, dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
+}
 // over-full buckets (see msm_acc.h): item list, per-item partial sums, combination into the buckets; all on `st`
 void launch_heavy_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
-                     u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat) {
+                     u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat, int ubuckets) {
     (void)hipMemsetAsync(hdr, 0, 16, st);
     hipLaunchKernelGGL(k_heavy_list<Fq>, dim3((unsigned)((B + 255) / 256), lanes), dim3(256), 0, st, counts, B, hdr, items, heavy, cap);
     hipLaunchKernelGGL(k_accumulate_heavy<Fq>, dim3((cap + 127) / 128), dim3(128), 0, st, pts, sorted, offsets, counts, B, sorted_stride, hdr, items,
                        partials, cap, unsat);
-    hipLaunchKernelGGL(k_heavy_combine<Fq>, dim3(cap / 4 + 1), dim3(128), 0, st, hdr, heavy, partials, B, buckets, dirty, cap);   // a bucket is over-full above 1024 entries: at most total / 1024 of them
+    hipLaunchKernelGGL(k_heavy_combine<Fq>, dim3(cap / 4 + 1), dim3(128), 0, st, hdr, heavy, partials, B, buckets, dirty, cap, ubuckets);   // a bucket is over-full above 1024 entries: at most total / 1024 of them
 }
 }  // namespace czk

@@ -11,6 +11,6 @@ void launch_heavy_g2(hipStream_t st, const u64* pts, const u32* sorted, const u3
     hipLaunchKernelGGL(k_heavy_list<Fq2>, dim3((unsigned)((B + 255) / 256), lanes), dim3(256), 0, st, counts, B, hdr, items, heavy, cap);
     hipLaunchKernelGGL(k_accumulate_heavy<Fq2>, dim3((cap + 127) / 128), dim3(128), 0, st, pts, sorted, offsets, counts, B, sorted_stride, hdr, items,
                        partials, cap, unsat);
-    hipLaunchKernelGGL(k_heavy_combine<Fq2>, dim3(cap / 4 + 1), dim3(128), 0, st, hdr, heavy, partials, B, buckets, dirty, cap);   // a bucket is over-full above 1024 entries: at most total / 1024 of them
+    hipLaunchKernelGGL(k_heavy_combine<Fq2>, dim3(cap / 4 + 1), dim3(128), 0, st, hdr, heavy, partials, B, buckets, dirty, cap, 0);   // a bucket is over-full above 1024 entries: at most total / 1024 of them
 }
 }  // namespace czk
