@@ -308,21 +308,22 @@ def verify_openings(czk, ctx, B, out) -> dict:
         if isinstance(o, dict) and o.get("of"):
             c = out[o["of"] + "_cmt"]
             check(lambda ln: pt(c[0][ln], c[1][ln]), o)
-    if "open_beta" in out:
-        labels = ["w", "z_a", "z_b", "mask_poly", "t", "g_1", "h_1"]
-        ch = out["open_beta"]["fold"]
+    for key in ("open_beta", "open_gamma"):
+        if key not in out:
+            continue
+        terms = out[key]["terms"]                                   # the opened polynomial = sum coef * (committed polynomial)
 
-        def folded(ln):
-            acc, c = None, 1
-            for lb in labels:
-                cm = out[lb + "_cmt"]
-                public = cm[0].shape[0] == 1            # a public polynomial (t) enters a share-wise sum on the lifting lanes only
-                if not public or B.lift[ln]:
+        def folded(ln, terms=terms):
+            acc = None
+            for coef, name in terms:
+                cm = out[name + "_cmt"]
+                public = cm[0].shape[0] == 1                        # a public polynomial enters a share-wise sum on the lifting lanes only
+                lanes_out = out[key]["value"].shape[0]
+                if not public or lanes_out == 1 or B.lift[ln]:
                     l2 = 0 if public else ln
-                    acc = _ec_add(_Fq, acc, _ec_scalar_mul(_Fq, pt(cm[0][l2], cm[1][l2]), c))
-                c = c * ch % R_MOD
+                    acc = _ec_add(_Fq, acc, _ec_scalar_mul(_Fq, pt(cm[0][l2], cm[1][l2]), coef))
             return acc
-        check(folded, out["open_beta"])
+        check(folded, out[key])
     return {"results_checked": True, "results_checked_points": checked, "results_check_s": round(time.perf_counter() - t0, 2),
             "results_check": "every KZG opening verified on the host against its commitment with the synthetic SRS's known tau"}
 

@@ -166,9 +166,19 @@ class Backend:
         """`Prover::eval` (mpc-plonk/src/lib.rs:343-369) / KZG10::open (poly-commit/src/kzg10/mod.rs:225-265): the witness
         polynomial a / (X - x), its commitment, and the evaluation.  public: the polynomial is public data (its value needs no
         opening between the parties); None = infer from the lane count."""
+        return self.open_finish(self.open_begin(a, x, public))
+
+    def open_begin(self, a, x: int, public=None):
+        """First half of open_at: the witness polynomial and the evaluation (KZG10::compute_witness_polynomial,
+        poly-commit/src/kzg10/mod.rs:200-224); open_finish commits it.  Split because marlin_pc computes the witness of a
+        degree-bounded polynomial before it opens the folded polynomial (marlin_pc/mod.rs:291-330)."""
         wit, value = self.div_linear(a, x)
         self.reveal(value)
-        return {"value": value, "proof": self.commit(wit), "point": x}
+        return {"value": value, "point": x, "_wit": wit}
+
+    def open_finish(self, o):
+        o["proof"] = self.commit(o.pop("_wit"))
+        return o
 
     def quotient(self, a, x: int):
         """a / (X - x) without the remainder"""
@@ -404,11 +414,11 @@ class GpuBackend(Backend):
         self._pending.append(p)
         return p
 
-    def open_at(self, a, x, public=None):
+    def open_begin(self, a, x, public=None):
         wit, rem = self._div_linear_dev(a, x)
         v = Pending((self._value_kind(a, public), rem))
         self._pending.append(v)
-        return {"value": v, "proof": self.commit(wit), "point": x}
+        return {"value": v, "point": x, "_wit": wit}
 
     def transcript_point(self):
         if not self._pending:
@@ -530,9 +540,10 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
     open_("f_wr_open", l1, w * r % R_MOD, "l1")
     open_("q_r_open", q_up, r, "q")
     # l2_q (:228-243)
+    num_c, den_c = B.ntt(num_evals, W, IFFT), B.ntt(den_evals, W, IFFT)         # interpolate() of both before the coset transforms (:225-226)
     l1_v = B.ntt(l1, W, COSET_FFT)
-    num_v = B.ntt(B.ntt(num_evals, W, IFFT), W, COSET_FFT)
-    den_v = B.ntt(B.ntt(den_evals, W, IFFT), W, COSET_FFT)
+    num_v = B.ntt(num_c, W, COSET_FFT)
+    den_v = B.ntt(den_c, W, COSET_FFT)
     l2_q = B.ntt(B.scale(B.sub(B.mul(l1_v, den_v), num_v), zinv_w), W, COSET_IFFT)
     commit("l2_q", l2_q)
     B.transcript_point()
@@ -575,6 +586,10 @@ def marlin_inputs(B: Backend, n_constraints: int, seed: int = 0x3A21) -> dict:
         inp["star"][m] = {"on_K": [B.random(seed + 10 * (i + 1) + j, K) for j in range(3)],              # row, col, val
                           "on_B": [B.random(seed + 10 * (i + 1) + 3 + j, b_size) for j in range(4)]}    # row, col, row_col, val
     inp["index_polys"] = [B.ntt(B.random(seed + 100 + j, K), K, IFFT) for j in range(12)]                 # row / col / val / row_col of A, B, C
+    # ... committed at index time (marlin/src/lib.rs index(): the index_vk); the prover only re-uses the commitments
+    cm = [B.commit(a) for a in inp["index_polys"]]
+    B.transcript_point()
+    inp["index_cmts"] = resolved(cm)
     return inp
 
 
@@ -615,6 +630,7 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     r_alpha_evals = B.scale(B.inverse(B.add_const(B.scale(hpow, R_MOD - 1), alpha)), vanishing(H, alpha))
     r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT)
     t_poly = B.ntt(B.mul(inp["t_rows"], r_alpha_evals), H, IFFT)          # calculate_t (:400-416): matrix-weighted r_alpha on H
+    x_poly = B.ntt(inp["x"], X, IFFT)                                              # interpolated again in the second round (:503-507)
     z_poly = _padded_add(B, _mul_by_vanishing(B, w_poly, X), x_poly)              # w v_X + x (:512-517)
     n_rhs = max(B.length(r_alpha_poly) + B.length(summed), B.length(t_poly) + B.length(z_poly)) - 1
     mul_size = next_pow2(max(B.length(mask_poly), n_rhs + 1))                     # GeneralEvaluationDomain::new(max(..)) (:522-531)
@@ -625,6 +641,10 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     g_1 = B.drop_first(x_g_1, 1)
     for label, a in (("t", t_poly), ("g_1", g_1), ("h_1", h_1)):
         commit(label, a)
+        if label == "g_1":
+            # a degree-bounded oracle (g_1: |H| - 2) carries a second commitment over the shifted powers (marlin_pc/mod.rs commit: `shifted_comm`):
+            # the same scalars, the same length -- the stand-in key commits over the same prefix of powers
+            commit("g_1_shifted", a)
     # ---- third round (:585-704): everything public ---------------------------------------------------------------
     B.transcript_point()
     beta = challenge("marlin.beta")
@@ -653,26 +673,73 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     h_2, _ = B.div_vanishing(B.sub(B.resized(a_poly, B.length(bf)), bf), K)        # (a - b f) / v_K (:693-696)
     for label, a in (("g_2", g_2), ("h_2", h_2)):
         commit(label, a)
-    # ---- openings (marlin/src/lib.rs:262-318 -> PC::open_combinations, poly-commit/src/marlin_pc/mod.rs): every oracle is evaluated at
-    # its query point (first / second round oracles at beta, third round oracles and the index polynomials at gamma) and all
-    # polynomials queried at one point are folded with powers of the opening challenge into ONE witness polynomial = one MSM
+        if label == "g_2":
+            commit("g_2_shifted", a)                                                # degree bound |K| - 2
+    # ---- evaluations and openings (marlin/src/lib.rs:262-318) ---------------------------------------------------------------
     B.transcript_point()
-    ch = challenge("marlin.opening_challenge")
     gamma = challenge("marlin.gamma")
-    idx_polys = inp["index_polys"]
-    for tag, pt, polys in (("beta", beta, [w_poly, z_a, z_b, mask_poly, t_poly, g_1, h_1]), ("gamma", gamma, [g_2, h_2] + idx_polys)):
-        folded, c = None, 1
-        for a in polys:
-            out.setdefault("evals_" + tag, []).append(B.evaluate(a, pt))       # get_lc_eval: the polynomial's value at the point
-            term = B.scale(a, c)
+    idx = inp["index_polys"]                                                       # row, col, val, row_col of A, B, C
+    row, col, val, row_col = ({m: idx[4 * i + j] for i, m in enumerate("abc")} for j in range(4))
+    polys = {"w": w_poly, "z_a": z_a, "z_b": z_b, "mask_poly": mask_poly, "t": t_poly, "g_1": g_1, "h_1": h_1, "g_2": g_2, "h_2": h_2}
+    for i, m in enumerate("abc"):
+        polys.update({m + "_row": row[m], m + "_col": col[m], m + "_val": val[m], m + "_row_col": row_col[m]})
+        for j, part in enumerate(("row", "col", "val", "row_col")):
+            out[m + "_" + part + "_cmt"] = inp["index_cmts"][4 * i + j]            # index-time commitments (not prover work)
+    # the linear combinations of AHPForR1CS::construct_linear_combinations (marlin/src/ahp/mod.rs:115-260); their coefficients are
+    # products of challenges and evaluations in the reference -- fixed stand-ins here (values do not change the work); constant
+    # (LCTerm::One) terms do not enter the opened polynomial (poly-commit/src/marlin/mod.rs:256)
+    lcs = {"z_b": [(1, "z_b")], "g_1": [(1, "g_1")], "t": [(1, "t")], "g_2": [(1, "g_2")],
+           "outer_sumcheck": [(1, "mask_poly"), (challenge("marlin.lc.z_a"), "z_a"), (challenge("marlin.lc.w"), "w"), (challenge("marlin.lc.h_1"), "h_1")],
+           "inner_sumcheck": [(challenge("marlin.lc." + m + "_val"), m + "_val") for m in "abc"] + [(challenge("marlin.lc.h_2"), "h_2")]}
+    for m in "abc":
+        lcs[m + "_denom"] = [(R_MOD - alpha, m + "_row"), (R_MOD - beta, m + "_col"), (1, m + "_row_col")]
+    point = {"beta": beta, "gamma": gamma}
+    query = {"beta": ["g_1", "outer_sumcheck", "t", "z_b"], "gamma": ["a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"]}   # verifier_query_set (ahp/verifier.rs:143-146, 207-211), labels in BTreeSet order
+
+    def lc_eval(label, tag):
+        """EvaluationsProvider::get_lc_eval for the prover's polynomials (ahp/mod.rs:288-312): every polynomial of the combination
+        is evaluated at the point (Polynomial::evaluate), the sum is publicized"""
+        for _, name in lcs[label]:
+            out.setdefault("evals_" + tag, []).append(B.evaluate(polys[name], point[tag]))
+    # construct_linear_combinations evaluates what the coefficients of the two sumcheck combinations need (:155-157, :228-231) ...
+    for label, tag in (("z_b", "beta"), ("t", "beta"), ("g_1", "beta"), ("a_denom", "gamma"), ("b_denom", "gamma"), ("c_denom", "gamma"), ("g_2", "gamma")):
+        lc_eval(label, tag)
+    # ... and Marlin::prove evaluates every queried combination (lib.rs:283-292; the query set iterates in label order)
+    for label in sorted(lcs):
+        lc_eval(label, "beta" if label in query["beta"] else "gamma")
+    B.transcript_point()                                                           # fs_rng.absorb(&evaluations) (:299)
+    ch = challenge("marlin.opening_challenge")
+    # PC::open_combinations (poly-commit/src/marlin/mod.rs:213-300): one polynomial per combination ...
+    lc_poly = {}
+    for label, terms in lcs.items():
+        acc = None
+        for coef, name in terms:
+            term = polys[name] if coef == 1 else B.scale(polys[name], coef)
+            acc = term if acc is None else _padded_add(B, acc, term)
+        lc_poly[label] = acc
+    # ... then batch_open (poly-commit/src/lib.rs:597-640): per query point the queried polynomials are folded with powers of the opening
+    # challenge and opened once (marlin_pc/mod.rs:259-316); a degree-bounded polynomial (g_1: |H| - 2, g_2: |K| - 2) takes two
+    # challenges and also opens its own witness polynomial over the shifted powers (:291-310, :318-330)
+    for tag in ("beta", "gamma"):
+        folded, c, terms = None, 1, []
+        shifted = None
+        for label in query[tag]:
+            a = lc_poly[label]
+            term = a if c == 1 else B.scale(a, c)
             folded = term if folded is None else _padded_add(B, folded, term)
+            terms += [(c * coef % R_MOD, name) for coef, name in lcs[label]]
             c = c * ch % R_MOD
-        out["open_" + tag] = B.open_at(folded, pt)
-        out["open_" + tag]["fold"] = ch
-    # degree-bounded oracles (g_1: |H| - 2, g_2: |K| - 2) carry a second, shifted commitment (marlin_pc commit with a degree
-    # bound): the same scalars over the shifted powers -- same work; the stand-in commits over the same prefix of powers
-    commit("g_1_shifted", g_1)
-    commit("g_2_shifted", g_2)
+            if label in ("g_1", "g_2"):
+                shifted = label
+                c = c * ch % R_MOD
+        # the shifted-witness opening: (g - g(point)) / (X - point), computed inside the folding loop (:294-299), committed over the
+        # shifted powers after the folded polynomial has been opened (:318-330) -- the stand-in key commits over the same prefix of
+        # powers (same scalars, same length: same work)
+        sh = B.open_begin(polys[shifted], point[tag], public=B.lanes_of(polys[shifted]) == 1 and B.lanes > 1)
+        out["open_" + tag] = B.open_at(folded, point[tag])
+        out["open_" + tag]["terms"] = terms                                        # the opened polynomial as sum coef * committed polynomial
+        out["open_" + tag + "_shifted"] = B.open_finish(sh)
+        out["open_" + tag + "_shifted"]["of"] = shifted
     B.transcript_point()
     return resolved(out)
 

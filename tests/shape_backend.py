@@ -66,6 +66,16 @@ class ShapeBackend(Backend):
         self.log.append(("div_linear", a.n, a.lanes))
         return Arr(a.lanes, max(a.n - 1, 0)), np.zeros((a.lanes, 4), dtype=np.uint64)
 
+    def evaluate(self, a, x, public=None):
+        """Polynomial::evaluate at one point (the GPU backend runs it as the remainder of a division by X - x)"""
+        self.log.append(("evaluate", a.n, a.lanes))
+        return np.zeros((a.lanes, 4), dtype=np.uint64)
+
+    def div_vanishing(self, a, n):
+        """divide_by_vanishing_poly in coefficient form: an O(len) pass of additions in the reference; logged as one operation"""
+        self.log.append(("div_vanishing", a.n, a.lanes, int(n)))
+        return Arr(a.lanes, max(a.n - n, 0)), Arr(a.lanes, min(a.n, n))
+
     def prefix_product(self, a):
         self.log.append(("prefix_product", a.n, a.lanes))
         return Arr(a.lanes, a.n)
