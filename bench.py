@@ -498,6 +498,39 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     if world > 1:
         torch.distributed.destroy_process_group()
 
+def mac_shortcut_report(czk, device, tstream, n_constraints, args, value, check_results) -> dict:
+    """The reference's SPDZ multi_scale_pub_group reads `s.sh.val` for BOTH of its MSMs (mpc-algebra/src/share/spdz.rs:441-442), so
+    its mac-lane MSM is its sh-lane MSM again.  A binding at that function may therefore run one MSM per party and return the result
+    twice -- bit-identical to the reference.  Reported separately and NEVER as `value`: the headline keeps one MSM per share lane, which
+    is what SPDZ with distinct MAC scalars needs (and what the reference spends)."""
+    import torch
+    from czk_amd.provers import Groth16Local
+    try:
+        ctx2 = czk.Context(device, tstream.cuda_stream)
+        p2 = Groth16Local(czk, ctx2, n_constraints, args.parties, mac_msm_from_sh=True)
+        for _ in range(max(1, args.warmup)):
+            p2.step()
+        p2.all_results.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            p2.step(sync=False)
+        ctx2.sync()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res = {"proofs_per_s": args.steps / dt, "ms_per_proof": dt / args.steps * 1e3, "fraction_of_value": args.steps / dt / value,
+               "note": "one MSM per PARTY (over its sh lane), result used for the sh and the mac group share, as the reference's spdz.rs:440-446 "
+                       "computes them; witness map unchanged (all share lanes); never `value`"}
+        if not args.no_result_check:
+            res["results_checked"] = bool(check_results(czk, ctx2, p2, p2.expand_results(p2.all_results[-1]))["results_checked"])
+        del p2
+        ctx2.close()
+        torch.cuda.empty_cache()
+        return res
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)[-400:]}
+
+
 def seam_device_handles(n_constraints: int, parties: int, steps: int, warmup: int, value: float) -> dict:
     """The same step from a torch-free, Python-free host: tools/host_demo.cpp `bench` (C++ over include/czk.hpp, the mirror of the
     Rust shim) builds the same circuit, key and shares from host vectors, uploads the share lanes ONCE into czk_lanes handles,
@@ -763,6 +796,8 @@ def main():
                                    "note": "7 czk_ntt_fr + 5 czk_msm calls per proof with CZK_MEM_HOST (pageable) buffers for all share lanes, "
                                            "bases registered: what a reference caller binding only the NTT / MSM seams sees (PCIe staging included; "
                                            "never `value`)"}
+    if rank == 0 and world == 1 and not args.no_seam_report and not party_layout:
+        out["spdz_mac_msm_from_sh"] = mac_shortcut_report(czk, device, tstream, n_constraints, args, proofs / dt, check_results)
     if rank == 0 and world == 1 and not args.no_seam_report and not party_layout:
         out["seam_device_handles"] = seam_device_handles(n_constraints, args.parties, args.steps, args.warmup, proofs / dt)
     if rank == 0 and world == 1 and not args.no_seam_report and not party_layout:

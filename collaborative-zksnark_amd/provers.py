@@ -64,12 +64,19 @@ class Groth16Local:
     """Device-resident state + the per-proof pipeline for `n_constraints` constraints of the reference's benchmark
     circuit (squaring chain, mpc-snarks/src/proof.rs:304-344), SPDZ shares of `parties` parties."""
 
-    def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None, no_tables: bool = False):
+    def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None, no_tables: bool = False,
+                 mac_msm_from_sh: bool = False):
         """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
         configs[1]); with one party per rank the two opens of the witness map run the reference's two broadcast rounds
         over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused.  no_tables:
         register the proving key with CZK_MEM_NO_TABLES (what a prover that runs once should do)."""
         self.czk, self.ctx = czk, ctx
+        # mac_msm_from_sh: the reference's SPDZ multi_scale_pub_group computes BOTH group shares from the `sh` scalars
+        # (mpc-algebra/src/share/spdz.rs:440-446: `macs` is built from `s.sh.val` too), so its mac-lane MSM repeats its sh-lane MSM
+        # bit for bit.  A caller that binds at that function can run ONE MSM per party and use the result twice; this switch does
+        # exactly that (MSMs over the parties' sh lanes only, results duplicated).  Off by default: the headline keeps one MSM per
+        # share lane, as a general SPDZ implementation with distinct MAC scalars needs.
+        self.mac_msm_from_sh = bool(mac_msm_from_sh)
         self.N = int(n_constraints)
         self.P = parties
         self.local = list(range(parties)) if local_parties is None else list(local_parties)
@@ -176,6 +183,9 @@ class Groth16Local:
         self.sx, self.oy = (torch.zeros((D, 4), dtype=torch.int64, device=dev) for _ in range(2))
         self.chk = torch.zeros((2, D, 4), dtype=torch.int64, device=dev)
         self.ab = lanes_buf()
+        if self.mac_msm_from_sh:
+            self.wit_sh, self.asg_sh = self.wit[0::2].contiguous(), self.asg[0::2].contiguous()
+            self.ab_sh = torch.zeros((L // 2, D, 4), dtype=torch.int64, device=dev)
         self.results = {}
         self.all_results = []
 
@@ -207,10 +217,14 @@ class Groth16Local:
             ctx.fr_vec_op(SUB, chk.data_ptr(), shares[2 * p + 1].data_ptr(), out=chk.data_ptr(), n=D, mem=M)
 
     def new_results(self):
-        L = self.lanes
+        L = self.lanes // 2 if self.mac_msm_from_sh else self.lanes
         r = {k: np.zeros((L, 18), dtype=np.uint64) for k in ("h", "l", "a", "b_g1")}
         r["b_g2"] = np.zeros((L, 36), dtype=np.uint64)
         return r
+
+    def expand_results(self, r):
+        """mac_msm_from_sh: one result per party -> the (sh, mac) pair of every party, as the reference's multi_scale_pub_group returns"""
+        return {k: np.repeat(v, 2, axis=0) for k, v in r.items()} if self.mac_msm_from_sh and r["h"].shape[0] != self.lanes else r
 
     def step(self, sync=True):
         """One proof's local compute.  sync=False only enqueues (consecutive proofs then pipeline: the next proof's
@@ -222,6 +236,8 @@ class Groth16Local:
         MONT = czk.CZK_SCALAR_MONTGOMERY
         r = self.results = self.new_results()      # every proof keeps its own output buffers
         self.all_results.append(r)
+        if self.mac_msm_from_sh:
+            return self._step_mac_from_sh(r, sync)
         # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
         # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
         ctx.msm_async(self.b_g2_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g2"], stable=True)
@@ -248,6 +264,32 @@ class Groth16Local:
         # --- the h MSM (prover.rs:104) needs the witness map's output; NOT flagged stable: the next proof's witness
         # map overwrites `ab`, so the context's stream waits for this MSM's digit extraction (library-side ordering)
         ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"])
+        if sync:
+            ctx.sync()
+
+    def _step_mac_from_sh(self, r, sync):
+        """step() with the MSMs over the parties' sh lanes only (see mac_msm_from_sh); the witness map still runs every lane"""
+        czk, ctx = self.czk, self.ctx
+        D, N, L, ld = self.D, self.N, self.lanes, self.log_d
+        M, ADD, MONT, P = czk.CZK_MEM_DEVICE, 0, czk.CZK_SCALAR_MONTGOMERY, self.lanes // 2
+        ctx.msm_async(self.b_g2_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["b_g2"], stable=True)
+        ctx.msm_async(self.l_query, self.wit_sh.data_ptr(), N, P, MONT, r["l"], stable=True)
+        ctx.msm_async(self.a_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["a"], stable=True)
+        ctx.msm_async(self.b_g1_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["b_g1"], stable=True)
+        ctx.r1cs_matvec(self.mat_a, self.full.data_ptr(), lanes=L, out=self.a.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.r1cs_matvec(self.mat_b, self.full.data_ptr(), lanes=L, out=self.b.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.r1cs_matvec(self.mat_c, self.full.data_ptr(), lanes=L, out=self.c.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
+        ctx.witness_map_pre(self.a.data_ptr(), self.b.data_ptr(), ld, L, a_len=N + 2, b_len=N)
+        ctx.fr_vec_op(ADD, self.a.data_ptr(), self.tx.data_ptr(), out=self.a.data_ptr(), n=L * D, mem=M)
+        ctx.fr_vec_op(ADD, self.b.data_ptr(), self.ty.data_ptr(), out=self.b.data_ptr(), n=L * D, mem=M)
+        self._open(self.a, self.sx, self.chk[0])
+        self._open(self.b, self.oy, self.chk[1])
+        for ln in range(L):
+            ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
+                                  self.oy.data_ptr(), ln in self.king_lanes, out=self.ab[ln].data_ptr(), n=D, mem=M)
+        ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L, c_len=N)
+        self.ab_sh.copy_(self.ab[0::2])                      # the sh lanes of h, contiguous (torch's stream == the context's stream)
+        ctx.msm_async(self.h_query, self.ab_sh.data_ptr(), D, P, MONT, r["h"])
         if sync:
             ctx.sync()
 

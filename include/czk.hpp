@@ -294,14 +294,24 @@ inline void multi_scalar_mul_async(const Bases<GROUP>& bases, const DeviceLanes&
                                     CZK_MEM_DEVICE | (stable ? CZK_MEM_STABLE : 0), reinterpret_cast<uint64_t*>(out)));
 }
 
-// mpc-algebra/src/share/spdz.rs:440-446 -- SPDZ multi_scale_pub_group: two MSMs over the same bases.
-// Like the reference (line 442 re-reads `.sh.val`), BOTH results are computed from the sh values; they are
-// issued as two lanes of one call so the bases are gathered once.
+// mpc-algebra/src/share/spdz.rs:440-446 -- SPDZ multi_scale_pub_group.  The reference builds BOTH scalar vectors from `s.sh.val`
+// (:441 and :442), so its second MSM repeats the first bit for bit: one MSM is run and its result returned for `sh` and `mac` --
+// identical to the reference's output at half its work.  (A caller with distinct MAC scalars uses multi_scale_pub_group_lanes.)
 struct SpdzGroupShareG1 {
     G1Projective sh, mac;
     static SpdzGroupShareG1 multi_scale_pub_group(const G1Bases& bases, const std::vector<MpcField>& scalars) {
+        std::vector<Fr> shares(scalars.size());
+        for (size_t i = 0; i < scalars.size(); i++) shares[i] = scalars[i].sh;
+        G1Projective r = G1Affine::multi_scalar_mul(bases, shares);
+        return SpdzGroupShareG1{r, r};
+    }
+    // two scalar vectors over the same bases in ONE launch (the bases are gathered once): sh from .sh, mac from .mac
+    static SpdzGroupShareG1 multi_scale_pub_group_lanes(const G1Bases& bases, const std::vector<MpcField>& scalars) {
         std::vector<Fr> lanes(2 * scalars.size());
-        for (size_t i = 0; i < scalars.size(); i++) lanes[i] = lanes[scalars.size() + i] = scalars[i].sh;
+        for (size_t i = 0; i < scalars.size(); i++) {
+            lanes[i] = scalars[i].sh;
+            lanes[scalars.size() + i] = scalars[i].mac;
+        }
         G1Projective out[2];
         bases.ctx().check(czk_msm(bases.ctx().raw(), bases.raw(), lanes.empty() ? nullptr : lanes[0].l, scalars.size(), 2,
                                   CZK_SCALAR_MONTGOMERY, CZK_MEM_HOST, out[0].x.l));

@@ -293,3 +293,27 @@ def test_groth16_full_size_end_to_end_matches_checker(czk, orc, tmp_path):
             assert not winf
             assert not res_py[name][1][ln] and np.array_equal(res_py[name][0][ln], waff), ("python host", name, ln)
             assert not pts[name][1][ln] and np.array_equal(pts[name][0][ln], waff), ("c++ host", name, ln)
+
+
+@pytest.mark.gpu
+def test_groth16_mac_msm_from_sh_equals_the_per_lane_form(czk):
+    """The reference's SPDZ multi_scale_pub_group builds both of its scalar vectors from `s.sh.val` (mpc-algebra/src/share/spdz.rs:
+    441-442), so the mac group share is the sh MSM again: Groth16Local(mac_msm_from_sh=True) runs one MSM per party and duplicates
+    it; every group element must equal the per-lane form's (where the mac lanes carry the same values, MAC key 1)."""
+    import torch
+    from czk_amd.provers import Groth16Local
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        c2 = czk.Context(0, ts.cuda_stream)
+        outs = []
+        for flag in (False, True):
+            p = Groth16Local(czk, c2, 1000, 2, mac_msm_from_sh=flag)
+            p.step()
+            torch.cuda.synchronize()
+            r = p.expand_results(p.results)
+            assert all(v.shape[0] == 4 for v in r.values())
+            outs.append({k: c2.jac_to_affine(czk.CZK_G2 if k == "b_g2" else czk.CZK_G1, v) for k, v in r.items()})
+            del p
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k][0], outs[1][k][0]) and np.array_equal(outs[0][k][1], outs[1][k][1]), k
+        c2.close()

@@ -250,6 +250,20 @@ int main(int argc, char** argv) {
     G1Projective both[2] = {gs.sh, gs.mac};
     ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, both[0].x.l, 2, a2, i2));
     REQUIRE(memcmp(a2, a2 + 12, 96) == 0 && memcmp(a2, &pts[12 * n], 96) == 0);
+    // the two-lane form with distinct MAC scalars: mac = sum x[i % 13] * [i + 1] G differs from sh, and sh is unchanged
+    {
+        SpdzGroupShareG1 g2 = SpdzGroupShareG1::multi_scale_pub_group_lanes(bases, sc);
+        G1Projective pair[2] = {g2.sh, g2.mac};
+        uint64_t a3[24];
+        ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, pair[0].x.l, 2, a3, i2));
+        REQUIRE(memcmp(a3, a2, 96) == 0 && memcmp(a3 + 12, a2, 96) != 0);
+        std::vector<Fr> macs(n);
+        for (size_t i = 0; i < n; i++) macs[i] = sc[i].mac;
+        G1Projective want = G1Affine::multi_scalar_mul(bases, macs);
+        uint64_t w3[12];
+        ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, want.x.l, 1, w3, i2));
+        REQUIRE(memcmp(a3 + 12, w3, 96) == 0);
+    }
 
     // KZG10::commit: commitment to the all-ones polynomial with an all-ones blinding polynomial over the same powers
     // = 2 * [n(n+1)/2] G
