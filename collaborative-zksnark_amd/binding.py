@@ -15,6 +15,7 @@ _HEADER = os.path.join(os.path.dirname(_HERE), "include", "czk.h")
 CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT = 0, 1, 2, 3
 CZK_MEM_HOST, CZK_MEM_DEVICE = 0, 1
 CZK_MEM_NO_TABLES = 32   # czk_bases_register: OR-ed with the above, see include/czk.h
+CZK_MEM_ANY_POINTS = 64  # czk_bases_register: bases need not lie in the prime-order subgroup (keeps the XYZZ kernels for G1)
 CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY = 0, 1
 CZK_G1, CZK_G2 = 1, 2
 CZK_OP_ADD, CZK_OP_SUB, CZK_OP_MUL = 0, 1, 2
@@ -206,7 +207,7 @@ class Context:
     # ---- MSM ------------------------------------------------------------------------------------
     def register_bases(self, group: int, bases, inf=None, n: int | None = None, mem: int = CZK_MEM_HOST) -> "Bases":
         aw = 12 if group == CZK_G1 else 24
-        if (mem & ~CZK_MEM_NO_TABLES) == CZK_MEM_HOST:
+        if (mem & ~(CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS)) == CZK_MEM_HOST:
             bases = np.ascontiguousarray(bases, np.uint64)
             n = bases.size // aw
             if inf is not None:

@@ -137,6 +137,10 @@ struct czk_bases {
     unsigned c = 0;            // signed-digit window width chosen at registration
     unsigned W = 0;            // number of windows = ceil(254 / c)
     bool unsat = false;        // window tables hold coordinates * R' (fqu.h), used by k_accumulate_u / k_accumulate_u2
+    bool te = false;           // G1 only: window tables hold twisted Edwards niels entries (te.h: 18 u64 per point, u-form); buckets and the
+                               // reduction run in extended coordinates; `pts_sw0` keeps the original points for secondary table sets
+    bool te_wanted = true;     // false: registered with CZK_MEM_ANY_POINTS (bases need not lie in the prime-order subgroup)
+    uint64_t* pts_sw0 = nullptr;   // te: window 0 as registered (n x 12 u64, saturated Montgomery form)
     bool split = false;        // CZK_MEM_NO_TABLES: only window 0 is stored; an MSM runs one bucket set per window (windows become
                                // extra lanes of the same kernels) and the per-window results are combined afterwards
     uint64_t* pts = nullptr;   // device, W x n x (12|24) u64: window w holds 2^(c*w) * P_i, affine Montgomery
@@ -255,9 +259,16 @@ void launch_heavy_g1(hipStream_t st, const u64* pts, const u32* sorted, const u3
                      u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat, int ubuckets);
 // the bucket reduction on u-form buckets (G1: buckets stay in the unsaturated residue system of fqu.h until the last step)
 void launch_reduce_level_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
-                              unsigned lanes);
-void launch_finish_g1_u(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
-void launch_reduce_tail_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out, unsigned lanes);
+                              unsigned lanes, int te);
+void launch_finish_g1_u(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out, int te);
+void launch_reduce_tail_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out, unsigned lanes,
+                             int te);
+// G1 in twisted Edwards form (te.h): table conversion at registration, bucket accumulation, over-full buckets
+void launch_sw_to_te_niels(hipStream_t st, const u64* aff, const uint8_t* inf, size_t n, u64* scratch, u64* out, u32* bad);
+void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+                             size_t sorted_stride, u64* buckets, unsigned lanes);
+void launch_heavy_g1_te(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride, u64* buckets,
+                        unsigned lanes, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap);
 void launch_heavy_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
                      u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat);
 void launch_reduce_tail_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,

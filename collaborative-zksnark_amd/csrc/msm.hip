@@ -531,6 +531,37 @@ static unsigned choose_c_split(size_t n) {
     return best;
 }
 
+// G1 in twisted Edwards form (te.h): a saturated short-Weierstrass table of `count` points -> a freshly allocated niels table
+// (count x 18 u64, u-form).  *ok = false (and no table) when some point has no image under the map -- such a point has even order
+// and is never an element of G1; the caller then keeps the XYZZ path, which is complete on all of E.
+static int te_table_from_sw(czk_ctx* ctx, const u64* sw, const uint8_t* inf, size_t count, u64** out, bool* ok) {
+    *out = nullptr;
+    *ok = false;
+    u64 *te = nullptr, *scr = nullptr;
+    u32* bad = nullptr;
+    hipError_t e = hipMalloc(&te, count * 18 * 8);
+    if (e == hipSuccess) e = hipMalloc(&scr, count * 6 * 8);
+    if (e == hipSuccess) e = hipMalloc(&bad, 4);
+    if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, ctx->stream);
+    u32 hbad = 1;
+    if (e == hipSuccess) {
+        launch_sw_to_te_niels(ctx->stream, sw, inf, count, scr, te, bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (scr) (void)hipFree(scr);
+    if (bad) (void)hipFree(bad);
+    if (e != hipSuccess || hbad) {
+        if (te) (void)hipFree(te);
+        if (e != hipSuccess) return set_err(ctx, e == hipErrorOutOfMemory ? CZK_ERR_NOMEM : CZK_ERR_HIP, std::string("twisted Edwards table: ") + hipGetErrorString(e));
+        return CZK_OK;
+    }
+    *out = te;
+    *ok = true;
+    return CZK_OK;
+}
+
 template <class F>
 static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const uint8_t* inf_dev) {
     constexpr int AW = GT<F>::AW, JW = GT<F>::JW, FW = GT<F>::FW;
@@ -558,6 +589,28 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
         CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         CZK_HIP(ctx, hipFree(jac));
         CZK_HIP(ctx, hipFree(scr));
+    }
+    if (GT<F>::AW == 12 && b->te_wanted && !getenv("CZK_MSM_SAT") && !getenv("CZK_MSM_NO_TE") && !getenv("CZK_MSM_AFFINE")) {
+        // G1 bases in the prime-order subgroup: window tables as twisted Edwards niels entries (te.h), 7M unified mixed additions
+        u64* te = nullptr;
+        bool ok = false;
+        CZK_TRY(te_table_from_sw(ctx, b->pts, b->inf, (size_t)W * n, &te, &ok));
+        if (ok) {
+            u64* sw0 = nullptr;   // the registered points stay (secondary table sets are built from them)
+            hipError_t e = hipMalloc(&sw0, n * AW * 8);
+            if (e == hipSuccess) e = hipMemcpy(sw0, b->pts, n * AW * 8, hipMemcpyDeviceToDevice);
+            if (e != hipSuccess) {
+                (void)hipFree(te);
+                if (sw0) (void)hipFree(sw0);
+                return set_err(ctx, CZK_ERR_NOMEM, "hipMalloc registered points");
+            }
+            (void)hipFree(b->pts);
+            b->pts = te;
+            b->pts_sw0 = sw0;
+            b->te = true;
+            b->unsat = true;
+            return CZK_OK;
+        }
     }
     if (!getenv("CZK_MSM_SAT") && (GT<F>::AW == 12 || !getenv("CZK_MSM_SAT_G2"))) {
         // window tables go to the unsaturated residue system of fqu.h (infinity flags are unaffected); CZK_MSM_SAT=1
@@ -602,10 +655,10 @@ static int build_secondary(czk_ctx* ctx, const czk_bases* b, unsigned c, size_t 
     if (e == hipSuccess) e = hipMalloc(&t.inf, (size_t)W * cover);
     if (e == hipSuccess) e = hipMalloc(&jac, cover * JW * 8);
     if (e == hipSuccess) e = hipMalloc(&scr, cover * FW * 8);
-    if (e == hipSuccess) e = hipMemcpyAsync(t.pts, b->pts, cover * AW * 8, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(t.pts, b->te ? b->pts_sw0 : b->pts, cover * AW * 8, hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(t.inf, b->inf, cover, hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess) {
-        if (b->unsat) launch_convert_from_u(ctx->stream, t.pts, cover * (AW / 6));   // the key's window 0 back to Montgomery form
+        if (b->unsat && !b->te) launch_convert_from_u(ctx->stream, t.pts, cover * (AW / 6));   // the key's window 0 back to Montgomery form
         const unsigned CH = 32;
         unsigned g1 = (unsigned)((cover + 127) / 128), g2 = (unsigned)(((cover + CH - 1) / CH + 127) / 128);
         for (unsigned w = 1; w < W; w++) {
@@ -613,12 +666,24 @@ static int build_secondary(czk_ctx* ctx, const czk_bases* b, unsigned c, size_t 
             hipLaunchKernelGGL(k_batch_to_affine<F>, dim3(g2), dim3(128), 0, ctx->stream, jac, cover, CH, scr, t.pts + (size_t)w * cover * AW,
                                t.inf + (size_t)w * cover);
         }
-        if (b->unsat) launch_convert_to_u(ctx->stream, t.pts, (size_t)W * cover * (AW / 6));
+        if (b->unsat && !b->te) launch_convert_to_u(ctx->stream, t.pts, (size_t)W * cover * (AW / 6));
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (jac) (void)hipFree(jac);
     if (scr) (void)hipFree(scr);
+    if (e == hipSuccess && b->te) {   // the key is in twisted Edwards form: so is this set (its points have images: they are the key's)
+        u64* te = nullptr;
+        bool ok = false;
+        int rc = te_table_from_sw(ctx, t.pts, t.inf, (size_t)W * cover, &te, &ok);
+        (void)hipFree(t.pts);
+        t.pts = te;
+        if (rc != CZK_OK || !ok) {
+            if (t.inf) (void)hipFree(t.inf);
+            if (te) (void)hipFree(te);
+            return rc != CZK_OK ? rc : set_err(ctx, CZK_ERR_ARG, "secondary window tables: a multiple of a registered point has no twisted Edwards image");
+        }
+    }
     if (e != hipSuccess) {
         if (t.pts) (void)hipFree(t.pts);
         if (t.inf) (void)hipFree(t.inf);
@@ -710,8 +775,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     size_t need_aff = 0;
     // G1 buckets stay in the unsaturated residue system through the reduction (k_reduce_*_u) unless the batched-affine rounds
     // (which finish on saturated level points) or CZK_REDUCE_SAT ask for the saturated form
-    const int ub = (GT<F>::AW == 12 && b->unsat && !ctx->msm_reduce_sat && !(ctx->msm_affine_rounds > 0 && size > 0)) ? 1 : 0;
-    if (GT<F>::AW == 12 && b->unsat && ctx->msm_affine_rounds > 0 && size > 0) {
+    const int te = b->te ? 1 : 0;   // twisted Edwards tables and buckets (te.h): unified additions, no exception handling at all
+    const int ub = (te || (GT<F>::AW == 12 && b->unsat && !ctx->msm_reduce_sat && !(ctx->msm_affine_rounds > 0 && size > 0))) ? 1 : 0;
+    if (GT<F>::AW == 12 && b->unsat && !te && ctx->msm_affine_rounds > 0 && size > 0) {
         aff.rounds = ctx->msm_affine_rounds;
         aff.lanes = (unsigned)lanes;
         aff.B = B;
@@ -825,7 +891,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             aff.counts = counts;
             launch_affine_build_g1(ss, aff);
         }
-        if (b->unsat) {
+        if (b->unsat && !te) {
             // clear the dirty flags / exception list here rather than on the accumulate stream (the critical one); they live
             // in the slot's reduce workspace, which the slot's previous reduction may still be using
             if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_red, 0));
@@ -838,7 +904,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (!scalars_stable) CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
     CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
-    if (b->unsat) {
+    if (te) {
+        launch_accumulate_g1_te(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+    } else if (b->unsat) {
         // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
         if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, tv.pts, perm, buckets, dirty);
         else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
@@ -852,11 +920,13 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
     CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
     // work items beyond the first 1024 entries of over-full buckets (none with uniformly random scalars): reduce stream
-    if (GT<F>::AW == 12) launch_heavy_g1(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr,
+    if (te) launch_heavy_g1_te(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, heavy_hdr, heavy_items, heavy_list, heavy_partials,
+                               heavy_cap);
+    else if (GT<F>::AW == 12) launch_heavy_g1(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr,
                                          heavy_items, heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0, ub);
     else launch_heavy_g2(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr, heavy_items,
                          heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
-    if (b->unsat) {
+    if (b->unsat && !te) {
         // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
         if (aff.rounds)
             launch_accumulate_g1_u_fixup_lvl(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, aff.lvl[(aff.rounds - 1) & 1]);
@@ -873,7 +943,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         bool finished = false;
         while (n_in > 1) {
             if (n_in <= 1024) {   // latency-bound from here: bit-sum tree reductions instead of more levels
-                if (ub) launch_reduce_tail_g1_u(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
+                if (ub) launch_reduce_tail_g1_u(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes, te);
                 else if (GT<F>::AW == 12) launch_reduce_tail_g1(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
                 else launch_reduce_tail_g2(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
                 finished = true;
@@ -881,7 +951,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             }
             size_t n_out = (n_in + L - 1) / L;
             u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
-            if (ub) launch_reduce_level_g1_u(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
+            if (ub) launch_reduce_level_g1_u(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes, te);
             else if (GT<F>::AW == 12) launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
             else launch_reduce_level_g2(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
             P = Po;
@@ -891,7 +961,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             flip ^= 1;
         }
         if (finished) {
-        } else if (ub) launch_finish_g1_u(sr, P, E, lanes, result);
+        } else if (ub) launch_finish_g1_u(sr, P, E, lanes, result, te);
         else if (GT<F>::AW == 12) launch_finish_g1(sr, P, E, lanes, result);
         else launch_finish_g2(sr, P, E, lanes, result);
     }
@@ -1024,9 +1094,9 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     *out = nullptr;
     if (group != CZK_G1 && group != CZK_G2) return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
     if (n && !bases) return set_err(ctx, CZK_ERR_ARG, "null bases");
-    const bool no_tables = (mem & CZK_MEM_NO_TABLES) != 0;
-    mem &= ~CZK_MEM_NO_TABLES;
-    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (optionally | CZK_MEM_NO_TABLES)");
+    const bool no_tables = (mem & CZK_MEM_NO_TABLES) != 0, any_points = (mem & CZK_MEM_ANY_POINTS) != 0;
+    mem &= ~(CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS);
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (optionally | CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS)");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t aw = group == CZK_G1 ? 12 : 24;
     czk_bases* b = new czk_bases();
@@ -1034,6 +1104,7 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     b->group = group;
     b->n = n;
     b->split = no_tables;
+    b->te_wanted = !any_points;
     b->per_call_width = getenv("CZK_MSM_FIXED_C") == nullptr;
     b->c = no_tables ? choose_c_split(n) : choose_c(n);
     b->W = num_windows(b->c);
@@ -1070,6 +1141,7 @@ extern "C" void czk_bases_release(czk_bases* b) {
     (void)hipSetDevice(b->device);
     if (b->pts) (void)hipFree(b->pts);
     if (b->inf) (void)hipFree(b->inf);
+    if (b->pts_sw0) (void)hipFree(b->pts_sw0);
     for (int i = 0; i < b->n_extra.load(); i++) {
         if (b->extra[i].pts) (void)hipFree(b->extra[i].pts);
         if (b->extra[i].inf) (void)hipFree(b->extra[i].inf);

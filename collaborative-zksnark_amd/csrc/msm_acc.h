@@ -365,69 +365,218 @@ __global__ void k_convert_from_u(u64* pts, size_t n_coords) {
 }
 
 // ---- the bucket reduction in the unsaturated residue system (same algorithm as k_reduce_level / k_reduce_tail_* above; buckets and
-// every intermediate array in u-form, fqu.h XYZZU) --------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level_u(const u64* P_in, const u64* E_in, size_t n_in, unsigned L,
+// every intermediate array in u-form).  PT = the point type's operations: XyzzOps (fqu.h XYZZU, short Weierstrass) or TeOps (te.h TEU,
+// twisted Edwards: unified additions, no infinity flag) -----------------------------------------------------------------------------
+struct XyzzOps {
+    typedef XYZZU P;
+    static __device__ __forceinline__ P zero() { return xyzzu_zero(); }
+    static __device__ __forceinline__ P load(const u64* p) { return xyzzu_load(p); }
+    static __device__ __forceinline__ void store(u64* p, const P& a) { xyzzu_store(p, a); }
+    static __device__ __forceinline__ void add(P& a, const P& b) { xyzzu_add(a, b); }
+    static __device__ __forceinline__ void dbl(P& a) { xyzzu_double(a); }
+    static __device__ __forceinline__ Jac<Fq> to_jac(const P& a) { return xyzz_to_jac(xyzzu_to_sat(a)); }
+};
+struct TeOps {
+    typedef TEU P;
+    static __device__ __forceinline__ P zero() { return teu_identity(); }
+    static __device__ __forceinline__ P load(const u64* p) { return teu_load(p); }
+    static __device__ __forceinline__ void store(u64* p, const P& a) { teu_store(p, a); }
+    static __device__ __forceinline__ void add(P& a, const P& b) { teu_add(a, b); }
+    static __device__ __forceinline__ void dbl(P& a) { teu_double(a); }
+    static __device__ __forceinline__ Jac<Fq> to_jac(const P& a) { return teu_to_jac(a); }
+};
+template <class PT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level_p(const u64* P_in, const u64* E_in, size_t n_in, unsigned L,
                                                                                                     unsigned scale_dbl, u64* P_out, u64* E_out, size_t n_out) {
     size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_out) return;
     const size_t seg = blockIdx.y;
     const u64* P = P_in + (size_t)24 * seg * n_in;
     size_t start = m * L, end = start + L < n_in ? start + L : n_in;
-    XYZZU running = xyzzu_zero(), A = xyzzu_zero();
+    typename PT::P running = PT::zero(), A = PT::zero();
     for (size_t t = end; t-- > start;) {
-        xyzzu_add(running, xyzzu_load(P + 24 * t));
-        if (t > start) xyzzu_add(A, running);
+        PT::add(running, PT::load(P + 24 * t));
+        if (t > start) PT::add(A, running);
     }
-    for (unsigned k = 0; k < scale_dbl; k++) xyzzu_double(A);
+    for (unsigned k = 0; k < scale_dbl; k++) PT::dbl(A);
     if (E_in) {
         const u64* E = E_in + (size_t)24 * seg * n_in;
-        for (size_t t = start; t < end; t++) xyzzu_add(A, xyzzu_load(E + 24 * t));
+        for (size_t t = start; t < end; t++) PT::add(A, PT::load(E + 24 * t));
     }
-    xyzzu_store(P_out + (size_t)24 * (seg * n_out + m), running);
-    xyzzu_store(E_out + (size_t)24 * (seg * n_out + m), A);
+    PT::store(P_out + (size_t)24 * (seg * n_out + m), running);
+    PT::store(E_out + (size_t)24 * (seg * n_out + m), A);
 }
-__global__ void k_finish_u(const u64* P, const u64* E, size_t segs, u64* out) {
+template <class PT>
+__global__ void k_finish_p(const u64* P, const u64* E, size_t segs, u64* out) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= segs) return;
-    XYZZU r = xyzzu_load(P + (size_t)24 * s);
-    if (E) xyzzu_add(r, xyzzu_load(E + (size_t)24 * s));
-    jac_store<Fq>(out + (size_t)18 * s, xyzz_to_jac(xyzzu_to_sat(r)));   // the result leaves in the reference's Montgomery form
+    typename PT::P r = PT::load(P + (size_t)24 * s);
+    if (E) PT::add(r, PT::load(E + (size_t)24 * s));
+    jac_store<Fq>(out + (size_t)18 * s, PT::to_jac(r));   // the result leaves as the reference's Jacobian triple, Montgomery form
 }
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tail_sums_u(const u64* P_in, const u64* E_in, size_t n_in, u64* scratch,
+template <class PT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tail_sums_p(const u64* P_in, const u64* E_in, size_t n_in, u64* scratch,
                                                                                                         u64* sums) {
     const unsigned which = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
     const u64* src = which == 10 ? E_in : P_in;
-    XYZZU v = xyzzu_zero();
+    typename PT::P v = PT::zero();
     if (src) {
         src += (size_t)24 * seg * n_in;
         for (size_t j = tid; j < n_in; j += TAIL_THREADS)
-            if (which >= 10 || ((j >> which) & 1)) xyzzu_add(v, xyzzu_load(src + 24 * j));
+            if (which >= 10 || ((j >> which) & 1)) PT::add(v, PT::load(src + 24 * j));
     }
     u64* sc = scratch + (size_t)24 * ((size_t)(seg * TAIL_BLOCKS + which) * TAIL_THREADS);
-    xyzzu_store(sc + (size_t)24 * tid, v);
+    PT::store(sc + (size_t)24 * tid, v);
     __syncthreads();
     for (unsigned stride = TAIL_THREADS / 2; stride > 0; stride >>= 1) {
         if (tid < stride) {
-            xyzzu_add(v, xyzzu_load(sc + (size_t)24 * (tid + stride)));
-            xyzzu_store(sc + (size_t)24 * tid, v);
+            PT::add(v, PT::load(sc + (size_t)24 * (tid + stride)));
+            PT::store(sc + (size_t)24 * tid, v);
         }
         __syncthreads();
     }
-    if (tid == 0) xyzzu_store(sums + (size_t)24 * (seg * TAIL_BLOCKS + which), v);
+    if (tid == 0) PT::store(sums + (size_t)24 * (seg * TAIL_BLOCKS + which), v);
 }
-__global__ void k_reduce_tail_finish_u(const u64* sums, unsigned scale_dbl, size_t segs, u64* out) {
+template <class PT>
+__global__ void k_reduce_tail_finish_p(const u64* sums, unsigned scale_dbl, size_t segs, u64* out) {
     size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= segs) return;
     const u64* sm = sums + (size_t)24 * s * TAIL_BLOCKS;
-    XYZZU acc = xyzzu_load(sm + 24 * 9);
+    typename PT::P acc = PT::load(sm + 24 * 9);
     for (int b = 8; b >= 0; b--) {
-        xyzzu_double(acc);
-        xyzzu_add(acc, xyzzu_load(sm + 24 * b));
+        PT::dbl(acc);
+        PT::add(acc, PT::load(sm + 24 * b));
     }
-    for (unsigned k = 0; k < scale_dbl; k++) xyzzu_double(acc);
-    xyzzu_add(acc, xyzzu_load(sm + 24 * 10));
-    xyzzu_add(acc, xyzzu_load(sm + 24 * 11));   // weights are b + 1 (see k_finish)
-    jac_store<Fq>(out + (size_t)18 * s, xyzz_to_jac(xyzzu_to_sat(acc)));
+    for (unsigned k = 0; k < scale_dbl; k++) PT::dbl(acc);
+    PT::add(acc, PT::load(sm + 24 * 10));
+    PT::add(acc, PT::load(sm + 24 * 11));   // weights are b + 1 (see k_finish)
+    jac_store<Fq>(out + (size_t)18 * s, PT::to_jac(acc));
+}
+
+// ---- twisted Edwards kernels (te.h): table conversion, bucket accumulation, over-full buckets -------------------------------------
+// SW affine Montgomery points (12 u64 + infinity flag) -> (Y - X, Y + X, 2 D X Y) in u-form (18 u64).  With w = (x + 1) / s:
+//   X = f w / y,  Y = (w - 1) / (w + 1)   ->   one shared denominator y (w + 1) per point, Montgomery's trick over CH points per thread.
+// A point without an image (y = 0 or w = -1: even order, never in G1) raises *bad; infinity flags stay with the caller (such entries
+// are never referenced: their digits are dropped).  scratch: n Fq.
+__global__ __launch_bounds__(128) void k_sw_to_te_niels(const u64* aff, const uint8_t* inf, size_t n, unsigned CH, u64* scratch, u64* out, u32* bad) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t start = t * CH;
+    if (start >= n) return;
+    size_t end = start + CH < n ? start + CH : n;
+    constexpr u32 sim[12] = TE_S_INV_S, fm[12] = TE_F_S, dm[12] = TE_2D_S;
+    Fq s_inv, f, d2;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        s_inv.l[i] = sim[i];
+        f.l[i] = fm[i];
+        d2.l[i] = dm[i];
+    }
+    const Fq one = Fq::one();
+    Fq acc = one;
+    for (size_t i = start; i < end; i++) {
+        fp_store<FqParams>(scratch + 6 * i, acc);
+        if (inf[i]) continue;
+        const Fq w = fp_mul(fp_add(fp_load<FqParams>(aff + 12 * i), one), s_inv);
+        const Fq den = fp_mul(fp_load<FqParams>(aff + 12 * i + 6), fp_add(w, one));
+        if (den.is_zero()) {
+            atomicOr(bad, 1u);
+            continue;
+        }
+        acc = fp_mul(acc, den);
+    }
+    Fq inv = fp_inv(acc);
+    const Fq kt = fqu_k_to_u();
+    for (size_t i = end; i-- > start;) {
+        u64* o = out + 18 * i;
+        Fq ym = one, yp = one, k2 = Fq::zero();                       // the neutral element (0, 1) for entries that are never used
+        if (!inf[i]) {
+            const Fq y = fp_load<FqParams>(aff + 12 * i + 6);
+            const Fq w = fp_mul(fp_add(fp_load<FqParams>(aff + 12 * i), one), s_inv);
+            const Fq wp = fp_add(w, one), den = fp_mul(y, wp);
+            if (!den.is_zero()) {
+                const Fq dinv = fp_mul(inv, fp_load<FqParams>(scratch + 6 * i));
+                inv = fp_mul(inv, den);
+                const Fq X = fp_mul(fp_mul(fp_mul(f, w), wp), dinv);      // f w (w + 1) / (y (w + 1))
+                const Fq Y = fp_mul(fp_mul(fp_sub(w, one), y), dinv);     // (w - 1) y / (y (w + 1))
+                ym = fp_sub(Y, X);
+                yp = fp_add(Y, X);
+                k2 = fp_mul(d2, fp_mul(X, Y));
+            }
+        }
+        fp_store<FqParams>(o, fp_mul(ym, kt));
+        fp_store<FqParams>(o + 6, fp_mul(yp, kt));
+        fp_store<FqParams>(o + 12, fp_mul(k2, kt));
+    }
+}
+
+// bucket accumulation, one thread per bucket: unified additions, so no exception list, no dirty flags, no infinity flag
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_te(const u64* pts, const u32* sorted, const u32* offsets,
+                                                                                                   const u32* counts, const u32* perm, size_t B, size_t sorted_stride,
+                                                                                                   u64* buckets) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B) return;
+    const unsigned lane = blockIdx.y;
+    const size_t b = perm[(size_t)lane * B + t];
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
+    if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;   // the rest of an over-full bucket is folded by k_accumulate_heavy_te
+    TEU acc = teu_identity();
+    for (u32 e = 0; e < cnt; e++) {
+        const u32 code = srt[off + e];
+        FqU ym, yp, k2;
+        te_load_niels(pts + (size_t)18 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
+        teu_madd(acc, ym, yp, k2);
+    }
+    teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
+}
+// over-full buckets (see k_accumulate_heavy / k_heavy_combine above): the same work items, folded and combined with the unified law
+// (<= 128 VGPRs like k_accumulate_heavy: the normally empty launches must not wait for a drained SIMD beside the accumulate kernels)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_heavy_te(const u64* pts, const u32* sorted, const u32* offsets,
+                                                                                                         const u32* counts, size_t B, size_t sorted_stride, const u32* hdr,
+                                                                                                         const u32* items, u64* partials, u32 cap) {
+    u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 n_items = hdr[0] < cap ? hdr[0] : cap;
+    if (k >= n_items) return;
+    const u32 lane = items[3 * k], b = items[3 * k + 1], j = items[3 * k + 2];
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    const u32 first = HEAVY_CHUNK + j * HEAVY_SUB;
+    u32 off = offsets[(size_t)lane * B + b] + first, cnt = counts[(size_t)lane * B + b] - first;
+    if (cnt > HEAVY_SUB) cnt = HEAVY_SUB;
+    TEU acc = teu_identity();
+    for (u32 e = 0; e < cnt; e++) {
+        const u32 code = srt[off + e];
+        FqU ym, yp, k2;
+        te_load_niels(pts + (size_t)18 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
+        teu_madd(acc, ym, yp, k2);
+    }
+    teu_store(partials + (size_t)24 * k, acc);
+}
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_heavy_combine_te(const u32* hdr, const u32* heavy, u64* partials, size_t B,
+                                                                                                      u64* buckets, u32 cap) {
+    const u32 k = blockIdx.x, tid = threadIdx.x;
+    u32 n_heavy = hdr[1] < cap ? hdr[1] : cap;
+    if (k >= n_heavy) return;
+    const u32 lane = heavy[4 * k], b = heavy[4 * k + 1], base = heavy[4 * k + 2], extra = heavy[4 * k + 3];
+    u64* part = partials + (size_t)24 * base;
+    TEU v = teu_identity();
+    for (u32 j = tid; j < extra; j += 128) teu_add(v, teu_load(part + (size_t)24 * j));
+    __syncthreads();                                     // every partial has been read before slots 0..127 are reused
+    if (tid < extra) teu_store(part + (size_t)24 * tid, v);
+    __syncthreads();
+    const u32 live = extra < 128 ? extra : 128;
+    for (u32 stride = 64; stride > 0; stride >>= 1) {
+        if (tid < stride && tid + stride < live) {
+            teu_add(v, teu_load(part + (size_t)24 * (tid + stride)));
+            teu_store(part + (size_t)24 * tid, v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        u64* slot = buckets + (size_t)24 * ((size_t)lane * B + b);
+        TEU acc = teu_load(slot);
+        teu_add(acc, v);
+        teu_store(slot, acc);
+    }
 }
 #endif
 #ifdef CZK_FQU_G2

@@ -1,6 +1,7 @@
 // msm_acc_g1.hip -- bucket accumulation kernel instantiated for G1 (base field Fq).
 #define CZK_FQU_G1 1
 #include "fqu.h"
+#include "te.h"
 #include "msm_acc.h"
 #include "msm_aff.h"
 
@@ -107,17 +108,47 @@ void launch_reduce_tail_g1(hipStream_t st, const u64* P, const u64* E, size_t n_
     hipLaunchKernelGGL((k_reduce_tail_sums<Fq, 24, 0>), dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
     hipLaunchKernelGGL((k_reduce_tail_finish<Fq, 24, 0>), dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
 }
-// the same three steps of the bucket reduction on u-form buckets (msm_acc.h k_reduce_*_u)
+// the same three steps of the bucket reduction on u-form buckets (msm_acc.h k_reduce_*_p); te = twisted Edwards buckets (te.h)
 void launch_reduce_level_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
-                              unsigned lanes) {
-    hipLaunchKernelGGL(k_reduce_level_u, dim3((unsigned)((n_out + 127) / 128), lanes), dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
+                              unsigned lanes, int te) {
+    const dim3 grid((unsigned)((n_out + 127) / 128), lanes);
+    if (te) hipLaunchKernelGGL(k_reduce_level_p<TeOps>, grid, dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
+    else hipLaunchKernelGGL(k_reduce_level_p<XyzzOps>, grid, dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
 }
-void launch_finish_g1_u(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out) {
-    hipLaunchKernelGGL(k_finish_u, dim3((unsigned)((segs + 63) / 64)), dim3(64), 0, st, P, E, segs, out);
+void launch_finish_g1_u(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out, int te) {
+    const dim3 grid((unsigned)((segs + 63) / 64));
+    if (te) hipLaunchKernelGGL(k_finish_p<TeOps>, grid, dim3(64), 0, st, P, E, segs, out);
+    else hipLaunchKernelGGL(k_finish_p<XyzzOps>, grid, dim3(64), 0, st, P, E, segs, out);
 }
-void launch_reduce_tail_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out, unsigned lanes) {
-    hipLaunchKernelGGL(k_reduce_tail_sums_u, dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
-    hipLaunchKernelGGL(k_reduce_tail_finish_u, dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
+void launch_reduce_tail_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out, unsigned lanes,
+                             int te) {
+    if (te) {
+        hipLaunchKernelGGL(k_reduce_tail_sums_p<TeOps>, dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
+        hipLaunchKernelGGL(k_reduce_tail_finish_p<TeOps>, dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
+    } else {
+        hipLaunchKernelGGL(k_reduce_tail_sums_p<XyzzOps>, dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
+        hipLaunchKernelGGL(k_reduce_tail_finish_p<XyzzOps>, dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
+    }
+}
+// ---- twisted Edwards form (te.h) ----------------------------------------------------------------------------------------------------
+// table conversion at registration: n SW affine Montgomery points -> n x 18 u64 niels entries in u-form; *bad (device u32) is set when a
+// point has no image
+void launch_sw_to_te_niels(hipStream_t st, const u64* aff, const uint8_t* inf, size_t n, u64* scratch, u64* out, u32* bad) {
+    const unsigned CH = 32;
+    hipLaunchKernelGGL(k_sw_to_te_niels, dim3((unsigned)(((n + CH - 1) / CH + 127) / 128)), dim3(128), 0, st, aff, inf, n, CH, scratch, out, bad);
+}
+void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+                             size_t sorted_stride, u64* buckets, unsigned lanes) {
+    ProfScope ps(ctx, "msm_accumulate_g1", st);   // brackets the dominant kernel only
+    hipLaunchKernelGGL(k_accumulate_te, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B, sorted_stride,
+                       buckets);
+}
+void launch_heavy_g1_te(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride, u64* buckets,
+                        unsigned lanes, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap) {
+    (void)hipMemsetAsync(hdr, 0, 16, st);
+    hipLaunchKernelGGL(k_heavy_list<Fq>, dim3((unsigned)((B + 255) / 256), lanes), dim3(256), 0, st, counts, B, hdr, items, heavy, cap);
+    hipLaunchKernelGGL(k_accumulate_heavy_te, dim3((cap + 127) / 128), dim3(128), 0, st, pts, sorted, offsets, counts, B, sorted_stride, hdr, items, partials, cap);
+    hipLaunchKernelGGL(k_heavy_combine_te, dim3(cap / 4 + 1), dim3(128), 0, st, hdr, heavy, partials, B, buckets, cap);
 }
 // over-full buckets (see msm_acc.h): item list, per-item partial sums, combination into the buckets; all on `st`
 void launch_heavy_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,

@@ -55,7 +55,13 @@ typedef enum {
      * multiples.  Registration is then a copy (instead of ~240 point doublings per point: 65 ms per 2^20 G1 points), and
      * each MSM runs one bucket set per window plus the Horner combination of variable_base.rs:92-105 -- about 1.4x the
      * arithmetic of the table form.  For callers that use a set of bases once or a few times; czk_msm_g1 / czk_msm_g2 use it. */
-    CZK_MEM_NO_TABLES = 32
+    CZK_MEM_NO_TABLES = 32,
+    /* czk_bases_register only, OR-ed in: the bases are arbitrary points of the curve, not necessarily elements of the prime-order
+     * subgroup.  G1 handles then keep short-Weierstrass (XYZZ) bucket arithmetic with the reference's complete case analysis
+     * (short_weierstrass_jacobian.rs:570-597).  Without the flag G1 bases are taken to lie in G1 -- as every proving-key and SRS element
+     * does (the reference deserialises them with a subgroup check) -- and the bucket kernels use the curve's twisted Edwards form, whose
+     * unified 7-multiplication addition is exception-free exactly on that subgroup.  Results are the same group elements either way. */
+    CZK_MEM_ANY_POINTS = 64
 } czk_mem;
 
 /* EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (algebra/poly/src/domain/mod.rs:79,90,139,155) */

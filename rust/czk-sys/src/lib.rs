@@ -29,6 +29,7 @@ pub const CZK_MEM_HOST: c_int = 0; // czk_mem
 pub const CZK_MEM_DEVICE: c_int = 1; // czk_mem
 pub const CZK_MEM_STABLE: c_int = 16; // czk_mem
 pub const CZK_MEM_NO_TABLES: c_int = 32; // czk_mem
+pub const CZK_MEM_ANY_POINTS: c_int = 64; // czk_mem
 pub const CZK_FFT: c_int = 0; // czk_ntt_kind
 pub const CZK_IFFT: c_int = 1; // czk_ntt_kind
 pub const CZK_COSET_FFT: c_int = 2; // czk_ntt_kind
