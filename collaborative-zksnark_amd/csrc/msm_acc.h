@@ -454,7 +454,7 @@ __global__ void k_reduce_tail_finish_p(const u64* sums, unsigned scale_dbl, size
 }
 
 // ---- twisted Edwards kernels (te.h): table conversion, bucket accumulation, over-full buckets -------------------------------------
-// SW affine Montgomery points (12 u64 + infinity flag) -> (Y - X, Y + X, 2 D X Y) in u-form (18 u64).  With w = (x + 1) / s:
+// SW affine Montgomery points (12 u64 + infinity flag) -> (Y - X, Y + X, 2 D X Y) as 3 x 16 u32 limb arrays (te.h: 24 u64 per point).  With w = (x + 1) / s:
 //   X = f w / y,  Y = (w - 1) / (w + 1)   ->   one shared denominator y (w + 1) per point, Montgomery's trick over CH points per thread.
 // A point without an image (y = 0 or w = -1: even order, never in G1) raises *bad; infinity flags stay with the caller (such entries
 // are never referenced: their digits are dropped).  scratch: n Fq.
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(128) void k_sw_to_te_niels(const u64* aff, const ui
     Fq inv = fp_inv(acc);
     const Fq kt = fqu_k_to_u();
     for (size_t i = end; i-- > start;) {
-        u64* o = out + 18 * i;
+        u64* o = out + (size_t)TE_POINT_U64 * i;
         Fq ym = one, yp = one, k2 = Fq::zero();                       // the neutral element (0, 1) for entries that are never used
         if (!inf[i]) {
             const Fq y = fp_load<FqParams>(aff + 12 * i + 6);
@@ -503,16 +503,19 @@ __global__ __launch_bounds__(128) void k_sw_to_te_niels(const u64* aff, const ui
                 k2 = fp_mul(d2, fp_mul(X, Y));
             }
         }
-        fp_store<FqParams>(o, fp_mul(ym, kt));
-        fp_store<FqParams>(o + 6, fp_mul(yp, kt));
-        fp_store<FqParams>(o + 12, fp_mul(k2, kt));
+        te_store_coord(o, fqu_unpack(fp_mul(ym, kt)));
+        te_store_coord(o + 8, fqu_unpack(fp_mul(yp, kt)));
+        te_store_coord(o + 16, fqu_unpack(fp_mul(k2, kt)));
     }
 }
 
-// bucket accumulation, one thread per bucket: unified additions, so no exception list, no dirty flags, no infinity flag
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_te(const u64* pts, const u32* sorted, const u32* offsets,
-                                                                                                   const u32* counts, const u32* perm, size_t B, size_t sorted_stride,
-                                                                                                   u64* buckets) {
+// bucket accumulation, one thread per bucket: unified additions, so no exception list, no dirty flags, no infinity flag.  npos != null
+// (partitioned sort): a bucket's positive-digit entries come first, so the sign is compiled into two loops and the first entry is taken
+// over with one multiplication; npos == null (one-pass sort): the sign is selected per entry.
+template <int WAVES>   // waves per SIMD the register allocation aims at (2: up to 256 VGPRs, 3: up to 168)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_accumulate_te(const u64* pts, const u32* sorted, const u32* offsets,
+                                                                                                   const u32* counts, const u32* npos, const u32* perm, size_t B,
+                                                                                                   size_t sorted_stride, u64* buckets) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
     const unsigned lane = blockIdx.y;
@@ -521,11 +524,23 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;   // the rest of an over-full bucket is folded by k_accumulate_heavy_te
     TEU acc = teu_identity();
-    for (u32 e = 0; e < cnt; e++) {
-        const u32 code = srt[off + e];
-        FqU ym, yp, k2;
-        te_load_niels(pts + (size_t)18 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
-        teu_madd(acc, ym, yp, k2);
+    if (npos) {
+        u32 np = npos[(size_t)lane * B + b];
+        if (np > cnt) np = cnt;
+        u32 e = 0;
+        if (np) {
+            acc = teu_from_niels(pts + (size_t)TE_POINT_U64 * (srt[off] & 0x7fffffffu));
+            e = 1;
+        }
+        for (; e < np; e++) teu_madd_s<false>(acc, pts + (size_t)TE_POINT_U64 * (srt[off + e] & 0x7fffffffu));
+        for (; e < cnt; e++) teu_madd_s<true>(acc, pts + (size_t)TE_POINT_U64 * (srt[off + e] & 0x7fffffffu));
+    } else {
+        for (u32 e = 0; e < cnt; e++) {
+            const u32 code = srt[off + e];
+            FqU ym, yp, k2;
+            te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
+            teu_madd(acc, ym, yp, k2);
+        }
     }
     teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
 }
@@ -546,7 +561,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     for (u32 e = 0; e < cnt; e++) {
         const u32 code = srt[off + e];
         FqU ym, yp, k2;
-        te_load_niels(pts + (size_t)18 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
+        te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
         teu_madd(acc, ym, yp, k2);
     }
     teu_store(partials + (size_t)24 * k, acc);

@@ -21,7 +21,7 @@
 namespace czk {
 
 struct TEU {
-    FqU x, y, z, t;   // every coordinate a multiply output (< 1.01 p, normalised limbs) or a constant
+    FqU x, y, z, t;   // normalised limbs; multiply outputs (< 1.01 p) except after teu_from_niels (x < 5 p, y < 2 p, z = 2)
 };
 __device__ __forceinline__ FqU fqu_const(const u32 (&m)[14]) {
     FqU r;
@@ -61,7 +61,7 @@ __device__ __forceinline__ void teu_finish(TEU& a, const FqU& E, const FqU& F, c
 // a += (ym, yp, k2) = (Y2 - X2, Y2 + X2, 2 D X2 Y2) of an affine table point; madd-2008-hwcd-3, 7M.  ym, yp canonical (< p);
 // k2 canonical or the lazy 4 p - k2 of a negated point (limbs < 2^30).
 __device__ __forceinline__ void teu_madd(TEU& a, const FqU& ym, const FqU& yp, const FqU& k2) {
-    const FqU A = fqu_mul(fqu_sub_lazy<4>(a.y, a.x), ym);   // (Y1 - X1 + 4 p)(Y2 - X2)
+    const FqU A = fqu_mul(fqu_sub_lazy<8>(a.y, a.x), ym);   // (Y1 - X1 + 8 p)(Y2 - X2)   (X1 < 5 p after teu_from_niels)
     const FqU B = fqu_mul(fqu_add_lazy(a.y, a.x), yp);      // (Y1 + X1)(Y2 + X2)
     const FqU C = fqu_mul(a.t, k2);                         // T1 2 D T2
     FqU F, G;
@@ -75,7 +75,7 @@ __device__ __forceinline__ void teu_madd(TEU& a, const FqU& ym, const FqU& yp, c
 }
 // a += b, both extended (add-2008-hwcd-3, 8M + one multiplication by the constant 2 D)
 __device__ __forceinline__ void teu_add(TEU& a, const TEU& b) {
-    const FqU A = fqu_mul(fqu_sub_lazy<4>(a.y, a.x), fqu_sub_lazy<4>(b.y, b.x));
+    const FqU A = fqu_mul(fqu_sub_lazy<8>(a.y, a.x), fqu_sub_lazy<8>(b.y, b.x));
     const FqU B = fqu_mul(fqu_add_lazy(a.y, a.x), fqu_add_lazy(b.y, b.x));
     const FqU C = fqu_mul(fqu_mul(a.t, b.t), te_2d_u());
     const FqU Dh = fqu_mul(a.z, b.z);
@@ -126,16 +126,67 @@ __device__ __forceinline__ Jac<Fq> teu_to_jac(const TEU& a) {
     return r;
 }
 
-// one table point: 18 u64 = (Y - X, Y + X, 2 D X Y), each x R' mod p as a canonical integer; `neg` adds -P = (-X, Y)
+// One table point: 48 u32 = (Y - X, Y + X, 2 D X Y), each x R' mod p as 14 limbs of 28 bits in 16 u32 (two pad words): 192 bytes,
+// three aligned 64-byte sectors -- the limbs are loaded as they are used, no unpacking in the hot loop.
+constexpr int TE_POINT_U64 = 24;
+__device__ __forceinline__ FqU te_load_coord(const u64* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+    FqU r;
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    r.l[8] = c.x; r.l[9] = c.y; r.l[10] = c.z; r.l[11] = c.w;
+    r.l[12] = d.x; r.l[13] = d.y;
+    return r;
+}
+__device__ __forceinline__ void te_store_coord(u64* p, const FqU& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
+    q[3] = make_uint4(v.l[12], v.l[13], 0u, 0u);
+}
+// dynamic sign (the one-pass sort does not group a bucket's entries by sign): `neg` adds -P = (-X, Y)
 __device__ __forceinline__ void te_load_niels(const u64* pp, bool neg, FqU& ym, FqU& yp, FqU& k2) {
-    const FqU a = fqu_unpack(fp_load<FqParams>(pp)), b = fqu_unpack(fp_load<FqParams>(pp + 6));
-    k2 = fqu_unpack(fp_load<FqParams>(pp + 12));
+    const FqU a = te_load_coord(pp), b = te_load_coord(pp + 8);
+    k2 = te_load_coord(pp + 16);
     ym = neg ? b : a;
     yp = neg ? a : b;
     if (neg) {
 #pragma unroll
         for (int i = 0; i < 14; i++) k2.l[i] = fqu_4p(i) - k2.l[i];      // 4 p - k, lazy
     }
+}
+// a += +-P with the sign compiled in (entries grouped by sign: k_part_sort): for -P = (-X, Y) the roles of (Y - X, Y + X) and of
+// (D - C, D + C) swap -- no selects, no negation
+template <bool NEG>
+__device__ __forceinline__ void teu_madd_s(TEU& a, const u64* pp) {
+    const FqU ym = te_load_coord(pp), yp = te_load_coord(pp + 8), k2 = te_load_coord(pp + 16);
+    const FqU A = fqu_mul(fqu_sub_lazy<8>(a.y, a.x), NEG ? yp : ym);
+    const FqU B = fqu_mul(fqu_add_lazy(a.y, a.x), NEG ? ym : yp);
+    const FqU C = fqu_mul(a.t, k2);
+    FqU F, G;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        const u32 d = a.z.l[i] + a.z.l[i];
+        const u32 m = d + (fqu_4p(i) - C.l[i]), q = d + C.l[i];
+        F.l[i] = NEG ? q : m;
+        G.l[i] = NEG ? m : q;
+    }
+    teu_finish(a, fqu_sub_lazy<4>(B, A), F, G, fqu_add_lazy(B, A));
+}
+// a = P for the first (positive) entry of a bucket: (2 x : 2 y : 2 : 2 x y) from (Y - X, Y + X, 2 D X Y) with ONE multiplication
+// (by 1 / D) instead of a seven-multiplication addition to the neutral element.  x < 5 p, y < 2 p, normalised.
+__device__ __forceinline__ TEU teu_from_niels(const u64* pp) {
+    const FqU ym = te_load_coord(pp), yp = te_load_coord(pp + 8), k2 = te_load_coord(pp + 16);
+    constexpr u32 idm[14] = TE_INV_D_U;
+    TEU a;
+    a.x = fqu_normalize(fqu_sub_lazy<4>(yp, ym));
+    a.y = fqu_normalize(fqu_add_lazy(yp, ym));
+    a.z = fqu_add_lazy(fqu_one(), fqu_one());
+    a.z = fqu_normalize(a.z);
+    a.t = fqu_mul(k2, fqu_const(idm));
+    return a;
 }
 
 }  // namespace czk
