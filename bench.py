@@ -44,6 +44,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 REF_PROOFS_PER_S = 3.0 / (328.957 + 317.213 + 320.422)   # reference's published 2^20 SPDZ-2pc timings
 # csrc/fqu.h fqu_xyzz_acc_mixed: 6 multiplies (378 v_mad_u64_u32 each), 2 squarings (287), 1 fused two-product multiply (574)
 MADS_PER_MIXED_ADD = 6 * 378 + 2 * 287 + (2 * 196 + 182)
+# csrc/te.h teu_madd_s: G1 in twisted Edwards extended coordinates, 7 multiplies, no squarings
+MADS_PER_MIXED_ADD_TE = 7 * 378
 # csrc/fqu.h fq2u_xyzz_acc_mixed: 6 Fq2 products (2 x (2 x 196 + 182) each), 2 Fq2 squarings (2 Fq multiplies each), Y3 as two four-product sums
 MADS_PER_MIXED_ADD_G2 = 6 * 1148 + 2 * 756 + 2 * (4 * 196 + 182)
 # MI355X_MICROARCH.md: 256 CU x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles -> 256 x 4 x 32 x 2.4 GHz = 78.6 T lane-ops/s
@@ -700,7 +702,9 @@ def main():
     W = prover.h_query.windows()
     madds = args.steps * prover.g1_mixed_additions_per_step(W)       # G1 mixed additions in the timed region
     achieved = (alg_bytes * args.steps) / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
-    mad_gops = MADS_PER_MIXED_ADD * madds / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
+    te = prover.h_query.arith() == 2
+    mads_g1 = MADS_PER_MIXED_ADD_TE if te else MADS_PER_MIXED_ADD
+    mad_gops = mads_g1 * madds / (acc_ms / 1e3) / 1e9 if acc_ms > 0 else 0.0
     # G2: one launch per step over the b_g2 query (N + 1 points of 192 B, `lanes` scalar vectors of 32 B)
     n_g2 = prover.query_len["b_g2"]
     alg2 = n_g2 * 192 + prover.lanes * n_g2 * 32
@@ -772,12 +776,15 @@ def main():
                                    f"reference's two broadcast rounds (sh lanes, then dx_t = mac_share * value - mac) as all-gathers over {args.backend}, "
                                    "sums and the MAC check on device"),
                    "layout": args.layout, "results_sha256": digest, "window_tables": not args.no_tables},
-        "roofline": {"bound": "hbm", "kernel": "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "roofline": {"bound": "hbm", "kernel": ("k_accumulate_te (G1 bucket accumulation, twisted Edwards extended coordinates, unsaturated limbs)" if te else
+                                                "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
                      "algorithmic_bytes_per_launch": alg_bytes / launches,
                      "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md",
-                     "valu": valu_view(mad_gops, MADS_PER_MIXED_ADD, madds, acc_ms, clk1,
+                     "valu": valu_view(mad_gops, mads_g1, madds, acc_ms, clk1,
+                                       ("twisted Edwards unified mixed addition = 7M, no squarings, no exception handling (csrc/te.h); unsaturated 14x28-bit limbs: "
+                                        "7 multiplies x 378 v_mad_u64_u32 = 2646 per mixed addition") if te else
                                        "XYZZ mixed add = 8M+2S; unsaturated 14x28-bit limbs: 6 multiplies x 378 v_mad_u64_u32, 2 squarings x 287, Y3 as two products "
                                        "under one reduction (574) -> 3416 per mixed addition, no carry instructions (csrc/fqu.h)")},
         # the second kernel of the critical stream: the same view for the G2 bucket accumulation (one launch per proof)

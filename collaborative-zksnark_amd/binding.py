@@ -462,6 +462,10 @@ class Bases:
     def windows(self) -> int:
         return self.layout()[1]
 
+    def arith(self) -> int:
+        """0 = XYZZ saturated, 1 = XYZZ unsaturated, 2 = twisted Edwards (czk_bases_arith)"""
+        return int(lib().czk_bases_arith(self._h))
+
     def layout_for(self, n_scalars: int):
         """(c, windows) an MSM of n_scalars scalars over these bases runs with (czk_bases_layout_for)."""
         c, w = C.c_uint(0), C.c_uint(0)

@@ -1178,6 +1178,7 @@ extern "C" int czk_bases_layout_for(const czk_bases* b, size_t n_scalars, unsign
     if (windows) *windows = num_windows(cc);
     return CZK_OK;
 }
+extern "C" int czk_bases_arith(const czk_bases* b) { return !b ? -1 : b->te ? 2 : b->unsat ? 1 : 0; }
 extern "C" int czk_bases_prepare(czk_ctx* ctx, const czk_bases* b, size_t n_scalars) {
     if (!ctx || !b) return ctx ? set_err(ctx, CZK_ERR_ARG, "null bases") : CZK_ERR_ARG;
     CZK_HIP(ctx, hipSetDevice(ctx->device));

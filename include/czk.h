@@ -239,6 +239,9 @@ int czk_bases_layout(const czk_bases* b, unsigned* c, unsigned* windows);
  * front (e.g. at SRS load), czk_bases_layout_for reports the (c, windows) such a call runs with.  Handles registered with
  * CZK_MEM_NO_TABLES choose c per call outright. */
 int czk_bases_layout_for(const czk_bases* b, size_t n_scalars, unsigned* c, unsigned* windows);
+/* Bucket arithmetic the handle's MSMs run with (reporting only): 0 = XYZZ, saturated limbs; 1 = XYZZ, unsaturated limbs (8M + 2S per mixed
+ * addition); 2 = twisted Edwards extended coordinates, unsaturated limbs (G1 in the prime-order subgroup: 7M per mixed addition). */
+int czk_bases_arith(const czk_bases* b);
 int czk_bases_prepare(czk_ctx* ctx, const czk_bases* b, size_t n_scalars);
 
 /* Replaces VariableBaseMSM::multi_scalar_mul (algebra/ec/src/msm/variable_base.rs:12-106) / AffineCurve::

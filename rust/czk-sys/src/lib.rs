@@ -84,6 +84,7 @@ extern "C" {
     pub fn czk_bases_len(b: *const czk_bases) -> usize;
     pub fn czk_bases_layout(b: *const czk_bases, c: *mut c_uint, windows: *mut c_uint) -> c_int;
     pub fn czk_bases_layout_for(b: *const czk_bases, n_scalars: usize, c: *mut c_uint, windows: *mut c_uint) -> c_int;
+    pub fn czk_bases_arith(b: *const czk_bases) -> c_int;
     pub fn czk_bases_prepare(ctx: *mut czk_ctx, b: *const czk_bases, n_scalars: usize) -> c_int;
     pub fn czk_msm(ctx: *mut czk_ctx, bases: *const czk_bases, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *mut u64) -> c_int;
     pub fn czk_msm_async(ctx: *mut czk_ctx, bases: *const czk_bases, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *mut u64) -> c_int;
