@@ -94,7 +94,6 @@ struct czk_ctx {
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
     std::vector<czk::MsmPending> msm_pending;
     unsigned msm_affine_rounds = 0;  // CZK_MSM_AFFINE=R at pipeline creation: R rounds of batched-affine pair additions in front of the G1 bucket accumulation
-    int msm_te_waves = 2;            // CZK_TE_WAVES=3 at pipeline creation: the twisted Edwards accumulate kernel built for 3 waves per SIMD (A/B runs)
     bool msm_reduce_sat = false;     // CZK_REDUCE_SAT=1 at pipeline creation: G1 buckets and their reduction in the saturated form (A/B runs)
     bool msm_sort_onepass = false;   // CZK_SORT_ONEPASS=1 at pipeline creation: the single-pass digit sort (kept as the > 2048-partition fallback)
     unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
@@ -266,8 +265,8 @@ void launch_reduce_tail_g1_u(hipStream_t st, const u64* P, const u64* E, size_t 
                              int te);
 // G1 in twisted Edwards form (te.h): table conversion at registration, bucket accumulation, over-full buckets
 void launch_sw_to_te_niels(hipStream_t st, const u64* aff, const uint8_t* inf, size_t n, u64* scratch, u64* out, u32* bad);
-void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* npos,
-                             const u32* perm, size_t B, size_t sorted_stride, u64* buckets, unsigned lanes);
+void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+                             size_t sorted_stride, u64* buckets, unsigned lanes);
 void launch_heavy_g1_te(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride, u64* buckets,
                         unsigned lanes, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap);
 void launch_heavy_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,

@@ -375,29 +375,26 @@ __global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t 
         u32 b = (code[k] & 0x7fffffffu) - 1;
         size_t dst = (size_t)lane * total + base[b & (n_parts - 1)] + rank[k];
         part_idx[dst] = (u32)(w * n_bases + i) | (code[k] & 0x80000000u);
-        part_lb[dst] = (uint16_t)((b >> part_shift) | ((code[k] >> 31) << 15));   // bit 15: the digit's sign (k_part_sort groups a bucket's entries by it)
+        part_lb[dst] = (uint16_t)(b >> part_shift);
     }
 }
-// one workgroup per (partition, lane): bucket counts, offsets and the final placement of the partition's entries.  Inside a bucket
-// the entries with a positive digit come first, then the negative ones (npos[b] = number of positive entries): a bucket kernel can
-// then run two loops with the sign compiled in instead of selecting per entry (te.h, k_accumulate_te).
+// one workgroup per (partition, lane): bucket counts, offsets and the final placement of the partition's entries
 __global__ __launch_bounds__(256) void k_part_sort(const u32* part_idx, const uint16_t* part_lb, const u32* part_base, unsigned n_parts, unsigned part_shift,
-                                                   size_t total, size_t B, u32* sorted, u32* offsets, u32* counts, u32* npos) {
-    __shared__ u32 cnt[2 * PART_BUCKETS], cur[2 * PART_BUCKETS], red[256];
+                                                   size_t total, size_t B, u32* sorted, u32* offsets, u32* counts) {
+    __shared__ u32 cnt[PART_BUCKETS], cur[PART_BUCKETS], red[256];
     const unsigned p = blockIdx.x, lane = blockIdx.y, tid = threadIdx.x;
     const u32 r0 = part_base[(size_t)lane * (n_parts + 1) + p], r1 = part_base[(size_t)lane * (n_parts + 1) + p + 1];
-    for (unsigned t = tid; t < 2 * PART_BUCKETS; t += 256) cnt[t] = 0;
+    for (unsigned t = tid; t < PART_BUCKETS; t += 256) cnt[t] = 0;
     __syncthreads();
     const uint16_t* lb = part_lb + (size_t)lane * total;
     const u32* idx = part_idx + (size_t)lane * total;
-    // key = 2 * (bucket index inside the partition) + sign
-    for (u32 j = r0 + tid; j < r1; j += 256) atomicAdd(&cnt[2u * (lb[j] & 0x7fffu) + (lb[j] >> 15)], 1u);
+    for (u32 j = r0 + tid; j < r1; j += 256) atomicAdd(&cnt[lb[j]], 1u);
     __syncthreads();
-    // exclusive scan of cnt[0..2048): 8 consecutive entries (4 buckets) per thread
-    u32 v[8], s = 0;
+    // exclusive scan of cnt[0..1024): 4 consecutive entries per thread
+    u32 v[4], s = 0;
 #pragma unroll
-    for (unsigned k = 0; k < 8; k++) {
-        v[k] = cnt[tid * 8 + k];
+    for (unsigned k = 0; k < 4; k++) {
+        v[k] = cnt[tid * 4 + k];
         s += v[k];
     }
     red[tid] = s;
@@ -412,18 +409,16 @@ __global__ __launch_bounds__(256) void k_part_sort(const u32* part_idx, const ui
 #pragma unroll
     for (unsigned k = 0; k < 4; k++) {
         size_t b = ((size_t)(tid * 4 + k) << part_shift) | p;   // bucket = (index inside the partition, partition)
-        cur[tid * 8 + 2 * k] = run;
-        cur[tid * 8 + 2 * k + 1] = run + v[2 * k];
+        cur[tid * 4 + k] = run;
         if (b < B) {
             offsets[(size_t)lane * B + b] = run;
-            counts[(size_t)lane * B + b] = v[2 * k] + v[2 * k + 1];
-            npos[(size_t)lane * B + b] = v[2 * k];
+            counts[(size_t)lane * B + b] = v[k];
         }
-        run += v[2 * k] + v[2 * k + 1];
+        run += v[k];
     }
     __syncthreads();
     u32* out = sorted + (size_t)lane * total;
-    for (u32 j = r0 + tid; j < r1; j += 256) out[atomicAdd(&cur[2u * (lb[j] & 0x7fffu) + (lb[j] >> 15)], 1u)] = idx[j];
+    for (u32 j = r0 + tid; j < r1; j += 256) out[atomicAdd(&cur[lb[j]], 1u)] = idx[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,7 +766,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     const unsigned n_parts = (unsigned)((B + PART_BUCKETS - 1) >> PART_LOG);   // B is a power of two
     unsigned part_shift = 0;
     while ((1u << part_shift) < n_parts) part_shift++;
-    size_t need_sort = lanes * ((size_t)W * size * (4 * 3 + 2) + B * 4 * 5 + CNT_BINS * 4 + (size_t)n_parts * 12 + 64) + (1 << 16);
+    size_t need_sort = lanes * ((size_t)W * size * (4 * 3 + 2) + B * 4 * 4 + CNT_BINS * 4 + (size_t)n_parts * 12 + 64) + (1 << 16);
     const u32 heavy_cap = (u32)(lanes * (size_t)W * size / 256 + 64);   // >= number of 256-entry work items of over-full buckets (msm_acc.h HEAVY_SUB)
     size_t need_red = lanes * (B * XW * 8 + 4 * lvl0 * XW * 8 + JW * 8 + B + (size_t)12 * 513 * XW * 8) + (size_t)heavy_cap * (XW * 8 + 32) + (1 << 17);
     // batched-affine pre-reduction (G1, unsaturated tables): records, two level arrays, per-level bucket offsets / counts
@@ -825,7 +820,6 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     u32* counts = bs.take<u32>(lanes * B);
     u32* offsets = bs.take<u32>(lanes * B);
     u32* perm = bs.take<u32>(lanes * B);
-    u32* npos = bs.take<u32>(lanes * B);                    // partitioned sort: positive-digit entries per bucket (they come first)
     u32* chist = bs.take<u32>(lanes * CNT_BINS);
     const size_t n_tiles = (B + SCAN_TILE - 1) / SCAN_TILE;
     u32* tile_sums = bs.take<u32>(lanes * n_tiles);
@@ -885,7 +879,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                                    size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
             }
             hipLaunchKernelGGL(k_part_sort, dim3(n_parts, (unsigned)lanes), dim3(256), 0, ss, ranks, part_lb, part_base, n_parts, part_shift, total, B, sorted,
-                               offsets, counts, npos);
+                               offsets, counts);
         }
         CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
         hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
@@ -911,7 +905,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     if (te) {
-        launch_accumulate_g1_te(ctx, sa, tv.pts, sorted, offsets, counts, one_pass_sort ? nullptr : npos, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+        launch_accumulate_g1_te(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     } else if (b->unsat) {
         // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
         if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, tv.pts, perm, buckets, dirty);
@@ -991,7 +985,6 @@ int msm_pipeline_init(czk_ctx* ctx) {
     // (stream priorities for the short sort / reduce stages were measured: no gain, so all three are equal)
     ctx->msm_sort_onepass = getenv("CZK_SORT_ONEPASS") != nullptr;   // read once, not per enqueue
     ctx->msm_reduce_sat = getenv("CZK_REDUCE_SAT") != nullptr;
-    if (const char* e = getenv("CZK_TE_WAVES")) ctx->msm_te_waves = atoi(e) == 3 ? 3 : 2;
     if (const char* e = getenv("CZK_MSM_AFFINE")) {
         int v = atoi(e);
         if (v >= 0 && v <= 3) ctx->msm_affine_rounds = (unsigned)v;

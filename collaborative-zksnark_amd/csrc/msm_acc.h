@@ -509,13 +509,11 @@ __global__ __launch_bounds__(128) void k_sw_to_te_niels(const u64* aff, const ui
     }
 }
 
-// bucket accumulation, one thread per bucket: unified additions, so no exception list, no dirty flags, no infinity flag.  npos != null
-// (partitioned sort): a bucket's positive-digit entries come first, so the sign is compiled into two loops and the first entry is taken
-// over with one multiplication; npos == null (one-pass sort): the sign is selected per entry.
-template <int WAVES>   // waves per SIMD the register allocation aims at (2: up to 256 VGPRs, 3: up to 168)
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_accumulate_te(const u64* pts, const u32* sorted, const u32* offsets,
-                                                                                                   const u32* counts, const u32* npos, const u32* perm, size_t B,
-                                                                                                   size_t sorted_stride, u64* buckets) {
+// bucket accumulation, one thread per bucket: unified additions, so no exception list, no dirty flags, no infinity flag; the first
+// entry is taken over with one multiplication (teu_from_niels)
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_te(const u64* pts, const u32* sorted, const u32* offsets,
+                                                                                                   const u32* counts, const u32* perm, size_t B, size_t sorted_stride,
+                                                                                                   u64* buckets) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
     const unsigned lane = blockIdx.y;
@@ -524,23 +522,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WAVES, WAVE
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;   // the rest of an over-full bucket is folded by k_accumulate_heavy_te
     TEU acc = teu_identity();
-    if (npos) {
-        u32 np = npos[(size_t)lane * B + b];
-        if (np > cnt) np = cnt;
-        u32 e = 0;
-        if (np) {
-            acc = teu_from_niels(pts + (size_t)TE_POINT_U64 * (srt[off] & 0x7fffffffu));
-            e = 1;
-        }
-        for (; e < np; e++) teu_madd_s<false>(acc, pts + (size_t)TE_POINT_U64 * (srt[off + e] & 0x7fffffffu));
-        for (; e < cnt; e++) teu_madd_s<true>(acc, pts + (size_t)TE_POINT_U64 * (srt[off + e] & 0x7fffffffu));
-    } else {
-        for (u32 e = 0; e < cnt; e++) {
-            const u32 code = srt[off + e];
-            FqU ym, yp, k2;
-            te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
-            teu_madd(acc, ym, yp, k2);
-        }
+    for (u32 e = 0; e < cnt; e++) {
+        const u32 code = srt[off + e];
+        FqU ym, yp, k2;
+        te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
+        if (e == 0) acc = teu_from_niels(ym, yp, k2);
+        else teu_madd(acc, ym, yp, k2);
     }
     teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
 }

@@ -137,12 +137,12 @@ void launch_sw_to_te_niels(hipStream_t st, const u64* aff, const uint8_t* inf, s
     const unsigned CH = 32;
     hipLaunchKernelGGL(k_sw_to_te_niels, dim3((unsigned)(((n + CH - 1) / CH + 127) / 128)), dim3(128), 0, st, aff, inf, n, CH, scratch, out, bad);
 }
-void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* npos,
-                             const u32* perm, size_t B, size_t sorted_stride, u64* buckets, unsigned lanes) {
+void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
+                             size_t sorted_stride, u64* buckets, unsigned lanes) {
     ProfScope ps(ctx, "msm_accumulate_g1", st);   // brackets the dominant kernel only
-    const dim3 grid((unsigned)((B + 127) / 128), lanes);
-    if (ctx->msm_te_waves == 3) hipLaunchKernelGGL(k_accumulate_te<3>, grid, dim3(128), 0, st, pts, sorted, offsets, counts, npos, perm, B, sorted_stride, buckets);
-    else hipLaunchKernelGGL(k_accumulate_te<2>, grid, dim3(128), 0, st, pts, sorted, offsets, counts, npos, perm, B, sorted_stride, buckets);
+    // (a build for 3 waves per SIMD -- the kernel needs 155 VGPRs -- was measured: same isolated time, 88.6 against 84.0 ms per proof)
+    hipLaunchKernelGGL(k_accumulate_te, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B, sorted_stride,
+                       buckets);
 }
 void launch_heavy_g1_te(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride, u64* buckets,
                         unsigned lanes, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap) {

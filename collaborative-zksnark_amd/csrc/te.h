@@ -146,7 +146,9 @@ __device__ __forceinline__ void te_store_coord(u64* p, const FqU& v) {
     q[2] = make_uint4(v.l[8], v.l[9], v.l[10], v.l[11]);
     q[3] = make_uint4(v.l[12], v.l[13], 0u, 0u);
 }
-// dynamic sign (the one-pass sort does not group a bucket's entries by sign): `neg` adds -P = (-X, Y)
+// `neg` adds -P = (-X, Y): the roles of Y - X and Y + X swap, 2 D X Y changes sign.  (Grouping a bucket's entries by sign so that the
+// sign could be compiled into two loops was tried: the lanes of a wave then run max(#positive) + max(#negative) iterations instead of
+// max(#entries) -- 8.76 against 7.98 ms per launch.)
 __device__ __forceinline__ void te_load_niels(const u64* pp, bool neg, FqU& ym, FqU& yp, FqU& k2) {
     const FqU a = te_load_coord(pp), b = te_load_coord(pp + 8);
     k2 = te_load_coord(pp + 16);
@@ -157,34 +159,14 @@ __device__ __forceinline__ void te_load_niels(const u64* pp, bool neg, FqU& ym, 
         for (int i = 0; i < 14; i++) k2.l[i] = fqu_4p(i) - k2.l[i];      // 4 p - k, lazy
     }
 }
-// a += +-P with the sign compiled in (entries grouped by sign: k_part_sort): for -P = (-X, Y) the roles of (Y - X, Y + X) and of
-// (D - C, D + C) swap -- no selects, no negation
-template <bool NEG>
-__device__ __forceinline__ void teu_madd_s(TEU& a, const u64* pp) {
-    const FqU ym = te_load_coord(pp), yp = te_load_coord(pp + 8), k2 = te_load_coord(pp + 16);
-    const FqU A = fqu_mul(fqu_sub_lazy<8>(a.y, a.x), NEG ? yp : ym);
-    const FqU B = fqu_mul(fqu_add_lazy(a.y, a.x), NEG ? ym : yp);
-    const FqU C = fqu_mul(a.t, k2);
-    FqU F, G;
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        const u32 d = a.z.l[i] + a.z.l[i];
-        const u32 m = d + (fqu_4p(i) - C.l[i]), q = d + C.l[i];
-        F.l[i] = NEG ? q : m;
-        G.l[i] = NEG ? m : q;
-    }
-    teu_finish(a, fqu_sub_lazy<4>(B, A), F, G, fqu_add_lazy(B, A));
-}
-// a = P for the first (positive) entry of a bucket: (2 x : 2 y : 2 : 2 x y) from (Y - X, Y + X, 2 D X Y) with ONE multiplication
-// (by 1 / D) instead of a seven-multiplication addition to the neutral element.  x < 5 p, y < 2 p, normalised.
-__device__ __forceinline__ TEU teu_from_niels(const u64* pp) {
-    const FqU ym = te_load_coord(pp), yp = te_load_coord(pp + 8), k2 = te_load_coord(pp + 16);
+// a = +-P for the first entry of a bucket, from the (sign-applied) table entry of te_load_niels: (2 x : 2 y : 2 : 2 x y) with ONE
+// multiplication (by 1 / D) instead of a seven-multiplication addition to the neutral element.  x < 5 p, y < 2 p, normalised.
+__device__ __forceinline__ TEU teu_from_niels(const FqU& ym, const FqU& yp, const FqU& k2) {
     constexpr u32 idm[14] = TE_INV_D_U;
     TEU a;
     a.x = fqu_normalize(fqu_sub_lazy<4>(yp, ym));
     a.y = fqu_normalize(fqu_add_lazy(yp, ym));
-    a.z = fqu_add_lazy(fqu_one(), fqu_one());
-    a.z = fqu_normalize(a.z);
+    a.z = fqu_normalize(fqu_add_lazy(fqu_one(), fqu_one()));
     a.t = fqu_mul(k2, fqu_const(idm));
     return a;
 }
