@@ -1005,3 +1005,45 @@ def test_msm_short_calls_under_a_long_key_use_narrower_tables(ctx, czk, orc, g):
     gen = ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
     assert _same_point(ctx, orc, g, out[0], orc.scalar_mul(g, gen, False, ints_to_limbs([dot_mod_r(k, s)], 4)[0]))
     b.release()
+
+
+def test_g1_bucket_arithmetic_selection_and_any_points_flag(ctx, czk, orc):
+    """G1 handles run their buckets in twisted Edwards form (csrc/te.h: the unified 7M addition, exception-free on the prime-order
+    subgroup) unless the caller registers arbitrary curve points (CZK_MEM_ANY_POINTS) or a base has no image under the map -- then
+    the XYZZ kernels with the reference's complete case analysis (short_weierstrass_jacobian.rs:570-597) stay.  Both forms against the
+    checker's Pippenger on the same inputs, equal / opposite / infinity bases and zero / unit scalars included; G2 is always XYZZ."""
+    n = 3000
+    _, bases = _bases(ctx, 1, n, 777)
+    inf = np.zeros(n, dtype=np.uint8)
+    bases[3] = bases[2]
+    neg = bases[4].copy()
+    neg[6:] = orc.fq_neg(bases[4][6:])
+    bases[5] = neg
+    inf[7] = 1
+    sc = rand_fr_canonical(778, 2 * n).reshape(2, n, 4)
+    sc[:, 0] = 0
+    sc[:, 1] = ints_to_limbs([1], 4)[0]
+    sc[:, 2] = sc[:, 3] = ints_to_limbs([5], 4)[0]
+    sc[:, 4] = sc[:, 5] = ints_to_limbs([R_MOD - 3], 4)[0]
+    want = [orc.msm(1, bases, inf, sc[ln]) for ln in range(2)]
+    for flags, arith in ((0, 2), (czk.CZK_MEM_ANY_POINTS, 1), (czk.CZK_MEM_NO_TABLES, 2), (czk.CZK_MEM_NO_TABLES | czk.CZK_MEM_ANY_POINTS, 1)):
+        b = ctx.register_bases(1, bases, inf, mem=czk.CZK_MEM_HOST | flags)
+        assert b.arith() == arith, (flags, b.arith())
+        got = ctx.msm(b, sc, lanes=2)
+        for ln in range(2):
+            assert _same_point(ctx, orc, 1, got[ln], want[ln]), (flags, ln)
+        b.release()
+    # a base without an image under the map -- the 2-torsion point (-1, 0): on the curve, not in G1 -- sends the handle to the XYZZ path
+    odd = bases.copy()
+    minus_one = orc.fq_neg(orc.fq_from_repr(ints_to_limbs([1], 6)))[0]
+    odd[9, :6] = minus_one
+    odd[9, 6:] = 0
+    b = ctx.register_bases(1, odd, inf)
+    assert b.arith() == 1
+    got = ctx.msm(b, sc[0], lanes=1)
+    assert _same_point(ctx, orc, 1, got[0], orc.msm(1, odd, inf, sc[0]))
+    b.release()
+    _, b2 = _bases(ctx, 2, 50, 779)
+    h = ctx.register_bases(2, b2, None)
+    assert h.arith() == 1
+    h.release()
