@@ -28,7 +28,7 @@ def pick(counter, prefix):
 
 
 XCDS = 8   # GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md)
-g1_prefix = "void czk::k_accumulate_te<" if any(r["kernel"].startswith("void czk::k_accumulate_te<") for r in res.get("SQ_INSTS_VALU", []) + res.get("FETCH_SIZE", [])) else "czk::k_accumulate_u("
+g1_prefix = "czk::k_accumulate_te(" if any(r["kernel"].startswith("czk::k_accumulate_te(") for r in res.get("SQ_INSTS_VALU", []) + res.get("FETCH_SIZE", [])) else "czk::k_accumulate_u("
 summary["g1_kernel"] = g1_prefix
 for tag, key, prefix in (("g1", "k_accumulate_u", g1_prefix), ("g2", "k_accumulate_u2", "czk::k_accumulate_u2(")):
     f, w = pick("FETCH_SIZE", prefix), pick("WRITE_SIZE", prefix)
