@@ -260,7 +260,9 @@ int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_
 int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
                   int scalar_form, int mem, uint64_t* out_jac);
 
-/* One-shot forms with the reference's argument order (bases not kept on the GPU). */
+/* One-shot forms with the reference's argument order (bases not kept on the GPU).  Like every G1 handle registered without
+ * CZK_MEM_ANY_POINTS, czk_msm_g1 takes its bases to be elements of the prime-order subgroup G1 (GroupAffine values of the
+ * reference are, by construction and by deserialisation check); arbitrary curve points go through czk_bases_register with that flag. */
 int czk_msm_g1(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
                size_t lanes, int scalar_form, uint64_t* out_jac);
 int czk_msm_g2(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
