@@ -389,7 +389,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     # Independent proofs in flight on this GPU (replica layout): each prover has its own context, stream and share lanes and
     # shares only the registered SRS.  The reference's transcript forces a drain of the MSM pipeline before every challenge; a
     # second proof fills those bubbles -- the same thing the Groth16 bench does by pipelining consecutive proofs.
-    want_inflight = args.inflight if args.inflight is not None else (2 if plonk else 1)
+    want_inflight = args.inflight if args.inflight is not None else 2
     inflight = 1 if party else max(1, min(want_inflight, args.steps))
     provers = [(ctx, B, inp, torch.cuda.current_stream())]
     dev_index = torch.cuda.current_device()
@@ -583,7 +583,8 @@ def main():
                                                              "1/13 of the key memory -- what lets 8 party ranks of the 2^22 configuration share ONE GPU")
     ap.add_argument("--commit-opens", action="store_true", help="party layout: dx_t goes through atomic_broadcast (SHA-256 commit-then-open, channel.rs:50-75)")
     ap.add_argument("--inflight", type=int, default=None, help="plonk / marlin, replica layout: independent proofs in flight per GPU, each on its own context "
-                                                                 "(default: plonk 2 -- measured 203 -> 180 ms per proof --, marlin 1: one proof already saturates the GPU, 259 vs 273 ms)")
+                                                                 "(default 2: the transcript points of one proof drain the MSM pipeline, a second proof fills the bubbles -- round 3, "
+                                                                 "twisted Edwards G1 path: plonk 178 / 152 / 163 ms per proof with 1 / 2 / 3 in flight, marlin 231 / 205 with 1 / 2)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
 
