@@ -160,12 +160,16 @@ def emit():
     arr_s("TE_S_S", C["s"], "s")
     arr_s("TE_F_S", C["f"], "f")
     arr_s("TE_2D_S", 2 * C["D"] % Q, "2 D")
-    open(os.path.join(ROOT, "collaborative-zksnark_amd", "csrc", "te_constants.inc"), "w").write("\n".join(out) + "\n")
+    return "\n".join(out) + "\n"
 
+
+OUT = os.path.join(ROOT, "collaborative-zksnark_amd", "csrc", "te_constants.inc")
 
 if __name__ == "__main__":
     selfcheck()
-    emit()
+    if "--check" in sys.argv:
+        sys.exit(0 if open(OUT).read() == emit() else 1)
+    open(OUT, "w").write(emit())
     print("ok: s, f, D derived; TE law == group law of E on %d sums; wrote csrc/te_constants.inc" % 200)
     if "--print" in sys.argv:
         print(C)
