@@ -9,7 +9,7 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libczk_hip.so")
+_LIB = os.environ.get("CZK_LIB_PATH") or os.path.join(_HERE, "libczk_hip.so")   # CZK_LIB_PATH: A/B builds of the library (tools/)
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "czk.h")
 
 CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT = 0, 1, 2, 3

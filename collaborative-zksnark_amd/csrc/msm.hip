@@ -348,7 +348,10 @@ __global__ __launch_bounds__(1024) void k_part_scan(const u32* part_counts, u32*
     if (tid == 1023) base[n_parts] = part[1023];
 }
 // entries -> partition regions: part_idx[dst] = point code, part_lb[dst] = bucket index inside the partition
-constexpr unsigned PS_TILE = 16;   // entries per thread
+#ifndef CZK_PS_TILE
+#define CZK_PS_TILE 16
+#endif
+constexpr unsigned PS_TILE = CZK_PS_TILE;   // entries per thread
 __global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* part_base, u32* part_cursor,
                                                       unsigned n_parts, unsigned part_shift, u32* part_idx, uint16_t* part_lb) {
     __shared__ u32 h[MAX_PARTS], base[MAX_PARTS];

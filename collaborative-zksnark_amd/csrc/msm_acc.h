@@ -368,6 +368,7 @@ __global__ void k_convert_from_u(u64* pts, size_t n_coords) {
 // every intermediate array in u-form).  PT = the point type's operations: XyzzOps (fqu.h XYZZU, short Weierstrass) or TeOps (te.h TEU,
 // twisted Edwards: unified additions, no infinity flag) -----------------------------------------------------------------------------
 struct XyzzOps {
+    static constexpr int WAVES = 2;
     typedef XYZZU P;
     static __device__ __forceinline__ P zero() { return xyzzu_zero(); }
     static __device__ __forceinline__ P load(const u64* p) { return xyzzu_load(p); }
@@ -377,6 +378,9 @@ struct XyzzOps {
     static __device__ __forceinline__ Jac<Fq> to_jac(const P& a) { return xyzz_to_jac(xyzzu_to_sat(a)); }
 };
 struct TeOps {
+    // 3 waves per SIMD = at most 168 VGPRs: a reduction wave then fits NEXT to the two resident waves of k_accumulate_te (155 VGPRs
+    // each) instead of taking one of their slots (same-box A/B: 80.6 against 81.2 ms per proof)
+    static constexpr int WAVES = 3;
     typedef TEU P;
     static __device__ __forceinline__ P zero() { return teu_identity(); }
     static __device__ __forceinline__ P load(const u64* p) { return teu_load(p); }
@@ -386,7 +390,7 @@ struct TeOps {
     static __device__ __forceinline__ Jac<Fq> to_jac(const P& a) { return teu_to_jac(a); }
 };
 template <class PT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_level_p(const u64* P_in, const u64* E_in, size_t n_in, unsigned L,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PT::WAVES, PT::WAVES))) void k_reduce_level_p(const u64* P_in, const u64* E_in, size_t n_in, unsigned L,
                                                                                                     unsigned scale_dbl, u64* P_out, u64* E_out, size_t n_out) {
     size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_out) return;
@@ -415,7 +419,7 @@ __global__ void k_finish_p(const u64* P, const u64* E, size_t segs, u64* out) {
     jac_store<Fq>(out + (size_t)18 * s, PT::to_jac(r));   // the result leaves as the reference's Jacobian triple, Montgomery form
 }
 template <class PT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_reduce_tail_sums_p(const u64* P_in, const u64* E_in, size_t n_in, u64* scratch,
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PT::WAVES, PT::WAVES))) void k_reduce_tail_sums_p(const u64* P_in, const u64* E_in, size_t n_in, u64* scratch,
                                                                                                         u64* sums) {
     const unsigned which = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
     const u64* src = which == 10 ? E_in : P_in;
