@@ -94,7 +94,8 @@ struct czk_ctx {
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
     std::vector<czk::MsmPending> msm_pending;
     unsigned msm_affine_rounds = 0;  // CZK_MSM_AFFINE=R at pipeline creation: R rounds of batched-affine pair additions in front of the G1 bucket accumulation
-    bool msm_reduce_sat = false;     // CZK_REDUCE_SAT=1 at pipeline creation: G1 buckets and their reduction in the saturated form (A/B runs)
+    bool msm_reduce_sat = false;     // CZK_REDUCE_SAT=1 at pipeline creation: buckets and their reduction in the saturated form (A/B runs)
+    bool msm_reduce_sat_g2 = false;  // CZK_REDUCE_SAT_G2=1: the same for G2 only
     bool msm_sort_onepass = false;   // CZK_SORT_ONEPASS=1 at pipeline creation: the single-pass digit sort (kept as the > 2048-partition fallback)
     unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
     bool ntt_gen1 = false;           // CZK_NTT_GEN1=1 at context creation: first-generation NTT passes for every size (A/B runs)
@@ -251,8 +252,9 @@ void msm_pipeline_destroy(czk_ctx* ctx);
 int fixed_base_points_device(czk_ctx* ctx, int group, const u64* k_dev, size_t n, u64* out_dev);
 void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
                             unsigned lanes);
+// (G2: `ub` = buckets and level arrays in u-form, reduced on fq2pu.h's unsaturated lane pairs)
 void launch_reduce_level_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
-                            unsigned lanes);
+                            unsigned lanes, int ub);
 void launch_finish_g1(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
 // tail of the G1 bucket reduction for n_in <= 1024 entries per lane; scratch: lanes * 12 * 512 points, sums: lanes * 12 points
 void launch_heavy_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
@@ -270,12 +272,12 @@ void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const
 void launch_heavy_g1_te(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride, u64* buckets,
                         unsigned lanes, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap);
 void launch_heavy_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
-                     u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat);
+                     u64* buckets, unsigned lanes, const uint8_t* dirty, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap, int unsat, int ubuckets);
 void launch_reduce_tail_g2(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,
-                           unsigned lanes);
+                           unsigned lanes, int ub);
 void launch_reduce_tail_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned scale_dbl, u64* scratch, u64* sums, u64* out,
                            unsigned lanes);
-void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out);
+void launch_finish_g2(hipStream_t st, const u64* P, const u64* E, size_t segs, u64* out, int ub);
 // implemented in msm_acc_g1.hip / msm_acc_g2.hip (hot kernels, built with the multiply inlined)
 void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);
@@ -284,7 +286,7 @@ void launch_accumulate_g2_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, un
 void launch_accumulate_g1_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
                                   u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets);
 void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
-                                  u64* buckets, unsigned lanes, uint8_t* dirty);
+                                  u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets);
 void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets);
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords);
@@ -307,7 +309,7 @@ void launch_affine_accumulate_g1(czk_ctx* ctx, hipStream_t st, const AffArgs& a,
 void launch_accumulate_g1_u_fixup_lvl(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
                                       u64* buckets, unsigned lanes, uint8_t* dirty, const void* lvl);
 void launch_accumulate_g2_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
-                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty);
+                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets);
 void launch_accumulate_g2(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes);
 

@@ -779,7 +779,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     // G1 buckets stay in the unsaturated residue system through the reduction (k_reduce_*_u) unless the batched-affine rounds
     // (which finish on saturated level points) or CZK_REDUCE_SAT ask for the saturated form
     const int te = b->te ? 1 : 0;   // twisted Edwards tables and buckets (te.h): unified additions, no exception handling at all
-    const int ub = (te || (GT<F>::AW == 12 && b->unsat && !ctx->msm_reduce_sat && !(ctx->msm_affine_rounds > 0 && size > 0))) ? 1 : 0;
+    const int ub = (te || (b->unsat && !(GT<F>::AW == 12 ? ctx->msm_reduce_sat || (ctx->msm_affine_rounds > 0 && size > 0) : ctx->msm_reduce_sat_g2))) ? 1 : 0;
     if (GT<F>::AW == 12 && b->unsat && !te && ctx->msm_affine_rounds > 0 && size > 0) {
         aff.rounds = ctx->msm_affine_rounds;
         aff.lanes = (unsigned)lanes;
@@ -913,7 +913,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
         if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, tv.pts, perm, buckets, dirty);
         else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
-        else launch_accumulate_g2_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else launch_accumulate_g2_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
     } else {
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
         if (GT<F>::AW == 12) launch_accumulate_g1(sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
@@ -928,13 +928,13 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     else if (GT<F>::AW == 12) launch_heavy_g1(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr,
                                          heavy_items, heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0, ub);
     else launch_heavy_g2(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, b->unsat ? dirty : nullptr, heavy_hdr, heavy_items,
-                         heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0);
+                         heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0, ub);
     if (b->unsat && !te) {
         // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
         if (aff.rounds)
             launch_accumulate_g1_u_fixup_lvl(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, aff.lvl[(aff.rounds - 1) & 1]);
         else if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
-        else launch_accumulate_g2_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty);
+        else launch_accumulate_g2_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
     {
@@ -946,17 +946,17 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         bool finished = false;
         while (n_in > 1) {
             if (n_in <= 1024) {   // latency-bound from here: bit-sum tree reductions instead of more levels
-                if (ub) launch_reduce_tail_g1_u(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes, te);
-                else if (GT<F>::AW == 12) launch_reduce_tail_g1(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
-                else launch_reduce_tail_g2(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
+                if (GT<F>::AW != 12) launch_reduce_tail_g2(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes, ub);
+                else if (ub) launch_reduce_tail_g1_u(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes, te);
+                else launch_reduce_tail_g1(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
                 finished = true;
                 break;
             }
             size_t n_out = (n_in + L - 1) / L;
             u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
-            if (ub) launch_reduce_level_g1_u(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes, te);
-            else if (GT<F>::AW == 12) launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
-            else launch_reduce_level_g2(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
+            if (GT<F>::AW != 12) launch_reduce_level_g2(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes, ub);
+            else if (ub) launch_reduce_level_g1_u(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes, te);
+            else launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
             P = Po;
             E = Eo;
             n_in = n_out;
@@ -964,9 +964,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             flip ^= 1;
         }
         if (finished) {
-        } else if (ub) launch_finish_g1_u(sr, P, E, lanes, result, te);
-        else if (GT<F>::AW == 12) launch_finish_g1(sr, P, E, lanes, result);
-        else launch_finish_g2(sr, P, E, lanes, result);
+        } else if (GT<F>::AW != 12) launch_finish_g2(sr, P, E, lanes, result, ub);
+        else if (ub) launch_finish_g1_u(sr, P, E, lanes, result, te);
+        else launch_finish_g1(sr, P, E, lanes, result);
     }
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipMemcpyAsync(pinned, result, out_bytes, hipMemcpyDeviceToHost, sr));
@@ -988,6 +988,7 @@ int msm_pipeline_init(czk_ctx* ctx) {
     // (stream priorities for the short sort / reduce stages were measured: no gain, so all three are equal)
     ctx->msm_sort_onepass = getenv("CZK_SORT_ONEPASS") != nullptr;   // read once, not per enqueue
     ctx->msm_reduce_sat = getenv("CZK_REDUCE_SAT") != nullptr;
+    ctx->msm_reduce_sat_g2 = ctx->msm_reduce_sat || getenv("CZK_REDUCE_SAT_G2") != nullptr;
     if (const char* e = getenv("CZK_MSM_AFFINE")) {
         int v = atoi(e);
         if (v >= 0 && v <= 3) ctx->msm_affine_rounds = (unsigned)v;
@@ -1110,6 +1111,10 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     b->te_wanted = !any_points;
     b->per_call_width = getenv("CZK_MSM_FIXED_C") == nullptr;
     b->c = no_tables ? choose_c_split(n) : choose_c(n);
+    if (const char* e = getenv(group == CZK_G1 ? "CZK_MSM_C_G1" : "CZK_MSM_C_G2")) {   // measurement knob: the primary table set's width
+        const int v = atoi(e);
+        if (!no_tables && v >= 8 && v <= 22) b->c = (unsigned)v;
+    }
     b->W = num_windows(b->c);
     const u64* pts_dev = bases;
     const uint8_t* inf_dev = inf;

@@ -237,6 +237,85 @@ __global__ void k_reduce_tail_finish(const u64* sums, unsigned scale_dbl, size_t
     jac_store<F>(out + (size_t)(JW / 4 * 3) * s, xyzz_to_jac(acc));
 }
 
+// ------------------------------------------------------------------------------------------------
+// The bucket reduction in the unsaturated residue system: same algorithm as k_reduce_level / k_reduce_tail_* above, with the buckets and
+// every intermediate array in u-form.  PT = the point type's operations: XyzzOps (fqu.h XYZZU, short Weierstrass G1), TeOps (te.h TEU,
+// twisted Edwards G1: unified additions, no infinity flag) or Xyzz2Ops (fq2pu.h XYZZU2, G2: one point per lane PAIR, PT::SHIFT = 1).
+// PT::JW = u64 words per point, PT::JACW = u64 words of the Jacobian result.
+// ------------------------------------------------------------------------------------------------
+template <class PT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PT::WAVES, PT::WAVES))) void k_reduce_level_p(const u64* P_in, const u64* E_in, size_t n_in, unsigned L,
+                                                                                                    unsigned scale_dbl, u64* P_out, u64* E_out, size_t n_out) {
+    constexpr int JW = PT::JW;
+    size_t m = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> PT::SHIFT;
+    if (m >= n_out) return;
+    const size_t seg = blockIdx.y;
+    const u64* P = P_in + (size_t)JW * seg * n_in;
+    size_t start = m * L, end = start + L < n_in ? start + L : n_in;
+    typename PT::P running = PT::zero(), A = PT::zero();
+    for (size_t t = end; t-- > start;) {
+        PT::add(running, PT::load(P + JW * t));
+        if (t > start) PT::add(A, running);
+    }
+    for (unsigned k = 0; k < scale_dbl; k++) PT::dbl(A);
+    if (E_in) {
+        const u64* E = E_in + (size_t)JW * seg * n_in;
+        for (size_t t = start; t < end; t++) PT::add(A, PT::load(E + JW * t));
+    }
+    PT::store(P_out + (size_t)JW * (seg * n_out + m), running);
+    PT::store(E_out + (size_t)JW * (seg * n_out + m), A);
+}
+template <class PT>
+__global__ void k_finish_p(const u64* P, const u64* E, size_t segs, u64* out) {
+    constexpr int JW = PT::JW;
+    size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> PT::SHIFT;
+    if (s >= segs) return;
+    typename PT::P r = PT::load(P + (size_t)JW * s);
+    if (E) PT::add(r, PT::load(E + (size_t)JW * s));
+    PT::store_jac(out + (size_t)PT::JACW * s, r);   // the result leaves as the reference's Jacobian triple, Montgomery form
+}
+template <class PT>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PT::WAVES, PT::WAVES))) void k_reduce_tail_sums_p(const u64* P_in, const u64* E_in, size_t n_in, u64* scratch,
+                                                                                                        u64* sums) {
+    constexpr int JW = PT::JW;
+    constexpr unsigned NT = TAIL_THREADS >> PT::SHIFT;   // points in flight per block
+    const unsigned which = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x >> PT::SHIFT;
+    const u64* src = which == 10 ? E_in : P_in;
+    typename PT::P v = PT::zero();
+    if (src) {
+        src += (size_t)JW * seg * n_in;
+        for (size_t j = tid; j < n_in; j += NT)
+            if (which >= 10 || ((j >> which) & 1)) PT::add(v, PT::load(src + JW * j));
+    }
+    u64* sc = scratch + (size_t)JW * ((size_t)(seg * TAIL_BLOCKS + which) * TAIL_THREADS);
+    PT::store(sc + (size_t)JW * tid, v);
+    __syncthreads();
+    for (unsigned stride = NT / 2; stride > 0; stride >>= 1) {
+        if (tid < stride) {
+            PT::add(v, PT::load(sc + (size_t)JW * (tid + stride)));
+            PT::store(sc + (size_t)JW * tid, v);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) PT::store(sums + (size_t)JW * (seg * TAIL_BLOCKS + which), v);
+}
+template <class PT>
+__global__ void k_reduce_tail_finish_p(const u64* sums, unsigned scale_dbl, size_t segs, u64* out) {
+    constexpr int JW = PT::JW;
+    size_t s = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> PT::SHIFT;
+    if (s >= segs) return;
+    const u64* sm = sums + (size_t)JW * s * TAIL_BLOCKS;
+    typename PT::P acc = PT::load(sm + JW * 9);
+    for (int b = 8; b >= 0; b--) {
+        PT::dbl(acc);
+        PT::add(acc, PT::load(sm + JW * b));
+    }
+    for (unsigned k = 0; k < scale_dbl; k++) PT::dbl(acc);
+    PT::add(acc, PT::load(sm + JW * 10));
+    PT::add(acc, PT::load(sm + JW * 11));   // weights are b + 1 (see k_finish)
+    PT::store_jac(out + (size_t)PT::JACW * s, acc);
+}
+
 #ifdef CZK_FQU_G1
 // G1 accumulation in the unsaturated residue system (fqu.h): `pts` holds x R' mod p, y R' mod p as canonical
 // 12 x u32 integers (converted at registration).  Buckets leave in the usual saturated XYZZ Montgomery form.
@@ -364,99 +443,29 @@ __global__ void k_convert_from_u(u64* pts, size_t n_coords) {
     fp_store<FqParams>(pts + 6 * i, fp_mul(fp_load<FqParams>(pts + 6 * i), fqu_k_from_u()));
 }
 
-// ---- the bucket reduction in the unsaturated residue system (same algorithm as k_reduce_level / k_reduce_tail_* above; buckets and
-// every intermediate array in u-form).  PT = the point type's operations: XyzzOps (fqu.h XYZZU, short Weierstrass) or TeOps (te.h TEU,
-// twisted Edwards: unified additions, no infinity flag) -----------------------------------------------------------------------------
+// ---- the G1 point types of the u-form bucket reduction (k_reduce_*_p above) ----
 struct XyzzOps {
-    static constexpr int WAVES = 2;
+    static constexpr int WAVES = 2, JW = 24, JACW = 18, SHIFT = 0;
     typedef XYZZU P;
     static __device__ __forceinline__ P zero() { return xyzzu_zero(); }
     static __device__ __forceinline__ P load(const u64* p) { return xyzzu_load(p); }
     static __device__ __forceinline__ void store(u64* p, const P& a) { xyzzu_store(p, a); }
     static __device__ __forceinline__ void add(P& a, const P& b) { xyzzu_add(a, b); }
     static __device__ __forceinline__ void dbl(P& a) { xyzzu_double(a); }
-    static __device__ __forceinline__ Jac<Fq> to_jac(const P& a) { return xyzz_to_jac(xyzzu_to_sat(a)); }
+    static __device__ __forceinline__ void store_jac(u64* out, const P& a) { jac_store<Fq>(out, xyzz_to_jac(xyzzu_to_sat(a))); }
 };
 struct TeOps {
     // 3 waves per SIMD = at most 168 VGPRs: a reduction wave then fits NEXT to the two resident waves of k_accumulate_te (155 VGPRs
     // each) instead of taking one of their slots (same-box A/B: 80.6 against 81.2 ms per proof)
-    static constexpr int WAVES = 3;
+    static constexpr int WAVES = 3, JW = 24, JACW = 18, SHIFT = 0;
     typedef TEU P;
     static __device__ __forceinline__ P zero() { return teu_identity(); }
     static __device__ __forceinline__ P load(const u64* p) { return teu_load(p); }
     static __device__ __forceinline__ void store(u64* p, const P& a) { teu_store(p, a); }
     static __device__ __forceinline__ void add(P& a, const P& b) { teu_add(a, b); }
     static __device__ __forceinline__ void dbl(P& a) { teu_double(a); }
-    static __device__ __forceinline__ Jac<Fq> to_jac(const P& a) { return teu_to_jac(a); }
+    static __device__ __forceinline__ void store_jac(u64* out, const P& a) { jac_store<Fq>(out, teu_to_jac(a)); }
 };
-template <class PT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PT::WAVES, PT::WAVES))) void k_reduce_level_p(const u64* P_in, const u64* E_in, size_t n_in, unsigned L,
-                                                                                                    unsigned scale_dbl, u64* P_out, u64* E_out, size_t n_out) {
-    size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_out) return;
-    const size_t seg = blockIdx.y;
-    const u64* P = P_in + (size_t)24 * seg * n_in;
-    size_t start = m * L, end = start + L < n_in ? start + L : n_in;
-    typename PT::P running = PT::zero(), A = PT::zero();
-    for (size_t t = end; t-- > start;) {
-        PT::add(running, PT::load(P + 24 * t));
-        if (t > start) PT::add(A, running);
-    }
-    for (unsigned k = 0; k < scale_dbl; k++) PT::dbl(A);
-    if (E_in) {
-        const u64* E = E_in + (size_t)24 * seg * n_in;
-        for (size_t t = start; t < end; t++) PT::add(A, PT::load(E + 24 * t));
-    }
-    PT::store(P_out + (size_t)24 * (seg * n_out + m), running);
-    PT::store(E_out + (size_t)24 * (seg * n_out + m), A);
-}
-template <class PT>
-__global__ void k_finish_p(const u64* P, const u64* E, size_t segs, u64* out) {
-    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= segs) return;
-    typename PT::P r = PT::load(P + (size_t)24 * s);
-    if (E) PT::add(r, PT::load(E + (size_t)24 * s));
-    jac_store<Fq>(out + (size_t)18 * s, PT::to_jac(r));   // the result leaves as the reference's Jacobian triple, Montgomery form
-}
-template <class PT>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(PT::WAVES, PT::WAVES))) void k_reduce_tail_sums_p(const u64* P_in, const u64* E_in, size_t n_in, u64* scratch,
-                                                                                                        u64* sums) {
-    const unsigned which = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
-    const u64* src = which == 10 ? E_in : P_in;
-    typename PT::P v = PT::zero();
-    if (src) {
-        src += (size_t)24 * seg * n_in;
-        for (size_t j = tid; j < n_in; j += TAIL_THREADS)
-            if (which >= 10 || ((j >> which) & 1)) PT::add(v, PT::load(src + 24 * j));
-    }
-    u64* sc = scratch + (size_t)24 * ((size_t)(seg * TAIL_BLOCKS + which) * TAIL_THREADS);
-    PT::store(sc + (size_t)24 * tid, v);
-    __syncthreads();
-    for (unsigned stride = TAIL_THREADS / 2; stride > 0; stride >>= 1) {
-        if (tid < stride) {
-            PT::add(v, PT::load(sc + (size_t)24 * (tid + stride)));
-            PT::store(sc + (size_t)24 * tid, v);
-        }
-        __syncthreads();
-    }
-    if (tid == 0) PT::store(sums + (size_t)24 * (seg * TAIL_BLOCKS + which), v);
-}
-template <class PT>
-__global__ void k_reduce_tail_finish_p(const u64* sums, unsigned scale_dbl, size_t segs, u64* out) {
-    size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= segs) return;
-    const u64* sm = sums + (size_t)24 * s * TAIL_BLOCKS;
-    typename PT::P acc = PT::load(sm + 24 * 9);
-    for (int b = 8; b >= 0; b--) {
-        PT::dbl(acc);
-        PT::add(acc, PT::load(sm + 24 * b));
-    }
-    for (unsigned k = 0; k < scale_dbl; k++) PT::dbl(acc);
-    PT::add(acc, PT::load(sm + 24 * 10));
-    PT::add(acc, PT::load(sm + 24 * 11));   // weights are b + 1 (see k_finish)
-    jac_store<Fq>(out + (size_t)18 * s, PT::to_jac(acc));
-}
-
 // ---- twisted Edwards kernels (te.h): table conversion, bucket accumulation, over-full buckets -------------------------------------
 // SW affine Montgomery points (12 u64 + infinity flag) -> (Y - X, Y + X, 2 D X Y) as 3 x 16 u32 limb arrays (te.h: 24 u64 per point).  With w = (x + 1) / s:
 //   X = f w / y,  Y = (w - 1) / (w + 1)   ->   one shared denominator y (w + 1) per point, Montgomery's trick over CH points per thread.
@@ -590,6 +599,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 __device__ __forceinline__ Fq2U fq2u_load(const u64* p) {
     return Fq2U{fqu_unpack(fp_load<FqParams>(p)), fqu_unpack(fp_load<FqParams>(p + 6))};
 }
+__device__ __forceinline__ void fq2u_store(u64* p, const Fq2U& a) {
+    fp_store<FqParams>(p, fqu_pack(a.c0));
+    fp_store<FqParams>(p + 6, fqu_pack(a.c1));
+}
 __device__ __forceinline__ Fq2 fq2u_to_sat(const Fq2U& a) {
     const Fq kf = fqu_k_from_u();
     return Fq2{fp_mul(fqu_pack(a.c0), kf), fp_mul(fqu_pack(a.c1), kf)};
@@ -601,7 +614,7 @@ __device__ __forceinline__ Fq2 fq2_from_table_u(const u64* p) {   // table coord
 
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_accumulate_u2(
     const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets,
-    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap) {
+    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap, int ubuckets) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= B) return;
     const unsigned lane = blockIdx.y;
@@ -621,8 +634,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 qy.c0.l[i] = fqu_4p(i) - qy.c0.l[i];
                 qy.c1.l[i] = fqu_4p(i) - qy.c1.l[i];
             }
-            qy.c0 = fqu_normalize(qy.c0);
-            qy.c1 = fqu_normalize(qy.c1);
+            if (inf) {   // (as an accumulator's Y it must be normalised; as a multiplicand the lazy form will do: limbs < 2^30)
+                qy.c0 = fqu_normalize(qy.c0);
+                qy.c1 = fqu_normalize(qy.c1);
+            }
         }
         if (inf) {
             ax = qx;
@@ -646,6 +661,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             return;
         }
     }
+    u64* slot = buckets + (size_t)48 * ((size_t)lane * B + b);
+    if (ubuckets && !inf) {   // u-form for the reduction of fq2pu.h: the coordinates as they are (x < 85 p, y < 36 p, zz, zzz < 3 p: below 2^384)
+        fq2u_store(slot, ax);
+        fq2u_store(slot + 12, ay);
+        fq2u_store(slot + 24, azz);
+        fq2u_store(slot + 36, azzz);
+        return;
+    }
     XYZZ<Fq2> out = XYZZ<Fq2>::zero();
     if (!inf) {
         out.x = fq2u_to_sat(ax);
@@ -653,11 +676,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         out.zz = fq2u_to_sat(azz);
         out.zzz = fq2u_to_sat(azzz);
     }
-    xyzz_store<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), out);
+    xyzz_store<Fq2>(slot, out);
 }
 
 __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
-                                                          size_t sorted_stride, u64* buckets, const uint8_t* dirty) {
+                                                          size_t sorted_stride, u64* buckets, const uint8_t* dirty, int ubuckets) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const unsigned lane = blockIdx.y;
@@ -672,11 +695,11 @@ __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u2_fix(const u6
         if (code & 0x80000000u) qy = f_neg(qy);
         xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy);
     }
-    xyzz_store<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), XYZZ<Fq2>{ax, ay, azz, azzz});
+    bucket_store_sat<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), XYZZ<Fq2>{ax, ay, azz, azzz}, ubuckets);
 }
 
 __global__ void k_accumulate_u2_cleanup(const u64* pts, size_t B, u64* buckets, const uint8_t* dirty, const u32* exc_count, const u32* exc_list,
-                                        u32 exc_cap) {
+                                        u32 exc_cap, int ubuckets) {
     if (blockIdx.x != 0 || threadIdx.x != 0) return;
     u32 n = *exc_count;
     if (n > exc_cap) n = exc_cap;
@@ -684,12 +707,12 @@ __global__ void k_accumulate_u2_cleanup(const u64* pts, size_t B, u64* buckets, 
         u32 lane = exc_list[3 * k], b = exc_list[3 * k + 1], code = exc_list[3 * k + 2];
         if (dirty[(size_t)lane * B + b]) continue;
         u64* slot = buckets + (size_t)48 * ((size_t)lane * B + b);
-        XYZZ<Fq2> acc = xyzz_load<Fq2>(slot);
+        XYZZ<Fq2> acc = bucket_load_sat<Fq2>(slot, ubuckets);
         const u64* pp = pts + (size_t)24 * (code & 0x7fffffffu);
         Fq2 qx = fq2_from_table_u(pp), qy = fq2_from_table_u(pp + 12);
         if (code & 0x80000000u) qy = f_neg(qy);
         xyzz_acc_mixed(acc.x, acc.y, acc.zz, acc.zzz, qx, qy);
-        xyzz_store<Fq2>(slot, acc);
+        bucket_store_sat<Fq2>(slot, acc, ubuckets);
     }
 }
 

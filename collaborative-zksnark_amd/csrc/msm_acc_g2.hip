@@ -19,19 +19,19 @@ void launch_accumulate_g2_u_prepare(hipStream_t st, uint8_t* dirty, size_t B, un
     (void)hipMemsetAsync(dirty, 0, flags + 16, st);
 }
 void launch_accumulate_g2_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
-                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty) {
+                            size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets) {
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
     ProfScope ps(ctx, "msm_accumulate_g2", st);   // brackets the dominant kernel only
     hipLaunchKernelGGL(k_accumulate_u2, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                       sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP);
+                       sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP, ubuckets);
 }
 void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
-                                  u64* buckets, unsigned lanes, uint8_t* dirty) {
+                                  u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets) {
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
     hipLaunchKernelGGL(k_accumulate_u2_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
-                       sorted_stride, buckets, dirty);
-    hipLaunchKernelGGL(k_accumulate_u2_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G2_EXC_CAP);
+                       sorted_stride, buckets, dirty, ubuckets);
+    hipLaunchKernelGGL(k_accumulate_u2_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G2_EXC_CAP, ubuckets);
 }
 }  // namespace czk

@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box pass that regenerates the round's judged profiles (run through gpurun from the repo root):
-#   kernel-trace stats of the default bench command, three separate PMC passes (HBM traffic, instruction counts / clock), the stage
+#   kernel-trace stats of the default bench command, three separate PMC passes (HBM traffic, instruction counts / clock; per-kernel share of a proof's VALU instructions), the stage
 #   and width micro-benchmarks.  Raw databases stay under gpurun_out/; the summaries are copied to profiles/ by hand afterwards.
 #   usage: bash tools/profile_round.sh r03
 set -u
@@ -20,6 +20,7 @@ cd - > /dev/null
 DB=$(find $OUT/trace -name '*.db' | head -1)
 python tools/prof_summary.py $DB 20 > $OUT/kernel_trace_stats.txt 2>&1
 python tools/pmc_summary.py $OUT/pmc_traffic.json $(find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU -name '*.db') > $OUT/pmc_summary.log 2>&1
+python tools/valu_share.py $(find $OUT/pmc_SQ_INSTS_VALU -name '*.db' | head -1) > $OUT/valu_share.txt 2>&1
 python tools/stage_bench.py 20 4 > $OUT/stage_bench.txt 2>&1
 python tools/width_bench.py 3 > $OUT/width_bench.txt 2>&1
 ls -la $OUT | head -30
