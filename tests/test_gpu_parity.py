@@ -392,6 +392,43 @@ def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch, g, env):
     c2.close()
 
 
+@pytest.mark.parametrize("g,envs", [(1, ("CZK_MSM_NO_TE",)), (1, ("CZK_MSM_NO_TE", "CZK_REDUCE_SAT")), (2, ("CZK_REDUCE_SAT_G2",)), (2, ())])
+def test_msm_fallback_reductions_still_match(czk, orc, monkeypatch, g, envs):
+    """The bucket reduction has three forms per group: u-form buckets (G1 twisted Edwards / G1 XYZZ for CZK_MEM_ANY_POINTS handles /
+    G2 on unsaturated lane pairs, the defaults) and the saturated kernels behind CZK_REDUCE_SAT / CZK_REDUCE_SAT_G2.  n = 20000 gives
+    a bucket set of more than 1024 buckets, so the chunked level kernel runs as well as the tail kernels; lanes = 3 leaves a lane pair
+    of the G2 kernels with an idle neighbour block.  Equal and opposite bases put P + P and P - P into the reduction itself."""
+    for e in envs:
+        monkeypatch.setenv(e, "1")
+    c2 = czk.Context(0)
+    n = 20000
+    _, bases = _bases(c2, g, n, 141)
+    half = bases.shape[1] // 2
+    bases[1] = bases[0]                                   # the same point twice
+    bases[3] = bases[2]                                   # ... and a point with its inverse
+    bases[3][half:] = orc.fq_neg(bases[2][half:]) if g == 1 else np.concatenate([orc.fq_neg(bases[2][half:half + 6]), orc.fq_neg(bases[2][half + 6:])])
+    sc = rand_fr_canonical(142, 3 * n).reshape(3, n, 4)
+    sc[:, :4] = 0
+    sc[0, 0, 0], sc[0, 1, 0] = 5, 9                       # lane 0: buckets 5 and 9 of window 0 hold the same point -- the running sum doubles
+    sc[0, 2, 0], sc[0, 3, 0] = 6, 8                       #         buckets 6 and 8 hold P and -P
+    sc[1, 0, 0], sc[1, 1, 0] = 7, 7                       # lane 1: the accumulate kernel meets P + P
+    sc[2, 2, 0], sc[2, 3, 0] = 3, 3                       # lane 2: ... and P - P
+    inf = np.zeros(n, dtype=np.uint8)
+    inf[[11, 500]] = 1
+    b = c2.register_bases(g, bases, inf)
+    got = c2.msm(b, sc, lanes=3)
+    for ln in range(3):
+        assert _same_point(c2, orc, g, got[ln], orc.msm(g, bases, inf, sc[ln])), (envs, ln)
+    # the first four scalars alone (a short call: the c = 13 table set, 4096 buckets, so the level kernel runs): bucket 9 = P, 8 = -Q,
+    # 6 = Q, 5 = P and nothing else -- the level kernel's running sum meets Q - Q and P + P
+    head = np.ascontiguousarray(sc[:, :4])
+    got = c2.msm(b, head, n_scalars=4, lanes=3)
+    for ln in range(3):
+        assert _same_point(c2, orc, g, got[ln], orc.msm(g, bases[:4], inf[:4], head[ln])), (envs, "head", ln)
+    b.release()
+    c2.close()
+
+
 def test_msm_one_pass_sort_still_matches(czk, orc, monkeypatch):
     """CZK_SORT_ONEPASS=1 selects the single-pass counting sort (one global atomic + one random store per entry), the
     fallback for more than 2048 partitions; keep it covered."""
