@@ -454,10 +454,13 @@ struct XyzzOps {
     static __device__ __forceinline__ void dbl(P& a) { xyzzu_double(a); }
     static __device__ __forceinline__ void store_jac(u64* out, const P& a) { jac_store<Fq>(out, xyzz_to_jac(xyzzu_to_sat(a))); }
 };
+#ifndef CZK_TERED_WAVES
+#define CZK_TERED_WAVES 3   // (A/B builds)
+#endif
 struct TeOps {
     // 3 waves per SIMD = at most 168 VGPRs: a reduction wave then fits NEXT to the two resident waves of k_accumulate_te (155 VGPRs
     // each) instead of taking one of their slots (same-box A/B: 80.6 against 81.2 ms per proof)
-    static constexpr int WAVES = 3, JW = 24, JACW = 18, SHIFT = 0;
+    static constexpr int WAVES = CZK_TERED_WAVES, JW = 24, JACW = 18, SHIFT = 0;
     typedef TEU P;
     static __device__ __forceinline__ P zero() { return teu_identity(); }
     static __device__ __forceinline__ P load(const u64* p) { return teu_load(p); }
