@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libczk_hip.so")
 # group operations): out of line too, 14 s instead of 4.5 min of host compilation.
 SOURCES = [("core.hip", ["-DCZK_NOINLINE_MUL"]), ("lanes.hip", ["-DCZK_NOINLINE_MUL"]), ("ntt.hip", []), ("ntt_pass.hip", []), ("ntt_mixed.hip", []), ("msm.hip", ["-DCZK_NOINLINE_MUL"]), ("msm_acc_g1.hip", []),
            ("msm_acc_g2.hip", []), ("msm_red_g2.hip", []), ("msm_heavy_g2.hip", []), ("poly.hip", []), ("share.hip", [])]
-HEADERS = ["field.h", "curve.h", "czk_internal.h", "msm_acc.h", "fq2p.h", "fq2pu.h", "fqu.h", "fru.h", "fru_constants.inc", "ntt_pass.h", "fq_safegcd.h", "msm_aff.h", "te.h", "te_constants.inc", os.path.join("..", "..", "include", "czk.h")]
+HEADERS = ["field.h", "curve.h", "czk_internal.h", "msm_acc.h", "fq2p.h", "fq2pu.h", "fqu.h", "fqu_il.h", "fqu_mad_il.inc", "fru.h", "fru_constants.inc", "ntt_pass.h", "fq_safegcd.h", "msm_aff.h", "te.h", "te_constants.inc", os.path.join("..", "..", "include", "czk.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-Wno-unused-result", "-Wno-pass-failed"]

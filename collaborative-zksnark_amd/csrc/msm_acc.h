@@ -543,7 +543,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         FqU ym, yp, k2;
         te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
         if (e == 0) acc = teu_from_niels(ym, yp, k2);
+#ifdef CZK_TE_IL   // A/B builds: the products of an addition as 3 - 4 interleaved multiply-add chains (fqu_il.h: measured no faster, 206 VGPRs)
+        else teu_madd_il(acc, ym, yp, k2);
+#else
         else teu_madd(acc, ym, yp, k2);
+#endif
     }
     teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
 }
@@ -652,7 +656,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             inf = false;
             continue;
         }
+#ifdef CZK_G2_IL   // A/B builds: products grouped into four interleaved multiply-add chains (fqu_il.h: measured no faster, 369 registers)
+        if (!fq2u_xyzz_acc_mixed_il(ax, ay, azz, azzz, qx, qy)) {
+#else
         if (!fq2u_xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy)) {
+#endif
             u32 slot = atomicAdd(exc_count, 1u);
             if (slot < exc_cap) {
                 exc_list[3 * slot] = lane;

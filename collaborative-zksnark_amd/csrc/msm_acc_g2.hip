@@ -4,6 +4,7 @@
 #define CZK_FQU_G2 1
 #include "fq2p.h"
 #include "fqu.h"
+#include "fqu_il.h"
 #include "msm_acc.h"
 
 namespace czk {

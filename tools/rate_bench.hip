@@ -70,6 +70,12 @@ __global__ void k_rate(u32* out, int iters) {
             M(b0) M(b1) M(b2) M(b3) M(b4) M(b5) M(b6) M(b7)
 #undef M
             a0 = b0; a1 = b1; a2 = b2; a3 = b3; a4 = b4; a5 = b5; a6 = b6; a7 = b7;
+        } else if (MODE == 15) {   // eight chains with eight different, random-looking operand pairs: the multiplier array toggles on every issue (data-dependent power)
+            u32 x1 = x * 0x85ebca6bu + 0x1234567u, y1 = y * 0xc2b2ae35u + 0x89abcdeu, x2 = x1 * 0x27d4eb2fu + 7u, y2 = y1 * 0x165667b1u + 3u, x3 = ~x, y3 = ~y1;
+            x1 &= 0x0fffffffu; y1 &= 0x0fffffffu; x2 &= 0x0fffffffu; y2 &= 0x0fffffffu; x3 &= 0x0fffffffu; y3 &= 0x0fffffffu;
+#define M(A, X, Y) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(A) : "v"(X), "v"(Y) : "vcc");
+            M(a0, x1, y1) M(a1, x2, y2) M(a2, x3, y3) M(a3, x1, y2) M(a4, x2, y3) M(a5, x3, y1) M(a6, x1, y3) M(a7, x2, y1)
+#undef M
         } else if (MODE == 11) {   // the two-instruction form it would replace
             u32 b0 = (u32)a0, b1 = (u32)a1, b2 = (u32)a2, b3 = (u32)a3, b4 = (u32)a4, b5 = (u32)a5, b6 = (u32)a6, b7 = (u32)a7;
             const u32 cst = 0x40000000u + (u32)iters;
@@ -97,5 +103,52 @@ int main() {
     hipLaunchKernelGGL(k_rate<MODE>, dim3(blocks), dim3(threads), 0, 0, out, iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); \
     double ops = (double)blocks * threads * iters * 8; printf("%-44s %8.3f ms  %9.1f G lane-ops/s (8 per loop iteration)\n", names[MODE], ms, ops / ms / 1e6); }
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11)
+    // Sustained v_mad_u64_u32 rate: the figures above come from 0.5 ms bursts, which finish before the power management reacts.  The
+    // bucket kernels run for tens of milliseconds back to back, so this is the rate they can be priced against: 40 windows of 16
+    // launches (~10 ms each), per-window rate.
+    {
+        const int windows = 40, per = 16;
+        hipEvent_t ev[windows + 1];
+        for (int i = 0; i <= windows; i++) CK(hipEventCreate(&ev[i]));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(ev[0]));
+        for (int w = 0; w < windows; w++) {
+            for (int j = 0; j < per; j++) hipLaunchKernelGGL(k_rate<0>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+            CK(hipEventRecord(ev[w + 1]));
+        }
+        CK(hipEventSynchronize(ev[windows]));
+        printf("sustained v_mad_u64_u32 (8 independent chains per lane, %d waves per SIMD), T lane-ops/s per ~10 ms window:\n ", blocks * threads / 64 / (prop.multiProcessorCount * 4));
+        double last = 0;
+        for (int w = 0; w < windows; w++) {
+            float ms;
+            CK(hipEventElapsedTime(&ms, ev[w], ev[w + 1]));
+            last = (double)blocks * threads * iters * 8 * per / ms / 1e9;
+            printf(" %.1f", last);
+        }
+        printf("\nsustained_mad_u64_u32_T_per_s %.2f\n", last);
+    }
+    // The same sustained run with operands that look like field limbs (28 random bits, a different pair per chain) instead of one pair
+    // of registers for every multiply-add: switching activity in the multiplier is what the power management sees
+    {
+        const int windows = 24, per = 16;
+        hipEvent_t ev[windows + 1];
+        for (int i = 0; i <= windows; i++) CK(hipEventCreate(&ev[i]));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(ev[0]));
+        for (int w = 0; w < windows; w++) {
+            for (int j = 0; j < per; j++) hipLaunchKernelGGL(k_rate<15>, dim3(blocks), dim3(threads), 0, 0, out, iters);
+            CK(hipEventRecord(ev[w + 1]));
+        }
+        CK(hipEventSynchronize(ev[windows]));
+        printf("sustained v_mad_u64_u32, random 28-bit operands, a different pair per chain, T lane-ops/s per ~10 ms window:\n ");
+        for (int w = 0; w < windows; w++) {
+            float ms;
+            CK(hipEventElapsedTime(&ms, ev[w], ev[w + 1]));
+            printf(" %.1f", (double)blocks * threads * iters * 8 * per / ms / 1e9);
+        }
+        printf("\n");
+    }
+    // (Latency / occupancy questions are answered by tools/bank_bench.hip, whose blocks are single asm statements: between SEPARATE asm
+    // statements the compiler inserts an s_nop, which makes a one-accumulator loop of this file look latency-bound when it is not.)
     return 0;
 }
