@@ -49,11 +49,13 @@ MADS_PER_MIXED_ADD_TE = 7 * 378
 # csrc/fqu.h fq2u_xyzz_acc_mixed: 6 Fq2 products (2 x (2 x 196 + 182) each), 2 Fq2 squarings (2 Fq multiplies each), Y3 as two four-product sums
 MADS_PER_MIXED_ADD_G2 = 6 * 1148 + 2 * 756 + 2 * (4 * 196 + 182)
 # MI355X_MICROARCH.md: 256 CU x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles -> 256 x 4 x 32 x 2.4 GHz = 78.6 T lane-ops/s
-# for a full-rate instruction.  v_mad_u64_u32 is NOT full rate: measured 26.9 - 27.1 T lane-ops/s (tools/rate_bench.hip,
-# profiles/r02_instruction_rates.txt), i.e. ~1/3 rate (6 cycles per wave64 instruction) -- that measured figure is the peak.
+# for a full-rate instruction.  v_mad_u64_u32 is NOT full rate: a register-only loop sustains 33.5 - 35.5 T lane-ops/s at a measured
+# 2.42 GHz (tools/bank_bench.hip: 128 multiply-adds per asm statement, one dependent chain per lane or eight, any VGPR banks;
+# profiles/r03_interleave.txt), i.e. 4.5 cycles per wave64 instruction -- that figure is the peak.  (Rounds 1 - 2 priced against 27.1 T from
+# tools/rate_bench.hip, whose one-statement-per-instruction loops carry an s_nop per multiply-add; the better measurement lowers `frac`.)
 VALU_FULL_RATE_GOPS = 256 * 4 * 32 * 2.4
-MAD_PEAK_MEASURED_GOPS = 27100.0
-NOMINAL_CLOCK_GHZ = 2.4
+MAD_PEAK_MEASURED_GOPS = 35000.0
+NOMINAL_CLOCK_GHZ = 2.42
 
 
 def _free_port():
@@ -734,8 +736,9 @@ def main():
         v = {"mixed_adds_per_s": adds / (ms / 1e3) if ms > 0 else 0.0, "mad_u64_u32_per_mixed_add": per_add, "mad_u64_u32_gops": gops,
              "mad_u64_u32_peak_gops": MAD_PEAK_MEASURED_GOPS, "frac": gops / MAD_PEAK_MEASURED_GOPS,
              "full_rate_valu_peak_gops": VALU_FULL_RATE_GOPS,
-             "peak_note": "MI355X_MICROARCH.md: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s for a full-rate VALU instruction; v_mad_u64_u32 issues at ~1/3 of "
-                          "that -- 26.9 - 27.1 T measured (tools/rate_bench.hip), which is the peak this kernel is priced against",
+             "peak_note": "MI355X_MICROARCH.md: 256 CU x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-ops/s for a full-rate VALU instruction; v_mad_u64_u32 sustains 33.5 - 35.5 T "
+                          "in a register-only loop at a measured 2.42 GHz (tools/bank_bench.hip, profiles/r03_interleave.txt): the peak this kernel is priced against. "
+                          "Under this kernel the clock drops to effective_clock_ghz (power management): frac_clock_adjusted prices it at that clock",
              "effective_clock_ghz": clk, "nominal_clock_ghz": NOMINAL_CLOCK_GHZ,
              "frac_clock_adjusted": (gops / (MAD_PEAK_MEASURED_GOPS * clk / NOMINAL_CLOCK_GHZ)) if clk else None,
              "comment": comment}
