@@ -997,9 +997,18 @@ int msm_pipeline_init(czk_ctx* ctx) {
         int v = atoi(e);
         if (v >= 1 && v <= czk_ctx::MSM_SLOTS) ctx->msm_slots_in_use = v;
     }
-    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_sort, hipStreamNonBlocking));
-    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_acc, hipStreamNonBlocking));
-    CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_red, hipStreamNonBlocking));
+    if (const char* e = getenv("CZK_STREAM_PRIO")) {   // measurement knob: 1 = sort / reduce streams above the accumulate stream, 2 = the reverse
+        int least = 0, greatest = 0;
+        CZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const bool rev = atoi(e) == 2;
+        CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_sort, hipStreamNonBlocking, rev ? least : greatest));
+        CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_acc, hipStreamNonBlocking, rev ? greatest : least));
+        CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_red, hipStreamNonBlocking, rev ? least : greatest));
+    } else {
+        CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_sort, hipStreamNonBlocking));
+        CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_acc, hipStreamNonBlocking));
+        CZK_HIP(ctx, hipStreamCreateWithFlags(&ctx->s_red, hipStreamNonBlocking));
+    }
     CZK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
     for (auto& s : ctx->msm_slots) {
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_sorted, hipEventDisableTiming));

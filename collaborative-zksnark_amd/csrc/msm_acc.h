@@ -619,7 +619,10 @@ __device__ __forceinline__ Fq2 fq2_from_table_u(const u64* p) {   // table coord
     return Fq2{fp_mul(fp_load<FqParams>(p), kf), fp_mul(fp_load<FqParams>(p + 6), kf)};
 }
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_accumulate_u2(
+#ifndef CZK_G2ACC_WAVES
+#define CZK_G2ACC_WAVES 1   // (A/B builds)
+#endif
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CZK_G2ACC_WAVES, CZK_G2ACC_WAVES))) void k_accumulate_u2(
     const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets,
     uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap, int ubuckets) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
