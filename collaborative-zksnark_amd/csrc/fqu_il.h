@@ -8,8 +8,8 @@
 // k_accumulate_te has 2 646 multiply-adds, no two consecutive ones on the same accumulator).
 // Result (profiles/r03_interleave.txt): isolated 2^20 x 4-lane accumulation 7.839 ms interleaved against 7.836 ms serial (G1), 29.09 against
 // 29.30 ms (G2) -- nothing.  Dependent v_mad_u64_u32 issue back to back at full rate on this part (tools/bank_bench.hip: 30.9 T/s at two waves
-// per SIMD with ONE chain per lane as with eight; no VGPR-bank effect either), so a serial column costs nothing; and both bucket kernels deliver
-// the same ~19 T multiply-adds/s at different clocks (1.85 / 2.25 GHz), i.e. they sit on the board's power limit, which no reordering moves.
+// per SIMD with ONE chain per lane as with eight; no VGPR-bank effect either), so a serial column costs nothing: there was no latency to hide (the G1 kernel is
+// limited by the clock the power management allows, 1.84 GHz; the G2 kernel by its single wave per SIMD -- DESIGN.md section 5).
 // In the pipeline the interleaved kernels are SLOWER (83.1 against 77.2 ms per proof): 206 instead of 155 registers per wave (G1), 369
 // instead of 304 (G2) leave no room for the NTT / sort / reduction waves that used to run beside the accumulate waves.
 #pragma once
