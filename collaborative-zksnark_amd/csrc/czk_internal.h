@@ -96,6 +96,7 @@ struct czk_ctx {
     unsigned msm_affine_rounds = 0;  // CZK_MSM_AFFINE=R at pipeline creation: R rounds of batched-affine pair additions in front of the G1 bucket accumulation
     bool msm_reduce_sat = false;     // CZK_REDUCE_SAT=1 at pipeline creation: buckets and their reduction in the saturated form (A/B runs)
     bool msm_reduce_sat_g2 = false;  // CZK_REDUCE_SAT_G2=1: the same for G2 only
+    int msm_g2_mode = 0;             // CZK_G2_MODE: 0 = single-lane G2 accumulate kernel (k_accumulate_u2, adopted), 1 = lane pairs <128, 2> (faster alone, slower in the pipeline), 2 = lane pairs <512, 3> + LDS-limited occupancy
     bool msm_sort_onepass = false;   // CZK_SORT_ONEPASS=1 at pipeline creation: the single-pass digit sort (kept as the > 2048-partition fallback)
     unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
     bool ntt_gen1 = false;           // CZK_NTT_GEN1=1 at context creation: first-generation NTT passes for every size (A/B runs)

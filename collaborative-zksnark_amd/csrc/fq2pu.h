@@ -199,4 +199,43 @@ __device__ __forceinline__ void xyzzu2_double(XYZZU2& a) {
     a.y = y3;
 }
 
+
+// acc += (+-)P, P an affine table point (madd-2008-s over Fq2, 8 products per lane + the fused Y3): the bucket ACCUMULATION on lane pairs
+// (k_accumulate_u2p, CZK_G2_MODE=1 / 2).  One lane's footprint is 204 registers against the single-lane kernel's 304 (fqu.h fq2u_xyzz_acc_mixed, one
+// wave per SIMD), so two waves share a SIMD.  MEASURED: alone 23.9 against 29.3 ms per 2^20-point 4-lane launch, 25.3 - 25.9 against 33.1 - 33.9 ms
+// inside the Groth16 pipeline -- and the PROOF gets slower (78.7 - 81.3 against 76.2 - 77.6 ms, any MSM order): two such waves leave no room for
+// the NTT / sort / reduction waves that run beside the single-lane kernel's one wave, the accumulate stream then waits for them, and the machine's
+// instruction throughput was already used either way (profiles/r03_g2_lane_pairs.txt).  Not adopted; the default stays k_accumulate_u2.
+// Bounds (units of p): ax < 9.2 after an addition (a first point's < 1), ay < 4, azz, azzz < 3.2; qx canonical; qy canonical or the lazy
+// 4 p - y of a negated point.  H = U2 - X1 + 16 p: each half in (6.8, 17.2); it is 0 mod p only if it equals j p, j in 7..17, i.e. its low limb
+// is j -- returns false when both halves look like that (the caller defers the point to the saturated complete formulas).
+__device__ __forceinline__ bool xyzzu2_acc_mixed(FqU& ax, FqU& ay, FqU& azz, FqU& azzz, const FqU& qx, const FqU& qy) {
+    const FqU u2 = p2_mul(p2_a(qx), p2_b<false>(azz));
+    const FqU pp = fqu_normalize(fqu_sub_lazy<16>(u2, ax));
+    if (pair_all((pp.l[0] - 6u) <= 12u)) return false;
+    const FqU s2 = p2_mul(p2_a(qy), p2_b<false>(azzz));
+    const FqU r = fqu_normalize(fqu_sub_lazy<8>(s2, ay));                 // (4, 9.2)
+    const P2A ppa = p2_a(pp);
+    const FqU p2 = p2_mul(ppa, p2_b<true>(pp));
+    const P2B p2b = p2_b<false>(p2);
+    const FqU zz3 = p2_mul(p2_a(azz), p2b);
+    const FqU p3 = p2_mul(ppa, p2b);
+    const FqU qv = p2_mul(p2_a(ax), p2b);
+    const P2B p3b = p2_b<false>(p3);
+    const FqU zzz3 = p2_mul(p2_a(azzz), p3b);
+    const P2A ra = p2_a(r);
+    const FqU t = p2_mul(ra, p2_b<true>(r));
+    const FqU x3 = fqu_sub3_norm(t, p3, qv);                              // R^2 - PPP - 2 Q + 8 p  < 9.2 p
+    const P2B db = p2_b<true>(fqu_normalize(fqu_sub_lazy<16>(qv, x3)));   // Q - X3 + 16 p  < 17.2 p
+    FqU nay;                                                              // 8 p - Y1 (lazy)
+#pragma unroll
+    for (int i = 0; i < 14; i++) nay.l[i] = fqu_8p(i) - ay.l[i];
+    const P2A na = p2_a(nay);
+    ay = fqu_mul_add4(ra.own, db.x, ra.oth, db.y, na.own, p3b.x, na.oth, p3b.y);   // R (Q - X3) - Y1 PPP, one reduction
+    ax = x3;
+    azz = zz3;
+    azzz = zzz3;
+    return true;
+}
+
 }  // namespace czk

@@ -989,6 +989,7 @@ int msm_pipeline_init(czk_ctx* ctx) {
     ctx->msm_sort_onepass = getenv("CZK_SORT_ONEPASS") != nullptr;   // read once, not per enqueue
     ctx->msm_reduce_sat = getenv("CZK_REDUCE_SAT") != nullptr;
     ctx->msm_reduce_sat_g2 = ctx->msm_reduce_sat || getenv("CZK_REDUCE_SAT_G2") != nullptr;
+    if (const char* e = getenv("CZK_G2_MODE")) ctx->msm_g2_mode = atoi(e);
     if (const char* e = getenv("CZK_MSM_AFFINE")) {
         int v = atoi(e);
         if (v >= 0 && v <= 3) ctx->msm_affine_rounds = (unsigned)v;

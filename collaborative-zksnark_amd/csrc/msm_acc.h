@@ -693,6 +693,77 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CZK_G2ACC_W
     xyzz_store<Fq2>(slot, out);
 }
 
+#ifdef CZK_FQ2PU
+// The same accumulation with one bucket per lane PAIR (fq2pu.h): even lanes hold the c0 halves, odd lanes the c1 halves; two waves per SIMD.
+// Buckets leave in u-form (the reduction of fq2pu.h); exceptional additions go to the same deferred list / dirty flags as above.
+// BLOCK / WAVES: <128, 2> lets the kernel take what two waves per SIMD allow (204 registers); <512, 3> caps it at 168 registers and is
+// launched with 82 KiB of (unused) dynamic LDS, so that exactly ONE workgroup -- two waves per SIMD, 336 registers -- fits a CU and a wave of
+// the NTT / sort / reduction kernels (<= 168 registers, <= 78 KiB of LDS) still fits beside it.
+template <int BLOCK, int WAVES>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_accumulate_u2p(
+    const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets,
+    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap) {
+    size_t t = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;
+    if (t >= B) return;
+    const unsigned lane = blockIdx.y;
+    const bool par = pair_parity();
+    const size_t b = perm[(size_t)lane * B + t];
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
+    FqU ax, ay, azz, azzz;
+    bool inf = true;
+    if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;   // the rest of an over-full bucket is folded by k_accumulate_heavy
+    for (u32 e = 0; e < cnt; e++) {
+        const u32 code = srt[off + e];
+        const u64* pp = pts + (size_t)24 * (code & 0x7fffffffu) + (par ? 6 : 0);
+        FqU qx = fqu_unpack(fp_load<FqParams>(pp)), qy = fqu_unpack(fp_load<FqParams>(pp + 12));
+        if (code & 0x80000000u) {
+#pragma unroll
+            for (int i = 0; i < 14; i++) qy.l[i] = fqu_4p(i) - qy.l[i];
+            if (inf) qy = fqu_normalize(qy);
+        }
+        if (inf) {
+            ax = qx;
+            ay = qy;
+            azz = fqu_one();
+#pragma unroll
+            for (int i = 0; i < 14; i++) azz.l[i] = par ? 0u : azz.l[i];
+            azzz = azz;
+            inf = false;
+            continue;
+        }
+        if (!xyzzu2_acc_mixed(ax, ay, azz, azzz, qx, qy)) {
+            u32 slot = par ? 0u : atomicAdd(exc_count, 1u);
+            const u32 other = pair_swap_u32(slot);
+            if (par) slot = other;
+            if (slot < exc_cap) {
+                if (!par) {
+                    exc_list[3 * slot] = lane;
+                    exc_list[3 * slot + 1] = (u32)b;
+                    exc_list[3 * slot + 2] = code;
+                }
+                continue;
+            }
+            if (!par) dirty[(size_t)lane * B + b] = 1;
+            return;
+        }
+    }
+    u64* slot = buckets + (size_t)48 * ((size_t)lane * B + b) + (par ? 6 : 0);
+    if (inf) {
+        const Fq z = Fq::zero();
+        fp_store<FqParams>(slot, z);
+        fp_store<FqParams>(slot + 12, z);
+        fp_store<FqParams>(slot + 24, z);
+        fp_store<FqParams>(slot + 36, z);
+        return;
+    }
+    fp_store<FqParams>(slot, fqu_pack(ax));
+    fp_store<FqParams>(slot + 12, fqu_pack(ay));
+    fp_store<FqParams>(slot + 24, fqu_pack(azz));
+    fp_store<FqParams>(slot + 36, fqu_pack(azzz));
+}
+#endif
+
 __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                           size_t sorted_stride, u64* buckets, const uint8_t* dirty, int ubuckets) {
     size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -3,8 +3,10 @@
 
 #define CZK_FQU_G2 1
 #include "fq2p.h"
+#define CZK_FQ2PU 1
 #include "fqu.h"
 #include "fqu_il.h"
+#include "fq2pu.h"
 #include "msm_acc.h"
 
 namespace czk {
@@ -24,8 +26,15 @@ void launch_accumulate_g2_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const 
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
     ProfScope ps(ctx, "msm_accumulate_g2", st);   // brackets the dominant kernel only
-    hipLaunchKernelGGL(k_accumulate_u2, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                       sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP, ubuckets);
+    if (ubuckets && ctx->msm_g2_mode == 1)
+        hipLaunchKernelGGL((k_accumulate_u2p<128, 2>), dim3((unsigned)((2 * B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B, sorted_stride,
+                           buckets, dirty, exc, exc + 4, G2_EXC_CAP);
+    else if (ubuckets && ctx->msm_g2_mode == 2)
+        hipLaunchKernelGGL((k_accumulate_u2p<512, 3>), dim3((unsigned)((2 * B + 511) / 512), lanes), dim3(512), 82 * 1024, st, pts, sorted, offsets, counts, perm, B,
+                           sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP);
+    else
+        hipLaunchKernelGGL(k_accumulate_u2, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
+                           sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP, ubuckets);
 }
 void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
                                   u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets) {
