@@ -392,14 +392,16 @@ def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch, g, env):
     c2.close()
 
 
-@pytest.mark.parametrize("g,envs", [(1, ("CZK_MSM_NO_TE",)), (1, ("CZK_MSM_NO_TE", "CZK_REDUCE_SAT")), (2, ("CZK_REDUCE_SAT_G2",)), (2, ())])
+@pytest.mark.parametrize("g,envs", [(1, ("CZK_MSM_NO_TE",)), (1, ("CZK_MSM_NO_TE", "CZK_REDUCE_SAT")), (2, ("CZK_REDUCE_SAT_G2",)), (2, ()),
+                                    (2, ("CZK_G2_MODE=1",)), (2, ("CZK_G2_MODE=2",))])
 def test_msm_fallback_reductions_still_match(czk, orc, monkeypatch, g, envs):
     """The bucket reduction has three forms per group: u-form buckets (G1 twisted Edwards / G1 XYZZ for CZK_MEM_ANY_POINTS handles /
-    G2 on unsaturated lane pairs, the defaults) and the saturated kernels behind CZK_REDUCE_SAT / CZK_REDUCE_SAT_G2.  n = 20000 gives
+    G2 on unsaturated lane pairs, the defaults) and the saturated kernels behind CZK_REDUCE_SAT / CZK_REDUCE_SAT_G2; CZK_G2_MODE=1 / 2
+    select the lane-pair G2 ACCUMULATE kernels (opt-in: faster alone, slower per proof).  n = 20000 gives
     a bucket set of more than 1024 buckets, so the chunked level kernel runs as well as the tail kernels; lanes = 3 leaves a lane pair
     of the G2 kernels with an idle neighbour block.  Equal and opposite bases put P + P and P - P into the reduction itself."""
     for e in envs:
-        monkeypatch.setenv(e, "1")
+        monkeypatch.setenv(*(e.split("=") if "=" in e else (e, "1")))
     c2 = czk.Context(0)
     n = 20000
     _, bases = _bases(c2, g, n, 141)
