@@ -541,7 +541,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (u32 e = 0; e < cnt; e++) {
         const u32 code = srt[off + e];
         FqU ym, yp, k2;
+#ifdef CZK_TE_IDX_MASK   // TIMING EXPERIMENT ONLY (wrong results): confine the gathers to a cache-resident part of the table
+        te_load_niels(pts + (size_t)TE_POINT_U64 * (code & CZK_TE_IDX_MASK), (code & 0x80000000u) != 0, ym, yp, k2);
+#else
         te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
+#endif
         if (e == 0) acc = teu_from_niels(ym, yp, k2);
 #ifdef CZK_TE_IL   // A/B builds: the products of an addition as 3 - 4 interleaved multiply-add chains (fqu_il.h: measured no faster, 206 VGPRs)
         else teu_madd_il(acc, ym, yp, k2);
