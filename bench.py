@@ -56,6 +56,79 @@ MADS_PER_MIXED_ADD_G2 = 6 * 1148 + 2 * 756 + 2 * (4 * 196 + 182)
 VALU_FULL_RATE_GOPS = 256 * 4 * 32 * 2.4
 MAD_PEAK_MEASURED_GOPS = 35000.0
 NOMINAL_CLOCK_GHZ = 2.42
+STREAM_ELAPSED_NOTE = ("HIP-event brackets on the library's internal streams, summed per stage: NOT a breakdown of the step -- the sort / accumulate / reduce / NTT "
+                       "streams overlap, so the entries add up to more than ms_per_step.  Only msm_accumulate_g1 / _g2 bracket single kernels on a stream of their own; "
+                       "accumulate_busy_ms_per_step is the union of those two")
+
+
+def busy_union_ms(ctxs, names) -> float:
+    """Time during which at least one kernel bracket named in `names` was running, over all contexts in `ctxs` (their profile
+    origins merged onto the first context's clock): the union of the HIP-event intervals, NOT the sum of elapsed times."""
+    iv = []
+    for c in ctxs:
+        off = 0.0 if c is ctxs[0] else ctxs[0].profile_base_offset(c)
+        for name in names:
+            a = c.profile_intervals(name)
+            if len(a):
+                iv.append(a + off)
+    if not iv:
+        return 0.0
+    a = np.concatenate(iv)
+    a = a[np.argsort(a[:, 0])]
+    busy, cur0, cur1 = 0.0, a[0, 0], a[0, 1]
+    for s0, s1 in a[1:]:
+        if s0 > cur1:
+            busy += cur1 - cur0
+            cur0, cur1 = s0, s1
+        else:
+            cur1 = max(cur1, s1)
+    return float(busy + cur1 - cur0)
+
+
+def csrc_changed_since(commit: str):
+    """Does `git diff <commit>..HEAD -- csrc` touch the kernels?  (None when git or the commit is unavailable, e.g. on the GPU box.)"""
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "diff", "--stat", f"{commit}..HEAD", "--", "collaborative-zksnark_amd/csrc"], capture_output=True, text=True, timeout=20)
+        if r.returncode != 0:
+            return None
+        return [ln.split("|")[0].strip().split("/")[-1] for ln in r.stdout.splitlines() if "|" in ln]
+    except Exception:      # noqa: BLE001
+        return None
+
+
+OTHER_WORKLOADS = (   # (key, bench.py arguments, HBM the run needs in GB) -- BASELINE configs[2], [3] and the configs[4] size on ONE GPU
+    ("plonk_gsz3_2e18", ["--workload", "plonk", "--parties", "3", "--log-n", "18", "--steps", "6", "--warmup", "2"], 20),
+    ("marlin_spdz2_2e20", ["--workload", "marlin", "--parties", "2", "--log-n", "20", "--steps", "6", "--warmup", "2"], 40),
+    ("groth16_spdz2_2e22", ["--workload", "groth16", "--parties", "2", "--log-n", "22", "--steps", "4", "--warmup", "2", "--no-seam-report"], 70),
+)
+
+
+def other_workloads_report(device: int) -> dict:
+    """The other BASELINE configs' workloads on this GPU, each as its own short `bench.py` process (own context, own key): what the
+    driver's default run would otherwise never see.  Never `value`."""
+    import torch
+    out = {}
+    for key, argv, need_gb in OTHER_WORKLOADS:
+        free_gb = torch.cuda.mem_get_info(device)[0] / 2**30
+        if free_gb < need_gb:
+            out[key] = {"skipped": f"{free_gb:.0f} GB of HBM free, {need_gb} GB needed"}
+            continue
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--device", str(device), "--no-cpu-baseline", "--no-other-workloads"] + argv,
+                               capture_output=True, text=True, timeout=600, env={**os.environ, "CZK_BENCH_CHILD": "1"})
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[key] = {"error": (r.stdout + r.stderr)[-400:]}
+                continue
+            j = json.loads(line[-1])
+            out[key] = {"proofs_per_s": j["value"], "ms_per_proof": j["ms_per_step"], "results_checked": bool(j.get("results_checked")),
+                        "accumulate_busy_frac": j.get("accumulate_busy_frac"), "steps": j["steps"], "metric": j["metric"],
+                        "proofs_in_flight": j["config"].get("proofs_in_flight", "pipelined"), "wall_s": time.time() - t0,
+                        "command": "python bench.py " + " ".join(argv)}
+        except Exception as e:      # noqa: BLE001 -- the report must not take the headline down with it
+            out[key] = {"error": repr(e)[-400:]}
+    return out
 
 
 def _free_port():
@@ -472,6 +545,8 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     reads = {k: [c.profile_read(k) for c, _, _, _ in provers] for k in ("ntt_pass", "ntt_mixed", "msm_sort", "msm_accumulate_g1", "msm_reduce")}
     acc_ms, acc_n = sum(r[0] for r in reads["msm_accumulate_g1"]), sum(r[1] for r in reads["msm_accumulate_g1"])
     breakdown = {k: sum(r[0] for r in v) / max(1, args.steps) for k, v in reads.items()}
+    busy_ms = busy_union_ms([c for c, _, _, _ in provers], ("msm_accumulate_g1", "msm_accumulate_g2"))
+    te = B.bases.arith() == 2
     msm_points, msm_count, ntt_count = (sum(getattr(b, a) for _, b, _, _ in provers) for a in ("msm_points", "msm_count", "ntt_count"))
     pts = msm_points / max(1, args.steps)                         # (point, lane) pairs per proof
     alg_bytes = pts * 32 + (msm_points / max(1, msm_count) * 96) * (msm_count / lanes / max(1, args.steps))   # scalars per lane + bases once per MSM
@@ -491,11 +566,13 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
                    "proofs_in_flight": inflight,
                    "ntt_lanes_per_proof": ntt_count / max(1, args.steps), "msms_per_proof": msm_count / max(1, args.steps),
                    "msm_point_lanes_per_proof": pts},
-        "roofline": {"bound": "hbm", "kernel": "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": ("k_accumulate_te (G1 bucket accumulation, twisted Edwards extended coordinates, unsaturated limbs)" if te else
+                                                "k_accumulate_u (G1 bucket accumulation, XYZZ, unsaturated limbs)"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
                      "note": "integer-VALU bound; the commitments between two transcript points are enqueued asynchronously (czk_msm_async), so their sort / "
                              "accumulate / reduce stages overlap each other and the NTTs that follow"},
-        "breakdown_ms_per_step": breakdown, "setup_srs_s": setup_s,
+        "accumulate_busy_frac": busy_ms / (dt * 1e3), "accumulate_busy_ms_per_step": busy_ms / max(1, args.steps),
+        "stream_elapsed_ms_per_step": {**breakdown, "note": STREAM_ELAPSED_NOTE}, "setup_srs_s": setup_s,
     }
     if rank == 0:
         print(json.dumps(res))
@@ -587,6 +664,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=None, help="plonk / marlin, replica layout: independent proofs in flight per GPU, each on its own context "
                                                                  "(default 2: the transcript points of one proof drain the MSM pipeline, a second proof fills the bubbles -- round 3, "
                                                                  "twisted Edwards G1 path: plonk 178 / 152 / 163 ms per proof with 1 / 2 / 3 in flight, marlin 231 / 205 with 1 / 2)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
 
@@ -701,6 +779,7 @@ def main():
     acc2_ms, acc2_n = ctx.profile_read("msm_accumulate_g2")
     breakdown = {k: ctx.profile_read(k)[0] / max(1, args.steps) for k in
                  ("ntt_pass", "msm_sort", "msm_accumulate_g1", "msm_accumulate_g2", "msm_reduce")}
+    busy_ms = busy_union_ms([ctx], ("msm_accumulate_g1", "msm_accumulate_g2"))
     alg_bytes, launches = prover.g1_accumulate_algorithmic_bytes()
     W = prover.h_query.windows()
     madds = args.steps * prover.g1_mixed_additions_per_step(W)       # G1 mixed additions in the timed region
@@ -717,13 +796,17 @@ def main():
     # HBM traffic and the effective clock of the dominant kernels: PMC counters cannot be read from inside this process; the figures
     # are per-launch averages of the same command under `rocprofv3 --pmc` (separate passes), stored with the commit they were taken at
     traffic, traffic_src, pmc = None, None, {}
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tf = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tf):
             try:
                 pmc = json.load(open(tf))
                 traffic = pmc.get("msm_accumulate_g1_bytes_per_launch")
                 traffic_src = f"profiles/{name}" + (f" @ {pmc['commit']}" if "commit" in pmc else "")
+                if "commit" in pmc:
+                    ch = csrc_changed_since(pmc["commit"])
+                    traffic_src += ("; csrc changed since: unknown (no git history here)" if ch is None else
+                                    "; csrc unchanged since" if not ch else f"; csrc files changed since: {', '.join(ch)} (see DESIGN.md for which are on the default path)")
                 break
             except Exception:
                 pmc = {}
@@ -798,7 +881,9 @@ def main():
                         "valu": valu_view(mad2_gops, MADS_PER_MIXED_ADD_G2, madds2, acc2_ms, clk2,
                                           "Fq2 XYZZ mixed add: 6 Fq2 products (schoolbook, one reduction per component: 1148), 2 Fq2 squarings (756), Y3 as two "
                                           "four-product sums (966 each) -> 10332 v_mad_u64_u32 per mixed addition (csrc/fqu.h)")},
-        "breakdown_ms_per_step": breakdown,
+        # time with an accumulate kernel running (union of the HIP-event intervals of the two accumulate kernels) / wall time of the timed region
+        "accumulate_busy_frac": busy_ms / (dt * 1e3), "accumulate_busy_ms_per_step": busy_ms / max(1, args.steps),
+        "stream_elapsed_ms_per_step": {**breakdown, "note": STREAM_ELAPSED_NOTE},
         "setup_key_s": prover.setup_key_s,
     }
     if rank == 0 and world == 1 and not args.no_seam_report:
@@ -827,6 +912,15 @@ def main():
                                              "what a prove-once caller should use"}
         if r1 is not None and not args.no_result_check:
             out["one_shot_no_tables"]["results_checked"] = bool(check_results(czk, ctx1, p1, r1)["results_checked"])
+    if (rank == 0 and world == 1 and not args.no_other_workloads and not party_layout and not args.no_tables and n_constraints == 1 << 20 and args.parties == 2
+            and not os.environ.get("CZK_BENCH_CHILD")):
+        try:
+            del p1
+            ctx1.close()
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        out["other_workloads"] = other_workloads_report(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, (n_constraints - 1).bit_length(), args.parties)
     if rank == 0:

@@ -16,6 +16,7 @@ CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT = 0, 1, 2, 3
 CZK_MEM_HOST, CZK_MEM_DEVICE = 0, 1
 CZK_MEM_NO_TABLES = 32   # czk_bases_register: OR-ed with the above, see include/czk.h
 CZK_MEM_ANY_POINTS = 64  # czk_bases_register: bases need not lie in the prime-order subgroup (keeps the XYZZ kernels for G1)
+CZK_MEM_CHECK_SUBGROUP = 128  # czk_bases_register: verify [r] P == infinity; a failing base keeps the handle on the XYZZ kernels
 CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY = 0, 1
 CZK_G1, CZK_G2 = 1, 2
 CZK_OP_ADD, CZK_OP_SUB, CZK_OP_MUL = 0, 1, 2
@@ -207,7 +208,7 @@ class Context:
     # ---- MSM ------------------------------------------------------------------------------------
     def register_bases(self, group: int, bases, inf=None, n: int | None = None, mem: int = CZK_MEM_HOST) -> "Bases":
         aw = 12 if group == CZK_G1 else 24
-        if (mem & ~(CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS)) == CZK_MEM_HOST:
+        if (mem & ~(CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS | CZK_MEM_CHECK_SUBGROUP)) == CZK_MEM_HOST:
             bases = np.ascontiguousarray(bases, np.uint64)
             n = bases.size // aw
             if inf is not None:
@@ -375,6 +376,22 @@ class Context:
         self._ck(lib().czk_profile_read(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def profile_intervals(self, kernel: str):
+        """(start, stop) in ms after this context's profile origin of every bracket of `kernel`: numpy array (n, 2)"""
+        n = C.c_size_t(0)
+        self._ck(lib().czk_profile_intervals(self._h, kernel.encode(), None, None, C.c_size_t(0), C.byref(n)))
+        a, b = np.zeros(n.value, np.float64), np.zeros(n.value, np.float64)
+        if n.value:
+            self._ck(lib().czk_profile_intervals(self._h, kernel.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
+                                                 C.c_size_t(n.value), C.byref(n)))
+        return np.stack([a, b], axis=1)
+
+    def profile_base_offset(self, other) -> float:
+        """other's profile origin minus this context's, in ms (both after profile_reset)"""
+        ms = C.c_double(0)
+        self._ck(lib().czk_profile_base_offset(self._h, other._h, C.byref(ms)))
+        return ms.value
+
     # ---- Groth16 witness map (device buffers) ------------------------------------------------------
     def witness_map_pre(self, a_ptr, b_ptr, log_d, lanes, a_len=None, b_len=None):
         """a_len / b_len: evaluations present in each lane (default D); the rest of the domain counts as zero."""
@@ -465,6 +482,12 @@ class Bases:
     def arith(self) -> int:
         """0 = XYZZ saturated, 1 = XYZZ unsaturated, 2 = twisted Edwards (czk_bases_arith)"""
         return int(lib().czk_bases_arith(self._h))
+
+    def check_subgroup(self) -> int:
+        """Number of registered bases outside the prime-order subgroup (czk_bases_check_subgroup: [r] P == infinity on the GPU)."""
+        bad = C.c_size_t(0)
+        self.ctx._ck(lib().czk_bases_check_subgroup(self.ctx._h, self._h, C.byref(bad)))
+        return int(bad.value)
 
     def layout_for(self, n_scalars: int):
         """(c, windows) an MSM of n_scalars scalars over these bases runs with (czk_bases_layout_for)."""

@@ -129,6 +129,9 @@ static void prof_resolve(czk_ctx* ctx) {
             if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
                 kv.second.ms += ms;
                 kv.second.launches++;
+                float t0 = 0;
+                if (ctx->prof_base && kv.second.intervals.size() < (1u << 20) && hipEventElapsedTime(&t0, ctx->prof_base, pr.first) == hipSuccess)
+                    kv.second.intervals.emplace_back(t0, t0 + ms);
             }
             ctx->event_pool.push_back(pr.first);
             ctx->event_pool.push_back(pr.second);
@@ -307,6 +310,7 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     xfer_destroy(ctx);
     prof_resolve(ctx);
     for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->prof_base) (void)hipEventDestroy(ctx->prof_base);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -328,6 +332,9 @@ extern "C" int czk_profile_reset(czk_ctx* ctx) {
     CZK_TRY(msm_pipeline_sync(ctx));
     prof_resolve(ctx);
     ctx->prof.clear();
+    if (!ctx->prof_base) CZK_HIP(ctx, hipEventCreate(&ctx->prof_base));
+    CZK_HIP(ctx, hipEventRecord(ctx->prof_base, ctx->stream));
+    CZK_HIP(ctx, hipEventSynchronize(ctx->prof_base));
     return CZK_OK;
 }
 extern "C" int czk_profile_read(czk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches) {
@@ -338,6 +345,29 @@ extern "C" int czk_profile_read(czk_ctx* ctx, const char* kernel, double* total_
     auto it = ctx->prof.find(kernel);
     if (total_ms) *total_ms = it == ctx->prof.end() ? 0.0 : it->second.ms;
     if (launches) *launches = it == ctx->prof.end() ? 0 : it->second.launches;
+    return CZK_OK;
+}
+
+extern "C" int czk_profile_intervals(czk_ctx* ctx, const char* kernel, double* start_ms, double* stop_ms, size_t cap, size_t* n) {
+    if (!ctx || !kernel || !n) return CZK_ERR_ARG;
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CZK_TRY(msm_pipeline_sync(ctx));
+    prof_resolve(ctx);
+    auto it = ctx->prof.find(kernel);
+    const size_t have = it == ctx->prof.end() ? 0 : it->second.intervals.size();
+    *n = have;
+    for (size_t i = 0; i < have && i < cap; i++) {
+        if (start_ms) start_ms[i] = it->second.intervals[i].first;
+        if (stop_ms) stop_ms[i] = it->second.intervals[i].second;
+    }
+    return CZK_OK;
+}
+extern "C" int czk_profile_base_offset(czk_ctx* a, czk_ctx* b, double* ms) {
+    if (!a || !b || !ms) return CZK_ERR_ARG;
+    if (!a->prof_base || !b->prof_base) return set_err(a, CZK_ERR_ARG, "czk_profile_base_offset: czk_profile_reset has not run on both contexts");
+    float d = 0;
+    CZK_HIP(a, hipEventElapsedTime(&d, a->prof_base, b->prof_base));
+    *ms = d;
     return CZK_OK;
 }
 

@@ -52,6 +52,7 @@ struct ProfEntry {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
     double ms = 0;
     uint64_t launches = 0;
+    std::vector<std::pair<float, float>> intervals;   // (start, stop) in ms after the context's profile base event (czk_profile_intervals)
 };
 }  // namespace czk
 
@@ -103,6 +104,7 @@ struct czk_ctx {
     bool profiling = false;
     std::map<std::string, czk::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
+    hipEvent_t prof_base = nullptr;   // recorded by czk_profile_reset: origin of czk_profile_intervals
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -141,6 +143,9 @@ struct czk_bases {
     bool unsat = false;        // window tables hold coordinates * R' (fqu.h), used by k_accumulate_u / k_accumulate_u2
     bool te = false;           // G1 only: window tables hold twisted Edwards niels entries (te.h: 24 u64 per point); buckets and the
                                // reduction run in extended coordinates; `pts_sw0` keeps the original points for secondary table sets
+    bool check_wanted = false; // CZK_MEM_CHECK_SUBGROUP: [r] P == infinity is verified at registration; a failing base clears te_wanted
+    bool checked = false;      // the check ran at registration; n_bad holds its result
+    size_t n_bad = 0;
     bool te_wanted = true;     // false: registered with CZK_MEM_ANY_POINTS (bases need not lie in the prime-order subgroup)
     uint64_t* pts_sw0 = nullptr;   // te: window 0 as registered (n x 12 u64, saturated Montgomery form)
     bool split = false;        // CZK_MEM_NO_TABLES: only window 0 is stored; an MSM runs one bucket set per window (windows become

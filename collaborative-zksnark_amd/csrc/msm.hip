@@ -565,6 +565,69 @@ static int te_table_from_sw(czk_ctx* ctx, const u64* sw, const uint8_t* inf, siz
     return CZK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Subgroup membership of registered bases: the reference's `is_in_correct_subgroup_assuming_on_curve` is `self.mul(r).is_zero()`
+// (short_weierstrass_jacobian.rs:131), enforced when a key is deserialised (:868, :881); its MSM itself is complete on every curve point.
+// The twisted Edwards G1 kernels are exception-free exactly on the prime-order subgroup, so a caller that cannot vouch for its bases asks
+// for this check (czk_bases_check_subgroup, or CZK_MEM_CHECK_SUBGROUP at registration: a failing base keeps the handle on the XYZZ kernels).
+// One thread per point: on-curve test (y^2 = x^3 + b), then [r] P by MSB-first double-and-add with the complete Jacobian formulas of curve.h.
+// ------------------------------------------------------------------------------------------------
+template <class F>
+struct CurveB;
+template <>
+struct CurveB<Fq> {   // COEFF_B = 1 (curves/bls12_377/src/curves/g1.rs:23)
+    static CZK_HD Fq get() { return Fq::one(); }
+};
+template <>
+struct CurveB<Fq2> {   // COEFF_B = (0, 1552...4906) (curves/bls12_377/src/curves/g2.rs:28-34), c1 in Montgomery form
+    static CZK_HD Fq2 get() {
+        Fq2 b = Fq2::zero();
+        constexpr u32 m[12] = {0x66666685u, 0x80722666u, 0x899999a9u, 0x8df55926u, 0xd64f34cfu, 0x7fe4561au,
+                               0xb6e4f01bu, 0xb95da6d8u, 0xfc142743u, 0x4b747cccu, 0x70f49f43u, 0x0039c3fau};
+#pragma unroll
+        for (int i = 0; i < 12; i++) b.c1.l[i] = m[i];
+        return b;
+    }
+};
+template <class F>
+__global__ __launch_bounds__(128) void k_subgroup_check(const u64* aff, const uint8_t* inf, size_t n, u32* bad) {
+    // r = 0x12ab655e9a2ca55660b44d1e5c37b00159aa76fed00000010a11800000000001, 253 bits (curves/bls12_377/src/fields/fr.rs MODULUS)
+    constexpr u32 R[8] = {0x00000001u, 0x0a118000u, 0xd0000001u, 0x59aa76feu, 0x5c37b001u, 0x60b44d1eu, 0x9a2ca556u, 0x12ab655eu};
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || (inf && inf[i])) return;
+    const Affine<F> a = aff_load<F>(aff + (size_t)GT<F>::AW * i);
+    bool ok = f_sqr(a.y) == f_add(f_mul(f_sqr(a.x), a.x), CurveB<F>::get());
+    if (ok) {
+        Jac<F> p{a.x, a.y, F::one()};
+        for (int bit = 251; bit >= 0; bit--) {   // bit 252 is the leading one
+            p = jac_double(p);
+            if ((R[bit >> 5] >> (bit & 31)) & 1u) p = jac_add_mixed(p, a, false);
+        }
+        ok = p.is_zero();
+    }
+    if (!ok) atomicAdd(bad, 1u);
+}
+// pts: `n` affine points in the reference's (saturated Montgomery) form, device memory
+template <class F>
+static int subgroup_check_impl(czk_ctx* ctx, const u64* pts, const uint8_t* inf, size_t n, size_t* out_bad) {
+    *out_bad = 0;
+    if (!n) return CZK_OK;
+    u32* bad = nullptr;
+    u32 h = 0;
+    CZK_HIP(ctx, hipMalloc(&bad, 4));
+    hipError_t e = hipMemsetAsync(bad, 0, 4, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_subgroup_check<F>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, pts, inf, n, bad);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, bad, 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(bad);
+    if (e != hipSuccess) return set_err(ctx, CZK_ERR_HIP, std::string("subgroup check: ") + hipGetErrorString(e));
+    *out_bad = h;
+    return CZK_OK;
+}
+
 template <class F>
 static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const uint8_t* inf_dev) {
     constexpr int AW = GT<F>::AW, JW = GT<F>::JW, FW = GT<F>::FW;
@@ -576,6 +639,11 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
     CZK_HIP(ctx, hipMemcpyAsync(b->pts, pts_dev, n * AW * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (inf_dev) CZK_HIP(ctx, hipMemcpyAsync(b->inf, inf_dev, n, hipMemcpyDeviceToDevice, ctx->stream));
     else CZK_HIP(ctx, hipMemsetAsync(b->inf, 0, n, ctx->stream));
+    if (b->check_wanted) {   // CZK_MEM_CHECK_SUBGROUP: a base outside the prime-order subgroup keeps the handle on the complete XYZZ kernels
+        CZK_TRY(subgroup_check_impl<F>(ctx, b->pts, b->inf, n, &b->n_bad));
+        b->checked = true;
+        if (b->n_bad) b->te_wanted = false;
+    }
     if (W > 1) {
         u64 *jac = nullptr, *scr = nullptr;
         CZK_HIP(ctx, hipMalloc(&jac, n * JW * 8));
@@ -1108,9 +1176,10 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     *out = nullptr;
     if (group != CZK_G1 && group != CZK_G2) return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
     if (n && !bases) return set_err(ctx, CZK_ERR_ARG, "null bases");
-    const bool no_tables = (mem & CZK_MEM_NO_TABLES) != 0, any_points = (mem & CZK_MEM_ANY_POINTS) != 0;
-    mem &= ~(CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS);
-    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (optionally | CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS)");
+    const bool no_tables = (mem & CZK_MEM_NO_TABLES) != 0, any_points = (mem & CZK_MEM_ANY_POINTS) != 0, check = (mem & CZK_MEM_CHECK_SUBGROUP) != 0;
+    mem &= ~(CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS | CZK_MEM_CHECK_SUBGROUP);
+    if (!valid_mem(mem))
+        return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (optionally | CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS | CZK_MEM_CHECK_SUBGROUP)");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t aw = group == CZK_G1 ? 12 : 24;
     czk_bases* b = new czk_bases();
@@ -1119,6 +1188,7 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     b->n = n;
     b->split = no_tables;
     b->te_wanted = !any_points;
+    b->check_wanted = check;
     b->per_call_width = getenv("CZK_MSM_FIXED_C") == nullptr;
     b->c = no_tables ? choose_c_split(n) : choose_c(n);
     if (const char* e = getenv(group == CZK_G1 ? "CZK_MSM_C_G1" : "CZK_MSM_C_G2")) {   // measurement knob: the primary table set's width
@@ -1189,6 +1259,33 @@ extern "C" int czk_bases_layout_for(const czk_bases* b, size_t n_scalars, unsign
     if (windows) *windows = num_windows(cc);
     return CZK_OK;
 }
+extern "C" int czk_bases_check_subgroup(czk_ctx* ctx, const czk_bases* b, size_t* out_bad) {
+    if (!ctx || !b || !out_bad) return ctx ? set_err(ctx, CZK_ERR_ARG, "null check_subgroup argument") : CZK_ERR_ARG;
+    if (b->checked) {   // CZK_MEM_CHECK_SUBGROUP ran at registration
+        *out_bad = b->n_bad;
+        return CZK_OK;
+    }
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t aw = b->group == CZK_G1 ? 12 : 24;
+    const u64* pts = b->te ? b->pts_sw0 : b->pts;   // window 0 = the registered points
+    u64* tmp = nullptr;
+    if (b->unsat && !b->te && b->n) {   // the table is in the unsaturated residue system: check a converted copy
+        CZK_HIP(ctx, hipMalloc(&tmp, b->n * aw * 8));
+        hipError_t e = hipMemcpyAsync(tmp, b->pts, b->n * aw * 8, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            launch_convert_from_u(ctx->stream, tmp, b->n * (aw / 6));
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) {
+            (void)hipFree(tmp);
+            return set_err(ctx, CZK_ERR_HIP, std::string("subgroup check copy: ") + hipGetErrorString(e));
+        }
+        pts = tmp;
+    }
+    int rc = b->group == CZK_G1 ? subgroup_check_impl<Fq>(ctx, pts, b->inf, b->n, out_bad) : subgroup_check_impl<Fq2>(ctx, pts, b->inf, b->n, out_bad);
+    if (tmp) (void)hipFree(tmp);
+    return rc;
+}
 extern "C" int czk_bases_arith(const czk_bases* b) { return !b ? -1 : b->te ? 2 : b->unsat ? 1 : 0; }
 extern "C" int czk_bases_prepare(czk_ctx* ctx, const czk_bases* b, size_t n_scalars) {
     if (!ctx || !b) return ctx ? set_err(ctx, CZK_ERR_ARG, "null bases") : CZK_ERR_ARG;
@@ -1238,7 +1335,9 @@ static int msm_oneshot(czk_ctx* ctx, int group, const uint64_t* bases_xy, const 
                        int scalar_form, uint64_t* out_jac) {
     czk_bases* b = nullptr;
     // used once: no window tables (building them costs ~20 point doublings per point and window -- more than the MSM itself)
-    CZK_TRY(czk_bases_register(ctx, group, bases_xy, inf, n, CZK_MEM_HOST | CZK_MEM_NO_TABLES, &b));
+    // ... and CZK_MEM_ANY_POINTS: this is the reference's own signature (VariableBaseMSM::multi_scalar_mul, complete on every curve point), so the
+    // one-shot entry points make no subgroup assumption; registered keys (czk_bases_register) choose it themselves
+    CZK_TRY(czk_bases_register(ctx, group, bases_xy, inf, n, CZK_MEM_HOST | CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS, &b));
     int rc = czk_msm(ctx, b, scalars, n, lanes, scalar_form, CZK_MEM_HOST, out_jac);
     czk_bases_release(b);
     return rc;

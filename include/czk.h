@@ -60,8 +60,16 @@ typedef enum {
      * subgroup.  G1 handles then keep short-Weierstrass (XYZZ) bucket arithmetic with the reference's complete case analysis
      * (short_weierstrass_jacobian.rs:570-597).  Without the flag G1 bases are taken to lie in G1 -- as every proving-key and SRS element
      * does (the reference deserialises them with a subgroup check) -- and the bucket kernels use the curve's twisted Edwards form, whose
-     * unified 7-multiplication addition is exception-free exactly on that subgroup.  Results are the same group elements either way. */
-    CZK_MEM_ANY_POINTS = 64
+     * unified 7-multiplication addition is exception-free exactly on that subgroup.  Results are the same group elements either way.
+     * A base of even order registered WITHOUT this flag (and without the check below) can meet an exceptional pair of the unified law
+     * and yield a wrong group element with status CZK_OK: a caller that cannot vouch for its bases passes one of the two flags. */
+    CZK_MEM_ANY_POINTS = 64,
+    /* czk_bases_register only, OR-ed in: verify the assumption instead of trusting it.  Registration runs the reference's
+     * is_in_correct_subgroup_assuming_on_curve ([r] P == infinity, short_weierstrass_jacobian.rs:131; plus y^2 = x^3 + b) on every base
+     * -- what the reference does when it deserialises a key (:868, :881) -- and keeps the handle on the complete XYZZ kernels when any
+     * base fails, exactly as CZK_MEM_ANY_POINTS would.  czk_bases_check_subgroup then reports the count without re-running.  Costs about
+     * as much as building the window tables (252 doublings + 87 additions per point; 2^20 G1 points: ~0.1 s). */
+    CZK_MEM_CHECK_SUBGROUP = 128
 } czk_mem;
 
 /* EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (algebra/poly/src/domain/mod.rs:79,90,139,155) */
@@ -260,13 +268,19 @@ int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_
 int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
                   int scalar_form, int mem, uint64_t* out_jac);
 
-/* One-shot forms with the reference's argument order (bases not kept on the GPU).  Like every G1 handle registered without
- * CZK_MEM_ANY_POINTS, czk_msm_g1 takes its bases to be elements of the prime-order subgroup G1 (GroupAffine values of the
- * reference are, by construction and by deserialisation check); arbitrary curve points go through czk_bases_register with that flag. */
+/* One-shot forms with the reference's argument order (bases not kept on the GPU).  These are VariableBaseMSM::multi_scalar_mul's
+ * signature, which is complete on every curve point, so they make NO subgroup assumption: the bases are registered with
+ * CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS for the call (G1: XYZZ bucket arithmetic with the reference's case analysis). */
 int czk_msm_g1(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
                size_t lanes, int scalar_form, uint64_t* out_jac);
 int czk_msm_g2(czk_ctx* ctx, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n,
                size_t lanes, int scalar_form, uint64_t* out_jac);
+
+/* GroupAffine::is_in_correct_subgroup_assuming_on_curve (short_weierstrass_jacobian.rs:131: `self.mul(r).is_zero()`) over the
+ * registered bases, on the GPU: *out_bad = number of bases that are not on the curve or not annihilated by r (points at infinity
+ * pass).  0 means the default (twisted Edwards) G1 arithmetic is exact for this handle.  Blocking.  For a handle registered with
+ * CZK_MEM_CHECK_SUBGROUP the stored result of the registration-time check is returned. */
+int czk_bases_check_subgroup(czk_ctx* ctx, const czk_bases* bases, size_t* out_bad);
 
 /* From<GroupProjective> for GroupAffine (short_weierstrass_jacobian.rs:768-789): n host Jacobian points ->
  * n host affine points + infinity flags.  This is what AffineMsm::msm's `.into()` does (share/msm.rs:31-37).
@@ -303,6 +317,13 @@ int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, size_t c_len, 
 int czk_profile_enable(czk_ctx* ctx, int on);
 int czk_profile_reset(czk_ctx* ctx);
 int czk_profile_read(czk_ctx* ctx, const char* kernel, double* total_ms, uint64_t* launches);
+/* The same brackets as intervals: (start, stop) of every bracket of `kernel` in milliseconds after the context's profile origin (an
+ * event czk_profile_reset records on the context's stream).  Writes at most `cap` pairs, *n = the number available.  Summed elapsed
+ * times of brackets on different streams overlap; the UNION of the intervals is the time a kernel of that name was running -- what
+ * bench.py reports as accumulate-busy time.  czk_profile_base_offset: origin of `b` minus origin of `a` (same device), to merge the
+ * intervals of several contexts onto one clock. */
+int czk_profile_intervals(czk_ctx* ctx, const char* kernel, double* start_ms, double* stop_ms, size_t cap, size_t* n);
+int czk_profile_base_offset(czk_ctx* a, czk_ctx* b, double* ms);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ pub const CZK_MEM_DEVICE: c_int = 1; // czk_mem
 pub const CZK_MEM_STABLE: c_int = 16; // czk_mem
 pub const CZK_MEM_NO_TABLES: c_int = 32; // czk_mem
 pub const CZK_MEM_ANY_POINTS: c_int = 64; // czk_mem
+pub const CZK_MEM_CHECK_SUBGROUP: c_int = 128; // czk_mem
 pub const CZK_FFT: c_int = 0; // czk_ntt_kind
 pub const CZK_IFFT: c_int = 1; // czk_ntt_kind
 pub const CZK_COSET_FFT: c_int = 2; // czk_ntt_kind
@@ -90,6 +91,7 @@ extern "C" {
     pub fn czk_msm_async(ctx: *mut czk_ctx, bases: *const czk_bases, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *mut u64) -> c_int;
     pub fn czk_msm_g1(ctx: *mut czk_ctx, bases_xy: *const u64, inf: *const u8, scalars: *const u64, n: usize, lanes: usize, scalar_form: c_int, out_jac: *mut u64) -> c_int;
     pub fn czk_msm_g2(ctx: *mut czk_ctx, bases_xy: *const u64, inf: *const u8, scalars: *const u64, n: usize, lanes: usize, scalar_form: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_bases_check_subgroup(ctx: *mut czk_ctx, bases: *const czk_bases, out_bad: *mut usize) -> c_int;
     pub fn czk_jac_to_affine(ctx: *mut czk_ctx, group: c_int, jac: *const u64, n: usize, out_aff: *mut u64, out_inf: *mut u8) -> c_int;
     pub fn czk_jac_add(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, b_jac: *const u64, out_jac: *mut u64) -> c_int;
     pub fn czk_jac_add_mixed(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, b_aff: *const u64, b_inf: c_int, out_jac: *mut u64) -> c_int;
@@ -99,4 +101,6 @@ extern "C" {
     pub fn czk_profile_enable(ctx: *mut czk_ctx, on: c_int) -> c_int;
     pub fn czk_profile_reset(ctx: *mut czk_ctx) -> c_int;
     pub fn czk_profile_read(ctx: *mut czk_ctx, kernel: *const c_char, total_ms: *mut f64, launches: *mut u64) -> c_int;
+    pub fn czk_profile_intervals(ctx: *mut czk_ctx, kernel: *const c_char, start_ms: *mut f64, stop_ms: *mut f64, cap: usize, n: *mut usize) -> c_int;
+    pub fn czk_profile_base_offset(a: *mut czk_ctx, b: *mut czk_ctx, ms: *mut f64) -> c_int;
 }

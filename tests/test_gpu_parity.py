@@ -1086,3 +1086,92 @@ def test_g1_bucket_arithmetic_selection_and_any_points_flag(ctx, czk, orc):
     h = ctx.register_bases(2, b2, None)
     assert h.arith() == 1
     h.release()
+
+
+def _full_order_exceptional_pair(orc):
+    """(A, B = A + T): A a curve point of E(Fq) outside G1 (order divisible by the cofactor) WITH an image under the twisted Edwards map,
+    T a rational 2-torsion point that maps to a point at infinity of the Edwards model -- the unified law's denominator 1 - D x1 x2 y1 y2
+    vanishes for the pair (tools/gen_te_constants.py holds the map; checked here with integers).  Returns Montgomery-form affine limbs."""
+    import os
+    import random
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_te_constants as te
+    Q = te.Q
+    g = 2
+    while pow(g, (Q - 1) // 3, Q) == 1:
+        g += 1
+    zeta = pow(g, (Q - 1) // 3, Q)                       # a primitive cube root of unity: x^3 + 1 = (x + 1)(x + zeta)(x + zeta^2)
+    rng = random.Random(5)
+    while True:
+        x = rng.randrange(Q)
+        if te.is_sq((x ** 3 + 1) % Q):
+            A = (x, te.sqrt((x ** 3 + 1) % Q))
+            break
+    T = ((-zeta) % Q, 0)
+    B = te.sw_add(A, T)
+    a, b = te.sw_to_te(A), te.sw_to_te(B)
+    assert (1 - te.C["D"] * a[0] * b[0] * a[1] * b[1]) % Q == 0      # the exceptional pair of the unified law
+    return np.stack([np.concatenate([orc.fq_from_repr(ints_to_limbs([P[0]], 6))[0], orc.fq_from_repr(ints_to_limbs([P[1]], 6))[0]]) for P in (A, B)])
+
+
+def test_g1_full_order_bases_subgroup_check_and_fallback(ctx, czk, orc):
+    """VERDICT r03 item 2.  The reference's MSM is complete on every curve point; its subgroup check lives in deserialisation
+    (short_weierstrass_jacobian.rs:131, :868, :881).  Two full-order points forming an exceptional pair of the twisted Edwards law, in ONE bucket:
+    (i) CZK_MEM_ANY_POINTS -> the checker's result; (ii) CZK_MEM_CHECK_SUBGROUP -> the check fails, the handle falls back to XYZZ, the checker's
+    result; (iii) default -> the handle trusts its caller (documented in czk.h): twisted Edwards kernels, and czk_bases_check_subgroup tells."""
+    pair = _full_order_exceptional_pair(orc)
+    inf = np.zeros(2, dtype=np.uint8)
+    assert orc.g1_on_curve(pair[0]) and orc.g1_on_curve(pair[1])
+    for name, sc in (("unit", ints_to_limbs([1, 1], 4)), ("same", np.repeat(rand_fr_canonical(4242, 1), 2, axis=0))):
+        want = orc.msm(1, pair, inf, sc)
+        for tables in (0, czk.CZK_MEM_NO_TABLES):
+            b = ctx.register_bases(1, pair, inf, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_ANY_POINTS | tables)
+            assert b.arith() == 1 and b.check_subgroup() == 2
+            assert _same_point(ctx, orc, 1, ctx.msm(b, sc)[0], want), (name, tables, "any points")
+            b.release()
+            b = ctx.register_bases(1, pair, inf, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_CHECK_SUBGROUP | tables)
+            assert b.arith() == 1 and b.check_subgroup() == 2, "a failed registration-time check must keep the XYZZ kernels"
+            assert _same_point(ctx, orc, 1, ctx.msm(b, sc)[0], want), (name, tables, "checked")
+            b.release()
+        # the reference's own signature (bases not kept) makes no subgroup assumption either
+        assert _same_point(ctx, orc, 1, ctx.msm_oneshot(1, pair, inf, sc)[0], want), (name, "one-shot")
+        # default: the caller vouches for its bases.  The handle runs the unified law, which has no answer for this pair -- the hazard the
+        # two flags exist for -- and the check, run on request, reports both bases
+        b = ctx.register_bases(1, pair, inf)
+        assert b.arith() == 2 and b.check_subgroup() == 2
+        assert not _same_point(ctx, orc, 1, ctx.msm(b, sc)[0], want), "the default path became complete on E: update czk.h / INTEGRATION.md"
+        b.release()
+    # bases that ARE in G1: the check passes, the fast path stays; mixed with one outsider / one off-curve point it does not
+    n = 500
+    _, good = _bases(ctx, 1, n, 4243)
+    ginf = np.zeros(n, dtype=np.uint8)
+    ginf[3] = 1                                                       # a point at infinity passes
+    sc = rand_fr_canonical(4244, n)
+    b = ctx.register_bases(1, good, ginf, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_CHECK_SUBGROUP)
+    assert b.arith() == 2 and b.check_subgroup() == 0
+    assert _same_point(ctx, orc, 1, ctx.msm(b, sc)[0], orc.msm(1, good, ginf, sc))
+    b.release()
+    b = ctx.register_bases(1, good, ginf)
+    assert b.check_subgroup() == 0                                    # on request, on a twisted Edwards handle (uses the kept registered points)
+    b.release()
+    mixed = good.copy()
+    mixed[17] = pair[0]
+    b = ctx.register_bases(1, mixed, ginf, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_CHECK_SUBGROUP)
+    assert b.arith() == 1 and b.check_subgroup() == 1
+    assert _same_point(ctx, orc, 1, ctx.msm(b, sc)[0], orc.msm(1, mixed, ginf, sc))
+    b.release()
+    off = good.copy()
+    off[20, 0] ^= np.uint64(1)                                        # not on the curve at all
+    b = ctx.register_bases(1, off, ginf, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_ANY_POINTS)
+    assert b.check_subgroup() == 1
+    b.release()
+    # G2 handles always run the complete XYZZ kernels; the check is offered for them too
+    _, g2 = _bases(ctx, 2, 40, 4245)
+    h = ctx.register_bases(2, g2, None, mem=czk.CZK_MEM_HOST | czk.CZK_MEM_CHECK_SUBGROUP)
+    assert h.arith() == 1 and h.check_subgroup() == 0
+    h.release()
+    g2[5, 0] ^= np.uint64(1)
+    h = ctx.register_bases(2, g2, None)
+    assert h.check_subgroup() == 1
+    h.release()
