@@ -9,6 +9,7 @@ this package imports the checker under oracle/.
 """
 from .binding import (CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT, CZK_MEM_HOST, CZK_MEM_DEVICE, CZK_MEM_NO_TABLES, CZK_MEM_ANY_POINTS, CZK_MEM_CHECK_SUBGROUP,  # noqa: F401
                       CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY, CZK_G1, CZK_G2, CzkError, Context, Bases, lib,
-                      lib_path, exported_symbols, header_symbols)
+                      lib_path, lab_lib, exported_symbols, header_symbols)
+from . import binding  # noqa: F401
 from .build import build  # noqa: F401
 from . import parallel  # noqa: F401

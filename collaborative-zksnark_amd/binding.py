@@ -33,31 +33,46 @@ def lib_path() -> str:
     return _LIB
 
 
+_LIB_LAB = os.path.join(_HERE, "libczk_hip_lab.so")   # the -DCZK_LAB build: product + the rejected variants kept for A/B runs (build.py)
 _lib = None
+_lab = None
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(there is no CPU fallback for the product path)")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes cannot share a process, so let
+    # torch's copy load first (same SONAME -> the library binds to it).  torch is plumbing here: device
+    # memory, streams, torch.distributed.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see csrc/core.hip: must be set before HIP initialises
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(path)
+    L.czk_last_error.restype = C.c_char_p
+    L.czk_version.restype = C.c_char_p
+    L.czk_bases_len.restype = C.c_size_t
+    L.czk_lanes_count.restype = C.c_size_t
+    L.czk_lanes_len.restype = C.c_size_t
+    L.czk_lanes_data.restype = C.c_void_p
+    return L
+
+
+def lab_lib():
+    """The lab build (libczk_hip_lab.so): same ABI, plus the rejected kernel variants and their options.  Tests and tools only."""
+    global _lab
+    if _lab is None:
+        _lab = _load(_LIB_LAB)
+    return _lab
 
 
 def lib():
     """Loads libczk_hip.so; raises (never falls back) when it has not been built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB):
-            raise FileNotFoundError(f"{_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                                    "(there is no CPU fallback for the product path)")
-        # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes cannot share a process, so let
-        # torch's copy load first (same SONAME -> libczk_hip.so binds to it).  torch is plumbing here: device
-        # memory, streams, torch.distributed.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see csrc/core.hip: must be set before HIP initialises
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
-        _lib = C.CDLL(_LIB)
-        _lib.czk_last_error.restype = C.c_char_p
-        _lib.czk_version.restype = C.c_char_p
-        _lib.czk_bases_len.restype = C.c_size_t
-        _lib.czk_lanes_count.restype = C.c_size_t
-        _lib.czk_lanes_len.restype = C.c_size_t
-        _lib.czk_lanes_data.restype = C.c_void_p
+        _lib = _load(_LIB)
     return _lib
 
 
@@ -90,15 +105,23 @@ class Context:
     own non-blocking stream -- note torch's DEFAULT stream has handle 0, so to share a stream with torch ops use an
     explicit `torch.cuda.Stream()` (bench.py does)."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, lab: bool = False, options: dict | None = None):
+        """lab=True binds this context to libczk_hip_lab.so (tests / A/B tools: the rejected kernel variants and their options);
+        `options`: {name: value} passed to czk_ctx_set_option before any work."""
+        self._L = lab_lib() if lab else lib()
         self._h = C.c_void_p(0)
-        rc = lib().czk_ctx_create(C.byref(self._h), C.c_int(device), C.c_void_p(stream or 0))
+        rc = self._L.czk_ctx_create(C.byref(self._h), C.c_int(device), C.c_void_p(stream or 0))
         if rc:
             raise CzkError(rc, "czk_ctx_create failed (no visible GPU?)")
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name: str, value: int):
+        self._ck(self._L.czk_ctx_set_option(self._h, name.encode(), C.c_long(int(value))))
 
     def close(self):
         if self._h:
-            lib().czk_ctx_destroy(self._h)
+            self._L.czk_ctx_destroy(self._h)
             self._h = C.c_void_p(0)
 
     def __del__(self):
@@ -109,16 +132,16 @@ class Context:
 
     def _ck(self, rc):
         if rc:
-            raise CzkError(rc, (lib().czk_last_error(self._h) or b"").decode())
+            raise CzkError(rc, (self._L.czk_last_error(self._h) or b"").decode())
 
     def sync(self):
-        self._ck(lib().czk_ctx_sync(self._h))
+        self._ck(self._L.czk_ctx_sync(self._h))
 
     # ---- device-resident share lanes ---------------------------------------------------------------
     def lanes_alloc(self, lanes: int, length: int) -> "Lanes":
         """czk_lanes_alloc: `lanes` x `length` Fr in HBM, zero-filled; the handle a caller without a HIP allocator uses."""
         h = C.c_void_p(0)
-        self._ck(lib().czk_lanes_alloc(self._h, C.c_size_t(lanes), C.c_size_t(length), C.byref(h)))
+        self._ck(self._L.czk_lanes_alloc(self._h, C.c_size_t(lanes), C.c_size_t(length), C.byref(h)))
         return Lanes(self, h)
 
     # ---- NTT ------------------------------------------------------------------------------------
@@ -129,7 +152,7 @@ class Context:
             in_len = d
         if isinstance(data, np.ndarray):
             assert data.dtype == np.uint64 and (log_d > 40 or data.size == lanes * d * 4), "buffer must hold lanes x D x 4 u64"
-        self._ck(lib().czk_ntt_fr(self._h, _ptr(data), C.c_uint(log_d), C.c_size_t(lanes), C.c_int(kind), C.c_size_t(in_len),
+        self._ck(self._L.czk_ntt_fr(self._h, _ptr(data), C.c_uint(log_d), C.c_size_t(lanes), C.c_int(kind), C.c_size_t(in_len),
                                   C.c_int(mem)))
         return data
 
@@ -139,18 +162,18 @@ class Context:
             in_len = size
         if isinstance(data, np.ndarray):
             assert data.dtype == np.uint64 and data.size == lanes * size * 4, "buffer must hold lanes x size x 4 u64"
-        self._ck(lib().czk_ntt_fr_mixed(self._h, _ptr(data), C.c_size_t(size), C.c_size_t(lanes), C.c_int(kind), C.c_size_t(in_len), C.c_int(mem)))
+        self._ck(self._L.czk_ntt_fr_mixed(self._h, _ptr(data), C.c_size_t(size), C.c_size_t(lanes), C.c_int(kind), C.c_size_t(in_len), C.c_int(mem)))
         return data
 
     def mixed_domain_constants(self, size: int):
         out = np.zeros((6, 4), dtype=np.uint64)
-        self._ck(lib().czk_mixed_domain_constants(self._h, C.c_size_t(size), _ptr(out)))
+        self._ck(self._L.czk_mixed_domain_constants(self._h, C.c_size_t(size), _ptr(out)))
         names = ["size_inv", "group_gen", "group_gen_inv", "generator", "generator_inv", "vanishing_inv"]
         return dict(zip(names, out))
 
     def domain_constants(self, log_d: int):
         out = np.zeros((6, 4), dtype=np.uint64)
-        self._ck(lib().czk_domain_constants(self._h, C.c_uint(log_d), _ptr(out)))
+        self._ck(self._L.czk_domain_constants(self._h, C.c_uint(log_d), _ptr(out)))
         names = ["size_inv", "group_gen", "group_gen_inv", "generator", "generator_inv", "vanishing_inv"]
         return dict(zip(names, out))
 
@@ -160,7 +183,7 @@ class Context:
             a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
             n = a.size // 4
             out = np.empty_like(a) if out is None else out
-        self._ck(lib().czk_fr_vec_op(self._h, C.c_int(op), _ptr(a), _ptr(b), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        self._ck(self._L.czk_fr_vec_op(self._h, C.c_int(op), _ptr(a), _ptr(b), _ptr(out), C.c_size_t(n), C.c_int(mem)))
         return out
 
     def fr_vec_scale(self, a, k, out=None, n=None, mem=CZK_MEM_HOST):
@@ -168,7 +191,7 @@ class Context:
             a, k = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(k, np.uint64)
             n = a.size // 4
             out = np.empty_like(a) if out is None else out
-        self._ck(lib().czk_fr_vec_scale(self._h, _ptr(a), _ptr(k), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        self._ck(self._L.czk_fr_vec_scale(self._h, _ptr(a), _ptr(k), _ptr(out), C.c_size_t(n), C.c_int(mem)))
         return out
 
     def fr_powers(self, g, n: int, c=None, out=None, mem=CZK_MEM_HOST):
@@ -177,7 +200,7 @@ class Context:
         cc = None if c is None else np.ascontiguousarray(c, np.uint64).reshape(4)
         if mem == CZK_MEM_HOST:
             out = np.zeros((n, 4), dtype=np.uint64)
-        self._ck(lib().czk_fr_powers(self._h, _ptr(g), _ptr(cc), C.c_size_t(n), _ptr(out), C.c_int(mem)))
+        self._ck(self._L.czk_fr_powers(self._h, _ptr(g), _ptr(cc), C.c_size_t(n), _ptr(out), C.c_int(mem)))
         return out
 
     def fr_beaver_combine(self, x, y, z, sx, oy, add_open, out=None, n=None, mem=CZK_MEM_HOST):
@@ -185,7 +208,7 @@ class Context:
             x, y, z, sx, oy = (np.ascontiguousarray(v, np.uint64) for v in (x, y, z, sx, oy))
             n = x.size // 4
             out = np.empty_like(x) if out is None else out
-        self._ck(lib().czk_fr_beaver_combine(self._h, _ptr(x), _ptr(y), _ptr(z), _ptr(sx), _ptr(oy), C.c_int(int(add_open)),
+        self._ck(self._L.czk_fr_beaver_combine(self._h, _ptr(x), _ptr(y), _ptr(z), _ptr(sx), _ptr(oy), C.c_int(int(add_open)),
                                              _ptr(out), C.c_size_t(n), C.c_int(mem)))
         return out
 
@@ -194,7 +217,7 @@ class Context:
             a = np.ascontiguousarray(a, np.uint64)
             n = a.size // 4
             out = np.empty_like(a) if out is None else out
-        self._ck(lib().czk_fr_into_repr(self._h, _ptr(a), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        self._ck(self._L.czk_fr_into_repr(self._h, _ptr(a), _ptr(out), C.c_size_t(n), C.c_int(mem)))
         return out
 
     def fr_from_repr(self, a, out=None, n=None, mem=CZK_MEM_HOST):
@@ -202,7 +225,7 @@ class Context:
             a = np.ascontiguousarray(a, np.uint64)
             n = a.size // 4
             out = np.empty_like(a) if out is None else out
-        self._ck(lib().czk_fr_from_repr(self._h, _ptr(a), _ptr(out), C.c_size_t(n), C.c_int(mem)))
+        self._ck(self._L.czk_fr_from_repr(self._h, _ptr(a), _ptr(out), C.c_size_t(n), C.c_int(mem)))
         return out
 
     # ---- MSM ------------------------------------------------------------------------------------
@@ -214,7 +237,7 @@ class Context:
             if inf is not None:
                 inf = np.ascontiguousarray(inf, np.uint8)
         h = C.c_void_p(0)
-        self._ck(lib().czk_bases_register(self._h, C.c_int(group), _ptr(bases), _ptr(inf), C.c_size_t(n), C.c_int(mem), C.byref(h)))
+        self._ck(self._L.czk_bases_register(self._h, C.c_int(group), _ptr(bases), _ptr(inf), C.c_size_t(n), C.c_int(mem), C.byref(h)))
         return Bases(self, h, group, n)
 
     def msm(self, bases: "Bases", scalars, n_scalars: int | None = None, lanes: int = 1, scalar_form: int = CZK_SCALAR_CANONICAL,
@@ -226,14 +249,14 @@ class Context:
             if n_scalars is None:
                 n_scalars = scalars.size // (4 * lanes)
         out = np.zeros((lanes, jw), dtype=np.uint64)
-        self._ck(lib().czk_msm(self._h, bases._h, _ptr(scalars), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
+        self._ck(self._L.czk_msm(self._h, bases._h, _ptr(scalars), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
                                C.c_int(mem), _ptr(out)))
         return out
 
     def msm_async(self, bases: "Bases", scalars_ptr, n_scalars: int, lanes: int, scalar_form: int, out: np.ndarray, stable: bool = False):
         """czk_msm_async on device scalars; `out` (numpy, lanes x 18|36) is valid after sync().  stable=True promises
         the scalars stay untouched until then (CZK_MEM_STABLE)."""
-        self._ck(lib().czk_msm_async(self._h, bases._h, _ptr(scalars_ptr), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
+        self._ck(self._L.czk_msm_async(self._h, bases._h, _ptr(scalars_ptr), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
                                      C.c_int(CZK_MEM_DEVICE | (16 if stable else 0)), _ptr(out)))
         return out
 
@@ -244,7 +267,7 @@ class Context:
         n = bases.size // aw
         inf = None if inf is None else np.ascontiguousarray(inf, np.uint8)
         out = np.zeros((lanes, jw), dtype=np.uint64)
-        fn = lib().czk_msm_g1 if group == CZK_G1 else lib().czk_msm_g2
+        fn = self._L.czk_msm_g1 if group == CZK_G1 else self._L.czk_msm_g2
         self._ck(fn(self._h, _ptr(bases), _ptr(inf), _ptr(scalars), C.c_size_t(n), C.c_size_t(lanes), C.c_int(scalar_form), _ptr(out)))
         return out
 
@@ -254,49 +277,49 @@ class Context:
         n = jac.shape[0]
         aff = np.zeros((n, aw), dtype=np.uint64)
         inf = np.zeros(n, dtype=np.uint8)
-        self._ck(lib().czk_jac_to_affine(self._h, C.c_int(group), _ptr(jac), C.c_size_t(n), _ptr(aff), _ptr(inf)))
+        self._ck(self._L.czk_jac_to_affine(self._h, C.c_int(group), _ptr(jac), C.c_size_t(n), _ptr(aff), _ptr(inf)))
         return aff, inf
 
     def jac_add(self, group, a, b):
         jw = 18 if group == CZK_G1 else 36
         a, b = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b, np.uint64)
         out = np.zeros(jw, dtype=np.uint64)
-        self._ck(lib().czk_jac_add(self._h, C.c_int(group), _ptr(a), _ptr(b), _ptr(out)))
+        self._ck(self._L.czk_jac_add(self._h, C.c_int(group), _ptr(a), _ptr(b), _ptr(out)))
         return out
 
     def jac_add_mixed(self, group, a, b_aff, b_inf=False):
         jw = 18 if group == CZK_G1 else 36
         a, b_aff = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(b_aff, np.uint64)
         out = np.zeros(jw, dtype=np.uint64)
-        self._ck(lib().czk_jac_add_mixed(self._h, C.c_int(group), _ptr(a), _ptr(b_aff), C.c_int(int(b_inf)), _ptr(out)))
+        self._ck(self._L.czk_jac_add_mixed(self._h, C.c_int(group), _ptr(a), _ptr(b_aff), C.c_int(int(b_inf)), _ptr(out)))
         return out
 
     def fr_spdz_open(self, shares_ptr, parties: int, n: int, out_value_ptr) -> int:
         """Local part of SpdzFieldShare::batch_open on device buffers; returns the number of failed MAC checks."""
         bad = C.c_uint64(0)
-        self._ck(lib().czk_fr_spdz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(out_value_ptr), C.byref(bad)))
+        self._ck(self._L.czk_fr_spdz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(out_value_ptr), C.byref(bad)))
         return bad.value
 
     def fr_lanes_sum(self, x_ptr, k: int, n: int, out_ptr=None, count_nonzero: bool = False):
         """out[i] = sum of k device vectors; returns the number of non-zero sums when count_nonzero."""
         nz = C.c_uint64(0)
-        self._ck(lib().czk_fr_lanes_sum(self._h, _ptr(x_ptr), C.c_size_t(k), C.c_size_t(n), _ptr(out_ptr), C.byref(nz) if count_nonzero else C.c_void_p(0)))
+        self._ck(self._L.czk_fr_lanes_sum(self._h, _ptr(x_ptr), C.c_size_t(k), C.c_size_t(n), _ptr(out_ptr), C.byref(nz) if count_nonzero else C.c_void_p(0)))
         return nz.value
 
     def fr_spdz_dx(self, value_ptr, mac_ptr, mac_share, out_ptr, n: int):
         """dx_t = mac_share * value - mac on device vectors (share/spdz.rs:176-180); mac_share: (4,) uint64 Montgomery."""
         ms = np.ascontiguousarray(mac_share, np.uint64).reshape(4)
-        self._ck(lib().czk_fr_spdz_dx(self._h, _ptr(value_ptr), _ptr(mac_ptr), _ptr(ms), _ptr(out_ptr), C.c_size_t(n)))
+        self._ck(self._L.czk_fr_spdz_dx(self._h, _ptr(value_ptr), _ptr(mac_ptr), _ptr(ms), _ptr(out_ptr), C.c_size_t(n)))
 
     def share_domain_constants(self, parties: int):
         out = np.zeros((3, 4), dtype=np.uint64)
-        self._ck(lib().czk_share_domain_constants(self._h, C.c_size_t(parties), _ptr(out)))
+        self._ck(self._L.czk_share_domain_constants(self._h, C.c_size_t(parties), _ptr(out)))
         return dict(zip(["size_inv", "group_gen", "group_gen_inv"], out))
 
     def fr_gsz_open(self, shares_ptr, parties: int, n: int, out_value_ptr, degree: int = 0, degrees_ptr=None) -> int:
         """Local part of GszFieldShare::batch_open on device buffers; returns the number of degree-bound violations."""
         bad = C.c_uint64(0)
-        self._ck(lib().czk_fr_gsz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(degrees_ptr), C.c_uint(degree),
+        self._ck(self._L.czk_fr_gsz_open(self._h, _ptr(shares_ptr), C.c_size_t(parties), C.c_size_t(n), _ptr(degrees_ptr), C.c_uint(degree),
                                        _ptr(out_value_ptr), C.byref(bad)))
         return bad.value
 
@@ -308,7 +331,7 @@ class Context:
             coeff = np.ascontiguousarray(coeff, np.uint64)
             m, nnz = row_ptr.size - 1, col_idx.size
         h = C.c_void_p(0)
-        self._ck(lib().czk_r1cs_matrix_register(self._h, _ptr(row_ptr), _ptr(col_idx), _ptr(coeff), C.c_size_t(m), C.c_size_t(nnz),
+        self._ck(self._L.czk_r1cs_matrix_register(self._h, _ptr(row_ptr), _ptr(col_idx), _ptr(coeff), C.c_size_t(m), C.c_size_t(nnz),
                                                 C.c_size_t(n_vars), C.c_int(mem), C.byref(h)))
         return R1csMatrix(self, h, m, n_vars)
 
@@ -319,7 +342,7 @@ class Context:
             z_stride = z.shape[1]
             out_stride = mat.m
             out = np.zeros((lanes, mat.m, 4), dtype=np.uint64)
-        self._ck(lib().czk_r1cs_matvec(self._h, mat._h, _ptr(z), C.c_size_t(z_stride), C.c_size_t(lanes), _ptr(out), C.c_size_t(out_stride), C.c_int(mem)))
+        self._ck(self._L.czk_r1cs_matvec(self._h, mat._h, _ptr(z), C.c_size_t(z_stride), C.c_size_t(lanes), _ptr(out), C.c_size_t(out_stride), C.c_int(mem)))
         return out
 
     def poly_div_linear(self, coeffs, z, lanes: int = 1, n=None, quotient=None, remainder=None, mem=CZK_MEM_HOST):
@@ -332,7 +355,7 @@ class Context:
             remainder = np.zeros((lanes, 4), dtype=np.uint64)
         qp = quotient if not (isinstance(quotient, np.ndarray) and quotient.size == 0) else None
         cp = coeffs if not (isinstance(coeffs, np.ndarray) and coeffs.size == 0) else None
-        self._ck(lib().czk_poly_div_linear(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(qp), _ptr(remainder), C.c_int(mem)))
+        self._ck(self._L.czk_poly_div_linear(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(qp), _ptr(remainder), C.c_int(mem)))
         return quotient, remainder
 
     def fr_prefix_product(self, x, out=None, n=None, mem=CZK_MEM_HOST):
@@ -341,7 +364,7 @@ class Context:
             x = np.ascontiguousarray(x, np.uint64).reshape(-1, 4)
             n = x.shape[0]
             out = np.zeros_like(x)
-        self._ck(lib().czk_fr_prefix_product(self._h, _ptr(x if n else None), C.c_size_t(n), _ptr(out if n else None), C.c_int(mem)))
+        self._ck(self._L.czk_fr_prefix_product(self._h, _ptr(x if n else None), C.c_size_t(n), _ptr(out if n else None), C.c_int(mem)))
         return out
 
     def fr_batch_inverse(self, v, coeff=None, out=None, n=None, mem=CZK_MEM_HOST):
@@ -352,7 +375,7 @@ class Context:
             out = np.zeros_like(v)
         if coeff is not None:
             coeff = np.ascontiguousarray(coeff, np.uint64).reshape(4)
-        self._ck(lib().czk_fr_batch_inverse(self._h, _ptr(v if n else None), C.c_size_t(n), _ptr(coeff), _ptr(out if n else None), C.c_int(mem)))
+        self._ck(self._L.czk_fr_batch_inverse(self._h, _ptr(v if n else None), C.c_size_t(n), _ptr(coeff), _ptr(out if n else None), C.c_int(mem)))
         return out
 
     def fixed_base_points(self, group, k, out=None, n=None, mem=CZK_MEM_HOST):
@@ -361,46 +384,46 @@ class Context:
             k = np.ascontiguousarray(k, np.uint64)
             n = k.size // 4
             out = np.zeros((n, aw), dtype=np.uint64)
-        self._ck(lib().czk_fixed_base_points(self._h, C.c_int(group), _ptr(k), C.c_size_t(n), _ptr(out), C.c_int(mem)))
+        self._ck(self._L.czk_fixed_base_points(self._h, C.c_int(group), _ptr(k), C.c_size_t(n), _ptr(out), C.c_int(mem)))
         return out
 
     # ---- measurement hooks ------------------------------------------------------------------------
     def profile_enable(self, on=True):
-        self._ck(lib().czk_profile_enable(self._h, C.c_int(1 if on else 0)))
+        self._ck(self._L.czk_profile_enable(self._h, C.c_int(1 if on else 0)))
 
     def profile_reset(self):
-        self._ck(lib().czk_profile_reset(self._h))
+        self._ck(self._L.czk_profile_reset(self._h))
 
     def profile_read(self, kernel: str):
         ms, n = C.c_double(0), C.c_uint64(0)
-        self._ck(lib().czk_profile_read(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
+        self._ck(self._L.czk_profile_read(self._h, kernel.encode(), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def profile_intervals(self, kernel: str):
         """(start, stop) in ms after this context's profile origin of every bracket of `kernel`: numpy array (n, 2)"""
         n = C.c_size_t(0)
-        self._ck(lib().czk_profile_intervals(self._h, kernel.encode(), None, None, C.c_size_t(0), C.byref(n)))
+        self._ck(self._L.czk_profile_intervals(self._h, kernel.encode(), None, None, C.c_size_t(0), C.byref(n)))
         a, b = np.zeros(n.value, np.float64), np.zeros(n.value, np.float64)
         if n.value:
-            self._ck(lib().czk_profile_intervals(self._h, kernel.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
+            self._ck(self._L.czk_profile_intervals(self._h, kernel.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), b.ctypes.data_as(C.POINTER(C.c_double)),
                                                  C.c_size_t(n.value), C.byref(n)))
         return np.stack([a, b], axis=1)
 
     def profile_base_offset(self, other) -> float:
         """other's profile origin minus this context's, in ms (both after profile_reset)"""
         ms = C.c_double(0)
-        self._ck(lib().czk_profile_base_offset(self._h, other._h, C.byref(ms)))
+        self._ck(self._L.czk_profile_base_offset(self._h, other._h, C.byref(ms)))
         return ms.value
 
     # ---- Groth16 witness map (device buffers) ------------------------------------------------------
     def witness_map_pre(self, a_ptr, b_ptr, log_d, lanes, a_len=None, b_len=None):
         """a_len / b_len: evaluations present in each lane (default D); the rest of the domain counts as zero."""
         d = 1 << log_d
-        self._ck(lib().czk_witness_map_pre(self._h, _ptr(a_ptr), C.c_size_t(d if a_len is None else a_len), _ptr(b_ptr),
+        self._ck(self._L.czk_witness_map_pre(self._h, _ptr(a_ptr), C.c_size_t(d if a_len is None else a_len), _ptr(b_ptr),
                                            C.c_size_t(d if b_len is None else b_len), C.c_uint(log_d), C.c_size_t(lanes)))
 
     def witness_map_post(self, ab_ptr, c_ptr, log_d, lanes, c_len=None):
-        self._ck(lib().czk_witness_map_post(self._h, _ptr(ab_ptr), _ptr(c_ptr), C.c_size_t((1 << log_d) if c_len is None else c_len),
+        self._ck(self._L.czk_witness_map_post(self._h, _ptr(ab_ptr), _ptr(c_ptr), C.c_size_t((1 << log_d) if c_len is None else c_len),
                                             C.c_uint(log_d), C.c_size_t(lanes)))
 
 
@@ -409,31 +432,31 @@ class Lanes:
 
     def __init__(self, ctx: "Context", handle):
         self.ctx, self._h = ctx, handle
-        self.lanes, self.len = int(lib().czk_lanes_count(handle)), int(lib().czk_lanes_len(handle))
+        self.lanes, self.len = int(self.ctx._L.czk_lanes_count(handle)), int(self.ctx._L.czk_lanes_len(handle))
 
     def ptr(self, lane: int = 0, elem: int = 0) -> int:
         """Device address of one element (0 when outside the allocation): use with CZK_MEM_DEVICE."""
-        return lib().czk_lanes_data(self._h, C.c_size_t(lane), C.c_size_t(elem)) or 0
+        return self.ctx._L.czk_lanes_data(self._h, C.c_size_t(lane), C.c_size_t(elem)) or 0
 
     def upload(self, host, lane: int = 0, elem: int = 0):
         host = np.ascontiguousarray(host, np.uint64)
-        self.ctx._ck(lib().czk_lanes_upload(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(host if host.size else None), C.c_size_t(host.size // 4)))
+        self.ctx._ck(self.ctx._L.czk_lanes_upload(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(host if host.size else None), C.c_size_t(host.size // 4)))
 
     def download(self, lane: int = 0, elem: int = 0, n: int | None = None) -> np.ndarray:
         n = self.len - elem if n is None else n
         out = np.zeros((n, 4), dtype=np.uint64)
-        self.ctx._ck(lib().czk_lanes_download(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(out if n else None), C.c_size_t(n)))
+        self.ctx._ck(self.ctx._L.czk_lanes_download(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(out if n else None), C.c_size_t(n)))
         return out
 
     def copy_from(self, src: "Lanes", n: int, lane: int = 0, elem: int = 0, src_lane: int = 0, src_elem: int = 0):
-        self.ctx._ck(lib().czk_lanes_copy(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), src._h, C.c_size_t(src_lane), C.c_size_t(src_elem), C.c_size_t(n)))
+        self.ctx._ck(self.ctx._L.czk_lanes_copy(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), src._h, C.c_size_t(src_lane), C.c_size_t(src_elem), C.c_size_t(n)))
 
     def zero(self, n: int, lane: int = 0, elem: int = 0):
-        self.ctx._ck(lib().czk_lanes_zero(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), C.c_size_t(n)))
+        self.ctx._ck(self.ctx._L.czk_lanes_zero(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), C.c_size_t(n)))
 
     def free(self):
         if self._h:
-            lib().czk_lanes_free(self._h)
+            self.ctx._L.czk_lanes_free(self._h)
             self._h = C.c_void_p(0)
 
     def __del__(self):
@@ -451,7 +474,7 @@ class R1csMatrix:
 
     def release(self):
         if self._h:
-            lib().czk_r1cs_matrix_release(self._h)
+            self.ctx._L.czk_r1cs_matrix_release(self._h)
             self._h = C.c_void_p(0)
 
     def __del__(self):
@@ -468,12 +491,12 @@ class Bases:
         self.ctx, self._h, self.group, self.n = ctx, handle, group, n
 
     def __len__(self):
-        return int(lib().czk_bases_len(self._h))
+        return int(self.ctx._L.czk_bases_len(self._h))
 
     def layout(self):
         """(window width c, number of windows) chosen at registration."""
         c, w = C.c_uint(0), C.c_uint(0)
-        lib().czk_bases_layout(self._h, C.byref(c), C.byref(w))
+        self.ctx._L.czk_bases_layout(self._h, C.byref(c), C.byref(w))
         return c.value, w.value
 
     def windows(self) -> int:
@@ -481,27 +504,27 @@ class Bases:
 
     def arith(self) -> int:
         """0 = XYZZ saturated, 1 = XYZZ unsaturated, 2 = twisted Edwards (czk_bases_arith)"""
-        return int(lib().czk_bases_arith(self._h))
+        return int(self.ctx._L.czk_bases_arith(self._h))
 
     def check_subgroup(self) -> int:
         """Number of registered bases outside the prime-order subgroup (czk_bases_check_subgroup: [r] P == infinity on the GPU)."""
         bad = C.c_size_t(0)
-        self.ctx._ck(lib().czk_bases_check_subgroup(self.ctx._h, self._h, C.byref(bad)))
+        self.ctx._ck(self.ctx._L.czk_bases_check_subgroup(self.ctx._h, self._h, C.byref(bad)))
         return int(bad.value)
 
     def layout_for(self, n_scalars: int):
         """(c, windows) an MSM of n_scalars scalars over these bases runs with (czk_bases_layout_for)."""
         c, w = C.c_uint(0), C.c_uint(0)
-        lib().czk_bases_layout_for(self._h, C.c_size_t(n_scalars), C.byref(c), C.byref(w))
+        self.ctx._L.czk_bases_layout_for(self._h, C.c_size_t(n_scalars), C.byref(c), C.byref(w))
         return c.value, w.value
 
     def prepare(self, n_scalars: int):
         """Builds the table set MSMs of n_scalars scalars will use, up front (czk_bases_prepare)."""
-        self.ctx._ck(lib().czk_bases_prepare(self.ctx._h, self._h, C.c_size_t(n_scalars)))
+        self.ctx._ck(self.ctx._L.czk_bases_prepare(self.ctx._h, self._h, C.c_size_t(n_scalars)))
 
     def release(self):
         if self._h:
-            lib().czk_bases_release(self._h)
+            self.ctx._L.czk_bases_release(self._h)
             self._h = C.c_void_p(0)
 
     def __del__(self):

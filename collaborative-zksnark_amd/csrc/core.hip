@@ -1,5 +1,6 @@
 // core.hip -- context lifecycle, error reporting, workspace management and the O(1) host-side group
 // helpers of libczk_hip.so.
+#include <string.h>
 #include "czk_internal.h"
 
 #include <stdlib.h>
@@ -258,7 +259,6 @@ extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
     if (hipSetDevice(device) != hipSuccess) return CZK_ERR_HIP;
     czk_ctx* c = new czk_ctx();
     c->device = device;
-    c->ntt_gen1 = getenv("CZK_NTT_GEN1") != nullptr;
     if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
     } else {
@@ -273,6 +273,17 @@ extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
         c->num_cu = prop.multiProcessorCount;
         c->lds_per_block = prop.sharedMemPerBlock;
     }
+    #ifdef CZK_LAB
+    // lab build only: the measurement tools' CZK_* environment switches, translated into options (the product library reads no environment)
+    {
+        static const char* const ENV[][2] = {{"CZK_NTT_GEN1", "ntt_gen1"}, {"CZK_SORT_ONEPASS", "msm_sort_onepass"}, {"CZK_REDUCE_SAT", "msm_reduce_sat"},
+            {"CZK_REDUCE_SAT_G2", "msm_reduce_sat_g2"}, {"CZK_G2_MODE", "msm_g2_mode"}, {"CZK_MSM_AFFINE", "msm_affine_rounds"}, {"CZK_MSM_SLOTS", "msm_slots"},
+            {"CZK_STREAM_PRIO", "msm_stream_priority"}, {"CZK_MSM_SAT", "msm_sat"}, {"CZK_MSM_SAT_G2", "msm_sat_g2"}, {"CZK_MSM_NO_TE", "msm_no_te"},
+            {"CZK_MSM_FIXED_C", "msm_fixed_c"}, {"CZK_MSM_C_G1", "msm_window_g1"}, {"CZK_MSM_C_G2", "msm_window_g2"}};
+        for (auto& e : ENV)
+            if (const char* v = getenv(e[0])) (void)czk_ctx_set_option(c, e[1], atol(v) ? atol(v) : (v[0] == '0' ? 0 : 1));
+    }
+#endif
     *out = c;
     return CZK_OK;
 }
@@ -313,6 +324,61 @@ extern "C" void czk_ctx_destroy(czk_ctx* ctx) {
     if (ctx->prof_base) (void)hipEventDestroy(ctx->prof_base);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// ---- options ------------------------------------------------------------------------------------------------------------------
+// The product library reads NO environment variables: what used to be CZK_* switches are explicit per-context options.  Names of the
+// second group select kernels that only the lab build (-DCZK_LAB, libczk_hip_lab.so) contains.
+namespace {
+struct OptDesc {
+    const char* name;
+    long lo, hi;
+    bool before_pipeline;   // must be set before the context's first MSM (streams are created then)
+    void (*set)(czk_ctx*, long);
+};
+const OptDesc OPTIONS[] = {
+    {"msm_slots", 1, czk_ctx::MSM_SLOTS, true, [](czk_ctx* c, long v) { c->msm_slots_in_use = (int)v; }},
+    {"msm_stream_priority", 0, 2, true, [](czk_ctx* c, long v) { c->msm_stream_prio = (int)v; }},
+    {"msm_sort_onepass", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sort_onepass = v != 0; }},
+    {"msm_fixed_c", 0, 1, false, [](czk_ctx* c, long v) { c->msm_fixed_c = v != 0; }},
+    {"msm_window_g1", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g1 = (unsigned)v; }},
+    {"msm_window_g2", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g2 = (unsigned)v; }},
+    {"ntt_gen1", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_gen1 = v != 0; }},
+#ifdef CZK_LAB
+    {"msm_affine_rounds", 0, 3, false, [](czk_ctx* c, long v) { c->msm_affine_rounds = (unsigned)v; }},
+    {"msm_reduce_sat", 0, 1, false, [](czk_ctx* c, long v) { c->msm_reduce_sat = v != 0; }},
+    {"msm_reduce_sat_g2", 0, 1, false, [](czk_ctx* c, long v) { c->msm_reduce_sat_g2 = v != 0; }},
+    {"msm_g2_mode", 0, 2, false, [](czk_ctx* c, long v) { c->msm_g2_mode = (int)v; }},
+    {"msm_sat", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sat = v != 0; }},
+    {"msm_sat_g2", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sat_g2 = v != 0; }},
+    {"msm_no_te", 0, 1, false, [](czk_ctx* c, long v) { c->msm_no_te = v != 0; }},
+#endif
+};
+}  // namespace
+extern "C" int czk_ctx_set_option(czk_ctx* ctx, const char* name, long value) {
+    if (!ctx || !name) return CZK_ERR_ARG;
+    for (const OptDesc& o : OPTIONS) {
+        if (strcmp(o.name, name) != 0) continue;
+        if (value < o.lo || value > o.hi || (!strncmp(name, "msm_window", 10) && value != 0 && value < 8))
+            return set_err(ctx, CZK_ERR_ARG, std::string("czk_ctx_set_option: value out of range for ") + name);
+        if (o.before_pipeline && ctx->s_sort) return set_err(ctx, CZK_ERR_ARG, std::string("czk_ctx_set_option: ") + name + " must be set before the context's first MSM");
+        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));   // options take effect between calls, never under enqueued work
+        CZK_TRY(msm_pipeline_sync(ctx));
+        o.set(ctx, value);
+        return CZK_OK;
+    }
+#ifdef CZK_LAB
+    return set_err(ctx, CZK_ERR_ARG, std::string("czk_ctx_set_option: unknown option \"") + name + "\" (lab build)");
+#else
+    return set_err(ctx, CZK_ERR_ARG, std::string("czk_ctx_set_option: unknown option \"") + name + "\" (product build: the switches of the rejected variants exist in libczk_hip_lab.so only)");
+#endif
+}
+extern "C" int czk_build_is_lab(void) {
+#ifdef CZK_LAB
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 extern "C" int czk_ctx_sync(czk_ctx* ctx) {

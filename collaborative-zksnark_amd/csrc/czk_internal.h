@@ -94,13 +94,20 @@ struct czk_ctx {
     char* msm_pinned = nullptr;
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
     std::vector<czk::MsmPending> msm_pending;
-    unsigned msm_affine_rounds = 0;  // CZK_MSM_AFFINE=R at pipeline creation: R rounds of batched-affine pair additions in front of the G1 bucket accumulation
-    bool msm_reduce_sat = false;     // CZK_REDUCE_SAT=1 at pipeline creation: buckets and their reduction in the saturated form (A/B runs)
-    bool msm_reduce_sat_g2 = false;  // CZK_REDUCE_SAT_G2=1: the same for G2 only
-    int msm_g2_mode = 0;             // CZK_G2_MODE: 0 = single-lane G2 accumulate kernel (k_accumulate_u2, adopted), 1 = lane pairs <128, 2> (faster alone, slower in the pipeline), 2 = lane pairs <512, 3> + LDS-limited occupancy
-    bool msm_sort_onepass = false;   // CZK_SORT_ONEPASS=1 at pipeline creation: the single-pass digit sort (kept as the > 2048-partition fallback)
+    // ---- czk_ctx_set_option (core.hip).  The product library knows the first group only; the second group selects kernels that exist in the
+    // lab build alone (libczk_hip_lab.so, -DCZK_LAB: the measured-and-rejected variants of EXPERIMENTS.md) and is fixed at its default otherwise.
+    bool msm_sort_onepass = false;   // "msm_sort_onepass": the single-pass digit sort for every call (it is the > 2048-partition fallback anyway)
+    bool msm_fixed_c = false;        // "msm_fixed_c": keys registered from now on keep their own window width for short calls (no secondary table sets)
+    unsigned msm_c_g1 = 0, msm_c_g2 = 0;   // "msm_window_g1" / "msm_window_g2": primary window width of keys registered from now on (0 = cost model)
+    int msm_stream_prio = 0;         // "msm_stream_priority": 1 = sort / reduce streams above the accumulate stream, 2 = the reverse (before the first MSM)
+    unsigned msm_affine_rounds = 0;  // lab "msm_affine_rounds": R rounds of batched-affine pair additions in front of the G1 bucket accumulation
+    bool msm_reduce_sat = false;     // lab "msm_reduce_sat": buckets and their reduction in the saturated form
+    bool msm_reduce_sat_g2 = false;  // lab "msm_reduce_sat_g2": the same for G2 only
+    int msm_g2_mode = 0;             // lab "msm_g2_mode": 0 = single-lane G2 accumulate kernel (k_accumulate_u2, adopted), 1 = lane pairs <128, 2>, 2 = lane pairs <512, 3> + LDS-limited occupancy
+    bool msm_sat = false, msm_sat_g2 = false;   // lab "msm_sat" / "msm_sat_g2": keys registered from now on keep saturated tables and accumulate kernels
+    bool msm_no_te = false;          // lab "msm_no_te": G1 keys registered from now on keep the XYZZ kernels (what CZK_MEM_ANY_POINTS does per key)
     unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
-    bool ntt_gen1 = false;           // CZK_NTT_GEN1=1 at context creation: first-generation NTT passes for every size (A/B runs)
+    bool ntt_gen1 = false;           // "ntt_gen1": first-generation NTT passes (ntt.hip, the small-domain kernels) for every size
     bool profiling = false;
     std::map<std::string, czk::ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
@@ -297,7 +304,7 @@ void launch_accumulate_g1_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const 
                             size_t sorted_stride, u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets);
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords);
 void launch_convert_from_u(hipStream_t st, u64* pts, size_t n_coords);   // the inverse: table coordinates back to the saturated Montgomery form
-// batched-affine pre-reduction of the bucket lists (msm_aff.h; G1)
+// batched-affine pre-reduction of the bucket lists (lab/msm_aff.h; G1; lab build only -- the struct stays so that msm_enqueue reads the same either way)
 struct AffArgs {
     unsigned rounds = 0, lanes = 0, n_parts = 0, part_shift = 0, part_log = 0;
     size_t B = 0, sorted_stride = 0, S[3] = {0, 0, 0};

@@ -661,7 +661,12 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
         CZK_HIP(ctx, hipFree(jac));
         CZK_HIP(ctx, hipFree(scr));
     }
-    if (GT<F>::AW == 12 && b->te_wanted && !getenv("CZK_MSM_SAT") && !getenv("CZK_MSM_NO_TE") && !getenv("CZK_MSM_AFFINE")) {
+#ifdef CZK_LAB   // keys keep saturated tables / the XYZZ kernels on request (A/B runs of the rejected variants)
+    const bool keep_sat = ctx->msm_sat || (GT<F>::AW != 12 && ctx->msm_sat_g2), no_te = ctx->msm_sat || ctx->msm_no_te || ctx->msm_affine_rounds > 0;
+#else
+    constexpr bool keep_sat = false, no_te = false;
+#endif
+    if (GT<F>::AW == 12 && b->te_wanted && !no_te) {
         // G1 bases in the prime-order subgroup: window tables as twisted Edwards niels entries (te.h), 7M unified mixed additions
         u64* te = nullptr;
         bool ok = false;
@@ -683,9 +688,9 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
             return CZK_OK;
         }
     }
-    if (!getenv("CZK_MSM_SAT") && (GT<F>::AW == 12 || !getenv("CZK_MSM_SAT_G2"))) {
-        // window tables go to the unsaturated residue system of fqu.h (infinity flags are unaffected); CZK_MSM_SAT=1
-        // (or CZK_MSM_SAT_G2=1 for G2 only) keeps the saturated kernels for A/B runs
+    if (!keep_sat) {
+        // window tables go to the unsaturated residue system of fqu.h (infinity flags are unaffected); the lab build's "msm_sat" /
+        // "msm_sat_g2" options keep the saturated kernels for A/B runs
         launch_convert_to_u(ctx->stream, b->pts, (size_t)W * n * (GT<F>::AW / 6));
         CZK_HIP(ctx, hipGetLastError());
         CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -847,7 +852,12 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     // G1 buckets stay in the unsaturated residue system through the reduction (k_reduce_*_u) unless the batched-affine rounds
     // (which finish on saturated level points) or CZK_REDUCE_SAT ask for the saturated form
     const int te = b->te ? 1 : 0;   // twisted Edwards tables and buckets (te.h): unified additions, no exception handling at all
-    const int ub = (te || (b->unsat && !(GT<F>::AW == 12 ? ctx->msm_reduce_sat || (ctx->msm_affine_rounds > 0 && size > 0) : ctx->msm_reduce_sat_g2))) ? 1 : 0;
+#ifdef CZK_LAB
+    const int ub = (te || (b->unsat && !(GT<F>::AW == 12 ? ctx->msm_reduce_sat || (ctx->msm_affine_rounds > 0 && size > 0) : ctx->msm_reduce_sat || ctx->msm_reduce_sat_g2))) ? 1 : 0;
+#else
+    const int ub = 1;   // product build: every key's tables are in the unsaturated residue system, buckets stay in u-form through the reduction
+#endif
+#ifdef CZK_LAB
     if (GT<F>::AW == 12 && b->unsat && !te && ctx->msm_affine_rounds > 0 && size > 0) {
         aff.rounds = ctx->msm_affine_rounds;
         aff.lanes = (unsigned)lanes;
@@ -860,12 +870,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         for (unsigned r = 0; r < aff.rounds; r++) need_aff += lanes * aff.S[r] * (8 + 1) + 512;
         need_aff += lanes * aff.S[0] * 128 + (aff.rounds > 1 ? lanes * aff.S[1] * 128 : 0) + 4 * lanes * B * 4 + aff_scratch_bytes(ctx) + (1 << 16);
     }
+#endif
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red || slot.ws_aff.bytes < need_aff) {
         CZK_TRY(msm_pipeline_sync(ctx));
         CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
         CZK_TRY(ensure_buf(ctx, slot.ws_red, need_red));
         if (need_aff) CZK_TRY(ensure_buf(ctx, slot.ws_aff, need_aff));
     }
+#ifdef CZK_LAB
     if (aff.rounds) {
         Bump ba{(char*)slot.ws_aff.p};
         for (unsigned r = 0; r < aff.rounds; r++) {
@@ -880,6 +892,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         }
         aff.scratch = ba.take<char>(aff_scratch_bytes(ctx));
     }
+#endif
     Bump bs{(char*)slot.ws_sort.p};
     u32* digits = bs.take<u32>(lanes * W * size);
     u32* sorted = bs.take<u32>(lanes * W * size);
@@ -956,12 +969,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
         hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
         hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
+#ifdef CZK_LAB
         if (aff.rounds) {
             aff.sorted = sorted;
             aff.offsets = offsets;
             aff.counts = counts;
             launch_affine_build_g1(ss, aff);
         }
+#endif
         if (b->unsat && !te) {
             // clear the dirty flags / exception list here rather than on the accumulate stream (the critical one); they live
             // in the slot's reduce workspace, which the slot's previous reduction may still be using
@@ -979,13 +994,20 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         launch_accumulate_g1_te(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     } else if (b->unsat) {
         // (these launchers bracket their main kernel with the "msm_accumulate_g{1,2}" profiling scope themselves)
+#ifdef CZK_LAB
         if (aff.rounds) launch_affine_accumulate_g1(ctx, sa, aff, tv.pts, perm, buckets, dirty);
-        else if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
+        else
+#endif
+        if (GT<F>::AW == 12) launch_accumulate_g1_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
         else launch_accumulate_g2_u(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
     } else {
+#ifdef CZK_LAB   // saturated tables ("msm_sat"): the round-1 kernels
         ProfScope ps(ctx, GT<F>::AW == 12 ? "msm_accumulate_g1" : "msm_accumulate_g2", sa);
         if (GT<F>::AW == 12) launch_accumulate_g1(sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
         else launch_accumulate_g2(sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
+#else
+        return set_err(ctx, CZK_ERR_ARG, "bases with saturated window tables: not part of the product build");
+#endif
     }
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
@@ -999,9 +1021,12 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                          heavy_list, heavy_partials, heavy_cap, b->unsat ? 1 : 0, ub);
     if (b->unsat && !te) {
         // dirty buckets / deferred points (normally none): on the reduce stream, so the accumulate stream goes straight on
+#ifdef CZK_LAB
         if (aff.rounds)
             launch_accumulate_g1_u_fixup_lvl(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, aff.lvl[(aff.rounds - 1) & 1]);
-        else if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
+        else
+#endif
+        if (GT<F>::AW == 12) launch_accumulate_g1_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
         else launch_accumulate_g2_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
@@ -1016,7 +1041,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             if (n_in <= 1024) {   // latency-bound from here: bit-sum tree reductions instead of more levels
                 if (GT<F>::AW != 12) launch_reduce_tail_g2(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes, ub);
                 else if (ub) launch_reduce_tail_g1_u(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes, te);
+#ifdef CZK_LAB
                 else launch_reduce_tail_g1(sr, P, E, n_in, level * logL, tail_scratch, tail_sums, result, (unsigned)lanes);
+#endif
                 finished = true;
                 break;
             }
@@ -1024,7 +1051,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             u64 *Po = lv[flip * 2], *Eo = lv[flip * 2 + 1];
             if (GT<F>::AW != 12) launch_reduce_level_g2(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes, ub);
             else if (ub) launch_reduce_level_g1_u(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes, te);
+#ifdef CZK_LAB
             else launch_reduce_level_g1(sr, P, E, n_in, L, level * logL, Po, Eo, n_out, (unsigned)lanes);
+#endif
             P = Po;
             E = Eo;
             n_in = n_out;
@@ -1034,7 +1063,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         if (finished) {
         } else if (GT<F>::AW != 12) launch_finish_g2(sr, P, E, lanes, result, ub);
         else if (ub) launch_finish_g1_u(sr, P, E, lanes, result, te);
+#ifdef CZK_LAB
         else launch_finish_g1(sr, P, E, lanes, result);
+#endif
     }
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipMemcpyAsync(pinned, result, out_bytes, hipMemcpyDeviceToHost, sr));
@@ -1054,22 +1085,10 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 int msm_pipeline_init(czk_ctx* ctx) {
     if (ctx->s_sort) return CZK_OK;
     // (stream priorities for the short sort / reduce stages were measured: no gain, so all three are equal)
-    ctx->msm_sort_onepass = getenv("CZK_SORT_ONEPASS") != nullptr;   // read once, not per enqueue
-    ctx->msm_reduce_sat = getenv("CZK_REDUCE_SAT") != nullptr;
-    ctx->msm_reduce_sat_g2 = ctx->msm_reduce_sat || getenv("CZK_REDUCE_SAT_G2") != nullptr;
-    if (const char* e = getenv("CZK_G2_MODE")) ctx->msm_g2_mode = atoi(e);
-    if (const char* e = getenv("CZK_MSM_AFFINE")) {
-        int v = atoi(e);
-        if (v >= 0 && v <= 3) ctx->msm_affine_rounds = (unsigned)v;
-    }
-    if (const char* e = getenv("CZK_MSM_SLOTS")) {
-        int v = atoi(e);
-        if (v >= 1 && v <= czk_ctx::MSM_SLOTS) ctx->msm_slots_in_use = v;
-    }
-    if (const char* e = getenv("CZK_STREAM_PRIO")) {   // measurement knob: 1 = sort / reduce streams above the accumulate stream, 2 = the reverse
+    if (ctx->msm_stream_prio) {   // option "msm_stream_priority": 1 = sort / reduce streams above the accumulate stream, 2 = the reverse
         int least = 0, greatest = 0;
         CZK_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
-        const bool rev = atoi(e) == 2;
+        const bool rev = ctx->msm_stream_prio == 2;
         CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_sort, hipStreamNonBlocking, rev ? least : greatest));
         CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_acc, hipStreamNonBlocking, rev ? greatest : least));
         CZK_HIP(ctx, hipStreamCreateWithPriority(&ctx->s_red, hipStreamNonBlocking, rev ? least : greatest));
@@ -1189,12 +1208,10 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     b->split = no_tables;
     b->te_wanted = !any_points;
     b->check_wanted = check;
-    b->per_call_width = getenv("CZK_MSM_FIXED_C") == nullptr;
+    b->per_call_width = !ctx->msm_fixed_c;
     b->c = no_tables ? choose_c_split(n) : choose_c(n);
-    if (const char* e = getenv(group == CZK_G1 ? "CZK_MSM_C_G1" : "CZK_MSM_C_G2")) {   // measurement knob: the primary table set's width
-        const int v = atoi(e);
-        if (!no_tables && v >= 8 && v <= 22) b->c = (unsigned)v;
-    }
+    if (const unsigned v = group == CZK_G1 ? ctx->msm_c_g1 : ctx->msm_c_g2)   // option "msm_window_g1" / "_g2": the primary table set's width
+        if (!no_tables && v >= 8 && v <= 22) b->c = v;
     b->W = num_windows(b->c);
     const u64* pts_dev = bases;
     const uint8_t* inf_dev = inf;

@@ -3,14 +3,18 @@
 #include "fqu.h"
 #include "te.h"
 #include "msm_acc.h"
-#include "msm_aff.h"
+#ifdef CZK_LAB
+#include "lab/msm_aff.h"
+#endif
 
 namespace czk {
+#ifdef CZK_LAB   // saturated tables (lab option "msm_sat"): the round-1 kernel
 void launch_accumulate_g1(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B,
                           size_t sorted_stride, u64* buckets, unsigned lanes) {
     hipLaunchKernelGGL(k_accumulate<Fq>, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
                        sorted_stride, buckets);
 }
+#endif
 // The unsaturated accumulation is issued in three pieces so that only the dominant kernel occupies the accumulate
 // stream: `prepare` (clear the dirty flags + exception list; sort stream), the kernel itself, `fixup` (recompute dirty
 // buckets, add deferred points; reduce stream, ahead of the bucket reduction).
@@ -36,7 +40,8 @@ void launch_accumulate_g1_u_fixup(hipStream_t st, const u64* pts, const u32* sor
                        sorted_stride, buckets, dirty, ubuckets);
     hipLaunchKernelGGL(k_accumulate_u_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP, ubuckets);
 }
-// ---- batched-affine pre-reduction (msm_aff.h) ----------------------------------------------------------------------------
+#ifdef CZK_LAB
+// ---- batched-affine pre-reduction (lab/msm_aff.h; measured slower, EXPERIMENTS.md) --------------------------------------------
 // Slot counts of the levels: S_r = round_up_64((S_{r-1} + B + 1) / 2 + 1) with S_0 = entries per lane.
 void aff_plan(size_t total0, size_t B, unsigned rounds, size_t* S) {
     size_t prev = total0;
@@ -90,12 +95,14 @@ void launch_accumulate_g1_u_fixup_lvl(hipStream_t st, const u64* pts, const u32*
                        sorted_stride, buckets, dirty, 0);
     hipLaunchKernelGGL(k_accumulate_u_lvl_cleanup, dim3(1), dim3(64), 0, st, (const uint4*)lvl, B, buckets, dirty, exc, exc + 4, G1_EXC_CAP);
 }
+#endif   // CZK_LAB
 void launch_convert_to_u(hipStream_t st, u64* pts, size_t n_coords) {
     hipLaunchKernelGGL(k_convert_to_u, dim3((unsigned)((n_coords + 255) / 256)), dim3(256), 0, st, pts, n_coords);
 }
 void launch_convert_from_u(hipStream_t st, u64* pts, size_t n_coords) {
     hipLaunchKernelGGL(k_convert_from_u, dim3((unsigned)((n_coords + 255) / 256)), dim3(256), 0, st, pts, n_coords);
 }
+#ifdef CZK_LAB   // bucket reduction in the saturated form (lab option "msm_reduce_sat")
 void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
                             unsigned lanes) {
     hipLaunchKernelGGL((k_reduce_level<Fq, 24, 0>), dim3((unsigned)(((n_out << 0) + 127) / 128), lanes), dim3(128), 0, st, P, E, n_in, L, scale_dbl, Po, Eo, n_out);
@@ -108,7 +115,8 @@ void launch_reduce_tail_g1(hipStream_t st, const u64* P, const u64* E, size_t n_
     hipLaunchKernelGGL((k_reduce_tail_sums<Fq, 24, 0>), dim3(TAIL_BLOCKS, lanes), dim3(TAIL_THREADS), 0, st, P, E, n_in, scratch, sums);
     hipLaunchKernelGGL((k_reduce_tail_finish<Fq, 24, 0>), dim3((lanes + 63) / 64), dim3(64), 0, st, sums, scale_dbl, (size_t)lanes, out);
 }
-// the same three steps of the bucket reduction on u-form buckets (msm_acc.h k_reduce_*_p); te = twisted Edwards buckets (te.h)
+#endif   // CZK_LAB
+// the three steps of the bucket reduction on u-form buckets (msm_acc.h k_reduce_*_p); te = twisted Edwards buckets (te.h)
 void launch_reduce_level_g1_u(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,
                               unsigned lanes, int te) {
     const dim3 grid((unsigned)((n_out + 127) / 128), lanes);

@@ -16,7 +16,9 @@
 // computes G1 MSMs in Jacobian coordinates (algebra/ec/src/msm/variable_base.rs:12-106); results are compared in affine, as ever.
 #pragma once
 #include "fqu.h"
-#include "fqu_il.h"
+#ifdef CZK_TE_IL   // A/B builds of the lab library only
+#include "lab/fqu_il.h"
+#endif
 #include "te_constants.inc"
 
 namespace czk {
@@ -74,6 +76,7 @@ __device__ __forceinline__ void teu_madd(TEU& a, const FqU& ym, const FqU& yp, c
     }
     teu_finish(a, fqu_sub_lazy<4>(B, A), F, G, fqu_add_lazy(B, A));
 }
+#ifdef CZK_TE_IL
 // The same addition with its products run side by side (fqu_il.h): A, B, C as three interleaved chains, then the four output
 // products as four.  Same values, same instruction count; the lane has 3 - 4 multiply-add chains in flight instead of one.
 __device__ __forceinline__ void teu_madd_il(TEU& a, const FqU& ym, const FqU& yp, const FqU& k2) {
@@ -103,6 +106,7 @@ __device__ __forceinline__ void teu_madd_il(TEU& a, const FqU& ym, const FqU& yp
     a.z = o[2];
     a.t = o[3];
 }
+#endif
 // a += b, both extended (add-2008-hwcd-3, 8M + one multiplication by the constant 2 D)
 __device__ __forceinline__ void teu_add(TEU& a, const TEU& b) {
     const FqU A = fqu_mul(fqu_sub_lazy<8>(a.y, a.x), fqu_sub_lazy<8>(b.y, b.x));

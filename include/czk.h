@@ -90,6 +90,18 @@ void czk_ctx_destroy(czk_ctx* ctx);
 int czk_ctx_sync(czk_ctx* ctx);
 const char* czk_last_error(const czk_ctx* ctx);
 const char* czk_version(void);
+/* Tuning options of one context.  The library reads NO environment variables: everything a caller may select is named here.
+ *   "msm_slots" 1..4            depth of the MSM pipeline's workspace ring (default 4)                          [before the first MSM]
+ *   "msm_stream_priority" 0..2  0 = equal priorities (default), 1 = sort / reduce streams above accumulate, 2 = the reverse [before the first MSM]
+ *   "msm_sort_onepass" 0/1      single-pass digit sort for every call (default: only beyond 2048 partitions)
+ *   "msm_fixed_c" 0/1           keys registered AFTERWARDS keep their own window width for short calls (no secondary table sets)
+ *   "msm_window_g1" / "msm_window_g2" 0, 8..22   primary window width of keys registered AFTERWARDS (0 = the cost model, default)
+ *   "ntt_gen1" 0/1              first-generation NTT passes (the small-domain kernels) for every size
+ * Any other name is CZK_ERR_ARG.  The call drains the context's enqueued work first, so an option never changes under a running proof.
+ * (libczk_hip_lab.so, the -DCZK_LAB build of the same sources, additionally knows the switches of the measured-and-rejected kernel
+ * variants it alone contains -- EXPERIMENTS.md; czk_build_is_lab() tells the two apart.) */
+int czk_ctx_set_option(czk_ctx* ctx, const char* name, long value);
+int czk_build_is_lab(void);
 
 /* ---- device-resident share lanes ---------------------------------------------------------------------- */
 /* A caller without a HIP allocator of its own (the Rust shim, a C++ host) keeps share vectors on the GPU between calls through

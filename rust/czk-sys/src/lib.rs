@@ -1,7 +1,7 @@
 //! Raw bindings of `libczk_hip.so` -- GENERATED from include/czk.h by tools/gen_rust_sys.py; do not edit.
 //! One `extern "C"` declaration per C declaration; constants mirror the C enums.  Safe wrappers live in the `czk` crate.
 #![allow(non_camel_case_types)]
-use std::os::raw::{c_char, c_int, c_uint, c_void};
+use std::os::raw::{c_char, c_int, c_long, c_uint, c_void};
 
 #[repr(C)]
 pub struct czk_ctx {
@@ -50,6 +50,8 @@ extern "C" {
     pub fn czk_ctx_sync(ctx: *mut czk_ctx) -> c_int;
     pub fn czk_last_error(ctx: *const czk_ctx) -> *const c_char;
     pub fn czk_version() -> *const c_char;
+    pub fn czk_ctx_set_option(ctx: *mut czk_ctx, name: *const c_char, value: c_long) -> c_int;
+    pub fn czk_build_is_lab() -> c_int;
     pub fn czk_lanes_alloc(ctx: *mut czk_ctx, lanes: usize, len: usize, out: *mut *mut czk_lanes) -> c_int;
     pub fn czk_lanes_free(l: *mut czk_lanes);
     pub fn czk_lanes_count(l: *const czk_lanes) -> usize;

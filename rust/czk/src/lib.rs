@@ -292,45 +292,92 @@ pub mod msm {
     }
 
     impl Pinned {
-        fn new(group: i32, key: (usize, usize, i32), fp: u64, pts: &[u64], inf: &[u8]) -> Pinned {
-            let ctx = CTX.lock().unwrap();
+        // Lock order everywhere in this module: PINNED before CTX, never the reverse (registration takes them one after the other).
+        fn new(group: i32, key: (usize, usize, i32), fp: u64, pts: &[u64], inf: &[u8], flags: i32) -> Pinned {
             let mut h: *mut sys::czk_bases = std::ptr::null_mut();
-            let rc = unsafe { sys::czk_bases_register(ctx.as_ptr(), group, pts.as_ptr(), inf.as_ptr(), inf.len(), sys::CZK_MEM_HOST, &mut h) };
-            ctx.expect(rc, "czk_bases_register");
+            {
+                let ctx = CTX.lock().unwrap();
+                let rc = unsafe { sys::czk_bases_register(ctx.as_ptr(), group, pts.as_ptr(), inf.as_ptr(), inf.len(), sys::CZK_MEM_HOST | flags, &mut h) };
+                ctx.expect(rc, "czk_bases_register");
+            }
             if let Some(old) = PINNED.lock().unwrap().insert(key, Entry { handle: h, fingerprint: fp }) {
                 // the same slice pinned twice: the older guard keeps its handle alive, the map now points at the newer one
                 let _ = old;
             }
             Pinned { handle: h, group, key, fingerprint: fp }
         }
-        /// Pins a G1 slice (window tables are built once: ~65 ms per 2^20 points).
+        /// Pins a G1 slice (window tables are built once: ~65 ms per 2^20 points).  The slice is taken to hold elements of the
+        /// prime-order subgroup -- what `GroupAffine` deserialisation guarantees (short_weierstrass_jacobian.rs:868, :881) and what a proving
+        /// key or SRS always is; the bucket kernels then use the curve's twisted Edwards form.  For points of unknown origin use
+        /// [`Pinned::g1_checked`] (verifies `[r] P = 0` on the GPU and keeps the complete formulas if any base fails) -- the unpinned
+        /// drop-in path ([`g1`]) makes no such assumption at all.
         pub fn g1(bases: &[G1Affine]) -> Pinned {
             let (pts, inf) = limbs::g1_bases(bases);
-            Pinned::new(sys::CZK_G1, (bases.as_ptr() as usize, bases.len(), sys::CZK_G1), sample_g1(bases), &pts, &inf)
+            Pinned::new(sys::CZK_G1, (bases.as_ptr() as usize, bases.len(), sys::CZK_G1), sample_g1(bases), &pts, &inf, 0)
+        }
+        /// As [`Pinned::g1`], with `is_in_correct_subgroup_assuming_on_curve` (short_weierstrass_jacobian.rs:131) run over the slice at
+        /// registration (CZK_MEM_CHECK_SUBGROUP); `bad_bases()` reports how many failed.
+        pub fn g1_checked(bases: &[G1Affine]) -> Pinned {
+            let (pts, inf) = limbs::g1_bases(bases);
+            Pinned::new(sys::CZK_G1, (bases.as_ptr() as usize, bases.len(), sys::CZK_G1), sample_g1(bases), &pts, &inf, sys::CZK_MEM_CHECK_SUBGROUP)
         }
         pub fn g2(bases: &[G2Affine]) -> Pinned {
             let (pts, inf) = limbs::g2_bases(bases);
-            Pinned::new(sys::CZK_G2, (bases.as_ptr() as usize, bases.len(), sys::CZK_G2), sample_g2(bases), &pts, &inf)
+            Pinned::new(sys::CZK_G2, (bases.as_ptr() as usize, bases.len(), sys::CZK_G2), sample_g2(bases), &pts, &inf, 0)
+        }
+        /// Number of pinned bases outside the prime-order subgroup (czk_bases_check_subgroup; runs the check now unless registration did).
+        pub fn bad_bases(&self) -> usize {
+            let mut bad: usize = 0;
+            let ctx = CTX.lock().unwrap();
+            let rc = unsafe { sys::czk_bases_check_subgroup(ctx.as_ptr(), self.handle, &mut bad) };
+            ctx.expect(rc, "czk_bases_check_subgroup");
+            bad
         }
         pub fn as_ptr(&self) -> *mut sys::czk_bases {
             self.handle
         }
-        /// The MSM over share lanes that are already on the GPU (`h` out of the witness map, prover.rs:104): one Jacobian
-        /// result per lane as 18 (G1) or 36 (G2) limbs, enqueue-only; valid after `CTX.sync()`.
-        pub fn msm_resident(&self, scalars: &super::resident::DeviceLanes, n_scalars: usize, out: &mut [u64]) {
+        /// The MSM over share lanes that are already on the GPU (`h` out of the witness map, prover.rs:104), enqueue-only.  The library
+        /// keeps the destination pointer until the next synchronisation, so the destination is OWNED by the returned [`PendingMsm`]: a
+        /// heap buffer that cannot be dropped or moved before the results are delivered (dropping the guard synchronises first; leaking it
+        /// with `mem::forget` leaks the buffer, which stays valid).  `wait()` yields one Jacobian result per lane, 18 (G1) or 36 (G2) limbs.
+        /// Borrowing `self` keeps the pinned handle alive for as long as the MSM is in flight.
+        pub fn msm_resident<'a>(&'a self, scalars: &super::resident::DeviceLanes, n_scalars: usize) -> PendingMsm<'a> {
             let jw = if self.group == sys::CZK_G1 { 18 } else { 36 };
-            assert!(out.len() >= jw * scalars.lanes());
+            let mut buf = vec![0u64; jw * scalars.lanes()].into_boxed_slice();
             let ctx = CTX.lock().unwrap();
             let rc = unsafe {
                 sys::czk_msm_async(ctx.as_ptr(), self.handle, scalars.data(0, 0), n_scalars, scalars.lanes(), sys::CZK_SCALAR_MONTGOMERY,
-                                   sys::CZK_MEM_DEVICE, out.as_mut_ptr())
+                                   sys::CZK_MEM_DEVICE, buf.as_mut_ptr())
             };
             ctx.expect(rc, "czk_msm_async");
+            PendingMsm { buf: Some(buf), _bases: std::marker::PhantomData }
+        }
+    }
+
+    /// Results of an enqueued MSM (see [`Pinned::msm_resident`]).
+    pub struct PendingMsm<'a> {
+        buf: Option<Box<[u64]>>,
+        _bases: std::marker::PhantomData<&'a Pinned>,
+    }
+    impl<'a> PendingMsm<'a> {
+        /// Synchronises the context (delivers every pending MSM of it) and returns the Jacobian limbs.
+        pub fn wait(mut self) -> Box<[u64]> {
+            CTX.lock().unwrap().sync();
+            self.buf.take().unwrap()
+        }
+    }
+    impl<'a> Drop for PendingMsm<'a> {
+        fn drop(&mut self) {
+            if self.buf.is_some() {
+                CTX.lock().unwrap().sync();   // the library may still hold the pointer: deliver before the buffer is freed
+            }
         }
     }
 
     impl Drop for Pinned {
         fn drop(&mut self) {
+            // released UNDER the PINNED lock: `g1` / `g2` hold that lock for the whole czk_msm call on a looked-up handle, so a guard dropped on
+            // another thread cannot free a handle that a call is using
             let mut map = PINNED.lock().unwrap();
             if let Some(e) = map.get(&self.key) {
                 if e.handle == self.handle {
@@ -342,21 +389,25 @@ pub mod msm {
         }
     }
 
-    /// The pinned handle of `key` if the slice still holds what was pinned.
-    fn lookup(key: (usize, usize, i32), fp: impl Fn() -> u64) -> Option<*mut sys::czk_bases> {
+    type PinnedMap<'a> = std::sync::MutexGuard<'a, HashMap<(usize, usize, i32), Entry>>;
+    /// The pinned handle of `key` if the slice still holds what was pinned -- together with the PINNED lock, which the caller keeps until
+    /// its call on the handle has returned.
+    fn lookup<'a>(key: (usize, usize, i32), fp: impl Fn() -> u64) -> (PinnedMap<'a>, Option<*mut sys::czk_bases>) {
         let map = PINNED.lock().unwrap();
-        match map.get(&key) {
+        let h = match map.get(&key) {
             Some(e) if e.fingerprint == fp() => Some(e.handle),
             _ => None,
-        }
+        };
+        (map, h)
     }
 
     /// Drop-in body for `<G1Affine as AffineCurve>::multi_scalar_mul`: pinned slices use their tables, everything else the
-    /// one-shot form (`czk_msm_g1`: bases copied, no tables, nothing kept).
+    /// one-shot form (`czk_msm_g1`: bases copied, no tables, nothing kept, and -- like the reference's own function -- correct for ANY
+    /// curve points: the one-shot entry points register with CZK_MEM_ANY_POINTS).
     pub fn g1(bases: &[G1Affine], scalars: &[Fr]) -> G1Projective {
         let mut out = [0u64; 18];
         let s = scalars_to_limbs(scalars);
-        let pinned = lookup((bases.as_ptr() as usize, bases.len(), sys::CZK_G1), || sample_g1(bases));
+        let (_pinned_lock, pinned) = lookup((bases.as_ptr() as usize, bases.len(), sys::CZK_G1), || sample_g1(bases));
         let ctx = CTX.lock().unwrap();
         let rc = match pinned {
             Some(h) => unsafe {
@@ -375,7 +426,7 @@ pub mod msm {
     pub fn g2(bases: &[G2Affine], scalars: &[Fr]) -> G2Projective {
         let mut out = [0u64; 36];
         let s = scalars_to_limbs(scalars);
-        let pinned = lookup((bases.as_ptr() as usize, bases.len(), sys::CZK_G2), || sample_g2(bases));
+        let (_pinned_lock, pinned) = lookup((bases.as_ptr() as usize, bases.len(), sys::CZK_G2), || sample_g2(bases));
         let ctx = CTX.lock().unwrap();
         let rc = match pinned {
             Some(h) => unsafe {

@@ -139,3 +139,37 @@ def test_host_side_field_code_matches_checker(orc):
             assert L.czk_jac_add_mixed(None, C.c_int(g), pv(jac[i]), pv(a_aff), C.c_int(int(a_inf)), pv(out2)) == 0
             w3, i3 = orc.jac_to_affine(g, out2)
             assert i1 == i3 and (i1 or np.array_equal(w1, w3)), (g, i, j)
+
+
+def test_product_library_has_no_environment_switches_and_no_lab_kernels():
+    """libczk_hip.so (what a prover links) imports no getenv and carries none of the measured-and-rejected kernel
+    variants; libczk_hip_lab.so (tests / A/B tools) is the same source with -DCZK_LAB: same exported ABI, the variants and the
+    environment-to-option shim included."""
+    import os
+    import subprocess
+    import czk_amd
+    pkg = os.path.dirname(czk_amd.lib_path())
+    prod, lab = os.path.join(pkg, "libczk_hip.so"), os.path.join(pkg, "libczk_hip_lab.so")
+    assert os.path.exists(lab), "build() makes both libraries"
+
+    def symbols(path):
+        return subprocess.run(["nm", "-D", "-C", path], capture_output=True, text=True, check=True).stdout
+    p, q = symbols(prod), symbols(lab)
+    assert " U getenv" not in p and " U secure_getenv" not in p
+    assert " U getenv" in q
+    lab_only = ("k_affine_round", "k_aff_build_first", "k_accumulate_u2p", "k_accumulate_u_lvl", "czk::k_accumulate<", "czk::k_reduce_level<")
+    for k in lab_only:
+        assert k not in p, f"{k} ships in the product library"
+        assert k in q, f"{k} missing from the lab library"
+    for k in ("k_accumulate_te", "k_accumulate_u2", "k_reduce_level_p", "k_ntt2"):
+        assert k in p, k
+    L = czk_amd.binding.lab_lib()
+    assert [s for s in czk_amd.header_symbols() if not hasattr(L, s)] == []
+    assert czk_amd.lib().czk_build_is_lab() == 0 and L.czk_build_is_lab() == 1
+    # no product source reads the environment either
+    csrc = os.path.join(pkg, "csrc")
+    for fn in os.listdir(csrc):
+        if fn.endswith((".hip", ".h")):
+            txt = open(os.path.join(csrc, fn)).read()
+            if "getenv" in txt:
+                assert fn == "core.hip" and txt.count("getenv(") == 1 and "#ifdef CZK_LAB" in txt, fn

@@ -377,12 +377,11 @@ def test_groth16_local_pipeline_config0_matches_reference(ctx, czk, orc, n_const
     c2.close()
 
 
-@pytest.mark.parametrize("g,env", [(1, "CZK_MSM_SAT"), (2, "CZK_MSM_SAT_G2")])
-def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch, g, env):
-    """CZK_MSM_SAT=1 / CZK_MSM_SAT_G2=1 select the saturated accumulate kernels (k_accumulate<Fq>, k_accumulate<Fq2>)
-    at registration; keep them covered."""
-    monkeypatch.setenv(env, "1")
-    c2 = czk.Context(0)
+@pytest.mark.parametrize("g,opt", [(1, "msm_sat"), (2, "msm_sat_g2")])
+def test_msm_saturated_kernel_still_matches(czk, orc, g, opt):
+    """LAB library (libczk_hip_lab.so): the options "msm_sat" / "msm_sat_g2" select the saturated accumulate kernels (k_accumulate<Fq>,
+    k_accumulate<Fq2>) at registration; keep them covered."""
+    c2 = czk.Context(0, lab=True, options={opt: 1})
     _, bases = _bases(c2, g, 500, 41)
     sc = rand_fr_canonical(42, 500)
     inf = np.zeros(500, dtype=np.uint8)
@@ -392,17 +391,15 @@ def test_msm_saturated_kernel_still_matches(czk, orc, monkeypatch, g, env):
     c2.close()
 
 
-@pytest.mark.parametrize("g,envs", [(1, ("CZK_MSM_NO_TE",)), (1, ("CZK_MSM_NO_TE", "CZK_REDUCE_SAT")), (2, ("CZK_REDUCE_SAT_G2",)), (2, ()),
-                                    (2, ("CZK_G2_MODE=1",)), (2, ("CZK_G2_MODE=2",))])
-def test_msm_fallback_reductions_still_match(czk, orc, monkeypatch, g, envs):
+@pytest.mark.parametrize("g,envs", [(1, ("msm_no_te",)), (1, ("msm_no_te", "msm_reduce_sat")), (2, ("msm_reduce_sat_g2",)), (2, ()),
+                                    (2, ("msm_g2_mode=1",)), (2, ("msm_g2_mode=2",))])
+def test_msm_fallback_reductions_still_match(czk, orc, g, envs):
     """The bucket reduction has three forms per group: u-form buckets (G1 twisted Edwards / G1 XYZZ for CZK_MEM_ANY_POINTS handles /
-    G2 on unsaturated lane pairs, the defaults) and the saturated kernels behind CZK_REDUCE_SAT / CZK_REDUCE_SAT_G2; CZK_G2_MODE=1 / 2
-    select the lane-pair G2 ACCUMULATE kernels (opt-in: faster alone, slower per proof).  n = 20000 gives
+    G2 on unsaturated lane pairs, the defaults) and, in the LAB library only, the saturated kernels behind the options "msm_reduce_sat" /
+    "msm_reduce_sat_g2"; "msm_g2_mode" = 1 / 2 selects the lane-pair G2 ACCUMULATE kernels (faster alone, slower per proof).  n = 20000 gives
     a bucket set of more than 1024 buckets, so the chunked level kernel runs as well as the tail kernels; lanes = 3 leaves a lane pair
     of the G2 kernels with an idle neighbour block.  Equal and opposite bases put P + P and P - P into the reduction itself."""
-    for e in envs:
-        monkeypatch.setenv(*(e.split("=") if "=" in e else (e, "1")))
-    c2 = czk.Context(0)
+    c2 = czk.Context(0, lab=True, options={e.split("=")[0]: int(e.split("=")[1]) if "=" in e else 1 for e in envs})
     n = 20000
     _, bases = _bases(c2, g, n, 141)
     half = bases.shape[1] // 2
@@ -431,11 +428,10 @@ def test_msm_fallback_reductions_still_match(czk, orc, monkeypatch, g, envs):
     c2.close()
 
 
-def test_msm_one_pass_sort_still_matches(czk, orc, monkeypatch):
-    """CZK_SORT_ONEPASS=1 selects the single-pass counting sort (one global atomic + one random store per entry), the
-    fallback for more than 2048 partitions; keep it covered."""
-    monkeypatch.setenv("CZK_SORT_ONEPASS", "1")
-    c2 = czk.Context(0)
+def test_msm_one_pass_sort_still_matches(czk, orc):
+    """The option "msm_sort_onepass" selects the single-pass counting sort (one global atomic + one random store per entry), the
+    fallback for more than 2048 partitions; keep it covered (product library)."""
+    c2 = czk.Context(0, options={"msm_sort_onepass": 1})
     n = 5000
     _, bases = _bases(c2, 1, n, 43)
     sc = rand_fr_canonical(44, 2 * n).reshape(2, n, 4)
@@ -768,12 +764,11 @@ def test_mixed_radix_ntt_plonk_wire_domain_and_errors(ctx, czk, orc):
 
 
 @pytest.mark.parametrize("rounds", [1, 3])
-def test_msm_batched_affine_rounds_still_match(czk, orc, monkeypatch, rounds):
-    """The opt-in batched-affine pre-reduction of the bucket lists (csrc/msm_aff.h, CZK_MSM_AFFINE=R; measured slower than the XYZZ
-    kernel and therefore off by default -- profiles/r02_affine_prototype.json) computes the same group elements: checker's
+def test_msm_batched_affine_rounds_still_match(czk, orc, rounds):
+    """LAB library: the batched-affine pre-reduction of the bucket lists (csrc/lab/msm_aff.h, option "msm_affine_rounds" = R; measured slower
+    than the XYZZ kernel and therefore not in the product -- profiles/r02_affine_prototype.json) computes the same group elements: checker's
     Pippenger at n = 4096 with zero / unit scalars and infinity bases, equal and opposite points in one bucket, 4 lanes."""
-    monkeypatch.setenv("CZK_MSM_AFFINE", str(rounds))
-    c = czk.Context(0)
+    c = czk.Context(0, lab=True, options={"msm_affine_rounds": rounds})
     n = 4096
     k = rand_fr_canonical(77, n)
     bases = c.fixed_base_points(1, k)
@@ -795,12 +790,11 @@ def test_msm_batched_affine_rounds_still_match(czk, orc, monkeypatch, rounds):
     c.close()
 
 
-def test_ntt_first_generation_passes_still_match(czk, orc, monkeypatch):
-    """CZK_NTT_GEN1=1 keeps the first-generation passes (ntt.hip) for every size -- the A/B switch behind the figures in
+def test_ntt_first_generation_passes_still_match(czk, orc):
+    """The option "ntt_gen1" keeps the first-generation passes (ntt.hip) for every size -- the A/B switch behind the figures in
     profiles/r02_pmc_ntt.json; they serve the domains below 2^11 by default.  Bit-exact at sizes that exercise their 6- and
     7-stage tiles (2^13, 2^14) and all four kinds."""
-    monkeypatch.setenv("CZK_NTT_GEN1", "1")
-    c = czk.Context(0)
+    c = czk.Context(0, options={"ntt_gen1": 1})
     for log_d in (13, 14):
         d = 1 << log_d
         x = orc.fr_from_repr(rand_fr_canonical(900 + log_d, 2 * d)).reshape(2, d, 4)
@@ -1175,3 +1169,41 @@ def test_g1_full_order_bases_subgroup_check_and_fallback(ctx, czk, orc):
     h = ctx.register_bases(2, g2, None)
     assert h.check_subgroup() == 1
     h.release()
+
+
+def test_options_are_explicit_and_the_product_library_ignores_the_environment(czk, orc, monkeypatch):
+    """no getenv dispatch in libczk_hip.so.  An environment variable that used to switch kernels changes nothing; the
+    rejected variants' options are unknown to the product library (CZK_ERR_ARG) and known to the lab library, which exports the same ABI."""
+    for e in ("CZK_MSM_NO_TE", "CZK_MSM_SAT", "CZK_REDUCE_SAT", "CZK_NTT_GEN1", "CZK_SORT_ONEPASS"):
+        monkeypatch.setenv(e, "1")
+    monkeypatch.setenv("CZK_G2_MODE", "1")
+    monkeypatch.setenv("CZK_MSM_C_G1", "9")
+    c = czk.Context(0)
+    assert c._L.czk_build_is_lab() == 0
+    _, bases = _bases(c, 1, 600, 9001)
+    b = c.register_bases(1, bases, None)
+    assert b.arith() == 2 and b.layout()[0] != 9            # twisted Edwards tables, the cost model's window: the environment was not read
+    sc = rand_fr_canonical(9002, 600)
+    assert _same_point(c, orc, 1, c.msm(b, sc)[0], orc.msm(1, bases, np.zeros(600, np.uint8), sc))
+    b.release()
+    for name in ("msm_sat", "msm_no_te", "msm_g2_mode", "msm_affine_rounds", "msm_reduce_sat", "no_such_option"):
+        with pytest.raises(czk.CzkError) as ei:
+            c.set_option(name, 1)
+        assert ei.value.code == 3 and name in str(ei.value)
+    with pytest.raises(czk.CzkError):
+        c.set_option("msm_window_g1", 5)                    # out of range
+    with pytest.raises(czk.CzkError):
+        c.set_option("msm_slots", 2)                        # the pipeline exists already
+    c.set_option("msm_window_g1", 9)
+    b = c.register_bases(1, bases, None)
+    assert b.layout()[0] == 9
+    assert _same_point(c, orc, 1, c.msm(b, sc)[0], orc.msm(1, bases, np.zeros(600, np.uint8), sc))
+    b.release()
+    c.close()
+    lab = czk.Context(0, lab=True)                          # the lab build translates the tools' environment switches into options
+    assert lab._L.czk_build_is_lab() == 1
+    b = lab.register_bases(1, bases, None)
+    assert b.arith() == 0 and b.layout()[0] == 9            # CZK_MSM_SAT: saturated tables; CZK_MSM_C_G1=9
+    assert _same_point(lab, orc, 1, lab.msm(b, sc)[0], orc.msm(1, bases, np.zeros(600, np.uint8), sc))
+    b.release()
+    lab.close()

@@ -5,7 +5,7 @@
 //   affine:  lambda = (y2 - y1) / (x2 - x1);  x3 = lambda^2 - x1 - x2;  y3 = lambda (x1 - x3) - y1
 //   with Montgomery's trick over a batch of K independent additions:  5 M + 1 S per addition + one inversion per batch.
 // Every lane of a wave executes the inversion whether or not other lanes need one, so the batch must be K additions of
-// the SAME thread; the inversion is Bernstein-Yang safegcd (csrc/fq_safegcd.h, ~25 k instructions) instead of Fermat
+// the SAME thread; the inversion is Bernstein-Yang safegcd (csrc/lab/fq_safegcd.h, ~25 k instructions) instead of Fermat
 // (~270 k).  Each thread owns K independent (P1_j, P2_j) pairs -- the shape of "thread owns K buckets and adds the next
 // point to each" -- kept in global memory in 16-byte-interleaved SoA order (coalesced), prefix products in a global scratch.
 // The kernel iterates P1_j <- P1_j + P2_j; results are dumped for an independent big-integer check (tools/affine_check.py).
@@ -18,7 +18,7 @@
 #include <vector>
 #include "curve.h"
 #include "fqu.h"
-#include "fq_safegcd.h"
+#include "lab/fq_safegcd.h"
 using namespace czk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)

@@ -18,7 +18,7 @@
 #include <vector>
 #include "curve.h"
 #include "fqu.h"
-#include "fq_safegcd.h"
+#include "lab/fq_safegcd.h"
 using namespace czk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); return 1; } } while (0)

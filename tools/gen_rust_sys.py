@@ -14,7 +14,7 @@ OUT = os.path.join(ROOT, "rust", "czk-sys", "src", "lib.rs")
 
 TYPES = {
     "int": "c_int", "unsigned": "c_uint", "size_t": "usize", "void": "()", "uint64_t": "u64", "uint32_t": "u32", "uint8_t": "u8",
-    "char": "c_char", "double": "f64",
+    "char": "c_char", "double": "f64", "long": "c_long",
 }
 
 
@@ -73,7 +73,7 @@ def generate() -> str:
         TYPES[o] = o
     out = ["//! Raw bindings of `libczk_hip.so` -- GENERATED from include/czk.h by tools/gen_rust_sys.py; do not edit.",
            "//! One `extern \"C\"` declaration per C declaration; constants mirror the C enums.  Safe wrappers live in the `czk` crate.",
-           "#![allow(non_camel_case_types)]", "use std::os::raw::{c_char, c_int, c_uint, c_void};", ""]
+           "#![allow(non_camel_case_types)]", "use std::os::raw::{c_char, c_int, c_long, c_uint, c_void};", ""]
     for opaque in opaques:
         out += ["#[repr(C)]", f"pub struct {opaque} {{", "    _private: [u8; 0],", "}"]
     out.append("")

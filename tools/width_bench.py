@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Window width per call: an MSM of m scalars under a key of n bases, once on the key's own tables (CZK_MSM_FIXED_C=1) and once with
+"""Window width per call: an MSM of m scalars under a key of n bases, once on the key's own tables (option "msm_fixed_c") and once with
 the secondary table sets (default).  Reports blocking and pipelined time per MSM and the stage spans.
 python tools/width_bench.py [log_key=20.58 (6*2^18)] [lanes=3]"""
 import os
@@ -17,11 +17,7 @@ from util import rand_fr_canonical  # noqa: E402
 
 
 def run(n_key, sizes, lanes, fixed):
-    if fixed:
-        os.environ["CZK_MSM_FIXED_C"] = "1"
-    else:
-        os.environ.pop("CZK_MSM_FIXED_C", None)
-    ctx = czk.Context(0)
+    ctx = czk.Context(0, options={"msm_fixed_c": 1 if fixed else 0})
     k = torch.from_numpy(rand_fr_canonical(5, n_key).view(np.int64)).cuda()
     pts = torch.empty((n_key, 12), dtype=torch.int64, device="cuda")
     ctx.fixed_base_points(1, k.data_ptr(), out=pts.data_ptr(), n=n_key, mem=czk.CZK_MEM_DEVICE)
