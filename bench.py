@@ -664,6 +664,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=None, help="plonk / marlin, replica layout: independent proofs in flight per GPU, each on its own context "
                                                                  "(default 2: the transcript points of one proof drain the MSM pipeline, a second proof fills the bubbles -- round 3, "
                                                                  "twisted Edwards G1 path: plonk 178 / 152 / 163 ms per proof with 1 / 2 / 3 in flight, marlin 231 / 205 with 1 / 2)")
+    ap.add_argument("--scheme", choices=("spdz", "hbc"), default="spdz", help="groth16: spdz (default; sh + mac lane per party) or hbc (the reference's honest-but-curious "
+                                                                               "additive sharing: one lane per party, mpc-snarks/src/proof.rs:379-387)")
+    ap.add_argument("--exchange", choices=("ring", "p2p"), default="ring", help="party layout over RCCL: the opens' share exchange as one ring all-gather or as "
+                                                                                 "world - 1 grouped point-to-point copies (parallel.set_exchange)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
@@ -711,11 +715,12 @@ def main():
     assert tstream.cuda_stream != 0
     if args.workload != "groth16":
         return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)
+    parallel.set_exchange(args.exchange)
     if party_layout:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables)
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables, scheme=args.scheme)
         prover.commit_opens = args.commit_opens
     else:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables)
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme)
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)
@@ -757,7 +762,7 @@ def main():
             for k in aff:
                 assert np.array_equal(aff[k][0], ref_aff[k][0]) and np.array_equal(aff[k][1], ref_aff[k][1]), f"pipelined proofs disagree on {k}"
     # MAC-check vectors of the two opens must be all zero (share/spdz.rs:176-183)
-    assert not bool(prover.chk.any().item()), "SPDZ MAC check failed"
+    assert args.scheme != "spdz" or not bool(prover.chk.any().item()), "SPDZ MAC check failed"
     # ... and they must be the RIGHT group elements: host-side check against the bases' known discrete logs (every rank
     # checks its own lanes)
     checked = {"results_checked": False}
@@ -828,7 +833,7 @@ def main():
         return v
     out = {
         # BASELINE.json's metric string for the BASELINE configuration; other sizes / party counts say what they are
-        "metric": f"collaborative Groth16 proofs/sec (BLS12-377, {size_txt} constraints, SPDZ N={args.parties})",
+        "metric": f"collaborative Groth16 proofs/sec (BLS12-377, {size_txt} constraints, {args.scheme.upper()} N={args.parties})",
         "value": proofs / dt,
         "unit": "proofs/s",
         "n_gpus": world,
@@ -849,11 +854,11 @@ def main():
         "scaling": "weak",
         # Groth16 SPDZ 2 parties 2^20 on 2x GCP n2-standard-2 (1 core each): 328.957 / 317.213 /
         # 320.422 s per proof (mpc-snarks/analysis/data/weak_1_20.csv:21-23) -> 1 / mean = 0.003104 proofs/s
-        "vs_baseline": (proofs / dt) / REF_PROOFS_PER_S if n_constraints == 1 << 20 and args.parties == 2 else None,
+        "vs_baseline": (proofs / dt) / REF_PROOFS_PER_S if n_constraints == 1 << 20 and args.parties == 2 and args.scheme == "spdz" else None,
         "dtype": "u32",
         "data": "synthetic",
         **checked,
-        "config": {"workload": f"Groth16 SPDZ {args.parties} parties, BLS12-377, {size_txt} constraints (squaring circuit), "
+        "config": {"workload": f"Groth16 {args.scheme.upper()} {args.parties} parties, BLS12-377, {size_txt} constraints (squaring circuit), "
                                + ("both parties' share-local NTT+MSM on one GPU" if not party_layout else "one party per GPU") +
                                ": " + prover.describe(),
                    "constraints": n_constraints, "domain": prover.D, "parties": args.parties, "share_lanes": prover.lanes,
@@ -886,12 +891,14 @@ def main():
         "stream_elapsed_ms_per_step": {**breakdown, "note": STREAM_ELAPSED_NOTE},
         "setup_key_s": prover.setup_key_s,
     }
-    if rank == 0 and world == 1 and not args.no_seam_report:
+    if rank == 0 and world == 1 and not args.no_seam_report and args.scheme == "spdz":
         t = prover.seam_calls_host_memory()
         out["seam_host_memory"] = {"ms_per_proof": t * 1e3, "proofs_per_s": 1.0 / t,
                                    "note": "7 czk_ntt_fr + 5 czk_msm calls per proof with CZK_MEM_HOST (pageable) buffers for all share lanes, "
                                            "bases registered: what a reference caller binding only the NTT / MSM seams sees (PCIe staging included; "
                                            "never `value`)"}
+    if args.scheme != "spdz":
+        args.no_seam_report = True     # the seam / shortcut reports below are SPDZ-shaped
     if rank == 0 and world == 1 and not args.no_seam_report and not party_layout:
         out["spdz_mac_msm_from_sh"] = mac_shortcut_report(czk, device, tstream, n_constraints, args, proofs / dt, check_results)
     if rank == 0 and world == 1 and not args.no_seam_report and not party_layout:
@@ -913,7 +920,7 @@ def main():
         if r1 is not None and not args.no_result_check:
             out["one_shot_no_tables"]["results_checked"] = bool(check_results(czk, ctx1, p1, r1)["results_checked"])
     if (rank == 0 and world == 1 and not args.no_other_workloads and not party_layout and not args.no_tables and n_constraints == 1 << 20 and args.parties == 2
-            and not os.environ.get("CZK_BENCH_CHILD")):
+            and args.scheme == "spdz" and not os.environ.get("CZK_BENCH_CHILD")):
         try:
             del p1
             ctx1.close()

@@ -57,6 +57,7 @@ def _load(path):
     L.czk_lanes_count.restype = C.c_size_t
     L.czk_lanes_len.restype = C.c_size_t
     L.czk_lanes_data.restype = C.c_void_p
+    L.czk_ctx_stream.restype = C.c_void_p
     return L
 
 
@@ -115,6 +116,10 @@ class Context:
             raise CzkError(rc, "czk_ctx_create failed (no visible GPU?)")
         for k, v in (options or {}).items():
             self.set_option(k, v)
+
+    def stream_handle(self) -> int:
+        """hipStream_t of this context as an integer (czk_ctx_stream): torch.cuda.ExternalStream(handle) orders torch work against it"""
+        return int(self._L.czk_ctx_stream(self._h) or 0)
 
     def set_option(self, name: str, value: int):
         self._ck(self._L.czk_ctx_set_option(self._h, name.encode(), C.c_long(int(value))))

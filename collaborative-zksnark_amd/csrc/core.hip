@@ -381,6 +381,7 @@ extern "C" int czk_build_is_lab(void) {
 #endif
 }
 
+extern "C" void* czk_ctx_stream(const czk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" int czk_ctx_sync(czk_ctx* ctx) {
     if (!ctx) return CZK_ERR_ARG;
     CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));

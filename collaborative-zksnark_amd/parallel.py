@@ -32,12 +32,51 @@ class MpcCheckError(RuntimeError):
     in release builds too (share/spdz.rs:181-184, share/gsz20/mod.rs:452), so they are exceptions here, never Python `assert`s."""
 
 
-def _settle(t: torch.Tensor):
+# How the share exchange of an open crosses the GPUs (RCCL backends; gloo always stages through the host):
+#   "ring" : one all_gather_into_tensor -- RCCL's ring, every hop bound by one xGMI link
+#   "p2p"  : world - 1 sends + world - 1 receives in ONE grouped batch_isend_irecv -- every pair of GPUs has its own xGMI link on an MI355X
+#            node, so the n - 1 copies of a party's buffer travel concurrently over n - 1 links (mpc-net's own shape: a star of point-to-point
+#            connections, mpc-net/src/multi.rs:145-173) instead of n - 1 ring steps.
+# Both deliver identical bytes (tests/test_opens.py); which is faster is for the first multi-GPU lease to A/B (DESIGN.md section 6).
+_EXCHANGE = "ring"
+
+
+def set_exchange(method: str):
+    global _EXCHANGE
+    if method not in ("ring", "p2p"):
+        raise ValueError("exchange method must be 'ring' or 'p2p'")
+    _EXCHANGE = method
+
+
+def get_exchange() -> str:
+    return _EXCHANGE
+
+
+def _ctx_stream(ctx, device):
+    """torch view of the czk context's stream (czk_ctx_stream): lets torch's stream and the context's stream wait on each other with
+    EVENTS instead of host synchronisation"""
+    return torch.cuda.ExternalStream(ctx.stream_handle(), device=device)
+
+
+def _before_exchange(ctx, t: torch.Tensor):
+    """`t` was produced by the context's kernels; the exchange runs on torch's current stream (or through the host)."""
+    if t.is_cuda and ctx is not None:
+        torch.cuda.current_stream(t.device).wait_stream(_ctx_stream(ctx, t.device))     # event wait, no host block
+    elif ctx is not None:
+        ctx.sync()
+
+
+def _settle(t: torch.Tensor, ctx=None):
     """After a collective on a CUDA backend: RCCL enqueues on torch's / its own stream and returns; the library's kernels that
-    read the result run on the czk context's stream, which may be a private non-blocking one.  Wait here so that the result has
-    landed whichever stream the caller's context uses (an open is a synchronisation point of the protocol anyway)."""
+    read the result run on the czk context's stream, which may be a private non-blocking one.  With the context at hand its stream
+    waits on an event recorded behind the collective (no host synchronisation: the host goes on enqueueing); without it the host waits."""
     if t is not None and t.is_cuda:
-        torch.cuda.current_stream(t.device).synchronize()
+        if ctx is not None:
+            cs = _ctx_stream(ctx, t.device)
+            cs.wait_stream(torch.cuda.current_stream(t.device))
+            t.record_stream(cs)      # torch's allocator must not recycle the buffer while the context's kernels read it
+        else:
+            torch.cuda.current_stream(t.device).synchronize()
     return t
 
 
@@ -79,23 +118,45 @@ def aggregate_throughput(units_local: float, seconds_local: float, device=None) 
     return sum_over_ranks(units_local, device) / t, t
 
 
-def all_gather_shares(share: torch.Tensor) -> torch.Tensor:
+def _p2p_exchange(out: torch.Tensor, mine: torch.Tensor, world: int, rank: int):
+    """out[p] <- party p's buffer: world - 1 isend + world - 1 irecv issued as one group"""
+    out[rank].copy_(mine)
+    ops = []
+    for d in range(1, world):
+        ops.append(dist.P2POp(dist.isend, mine, (rank + d) % world))
+        ops.append(dist.P2POp(dist.irecv, out[(rank - d) % world], (rank - d) % world))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()      # CUDA backends: orders torch's current stream behind the transfer (no host block); gloo: completes it
+
+
+def all_gather_shares(share: torch.Tensor, ctx=None, method: str | None = None) -> torch.Tensor:
     """mpc-net `broadcast`: every party contributes one equal-length buffer and receives all of them
     (mpc-net/src/multi.rs:145-173).  Returns a (world, *share.shape) tensor; the modular sum of an `open`
-    (share/spdz.rs:166-185) is then a local, share-linear pointwise step."""
+    (share/spdz.rs:166-185) is then a local, share-linear pointwise step.  `ctx`: the czk context whose kernels produced `share` and
+    will consume the result -- given, the hand-over in both directions is an event wait between streams; omitted, the caller has
+    synchronised and the host waits for the collective.  `method`: "ring" / "p2p" (default: set_exchange)."""
     if not dist.is_initialized():
         return share.unsqueeze(0)
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
+    method = method or _EXCHANGE
+    if ctx is not None:
+        _before_exchange(ctx, share)
     if dist.get_backend() == "gloo":
         # CPU tests, and rigs without one GPU per party (several ranks on one device): stage through the host
         host = share.contiguous().cpu()
+        if method == "p2p":
+            stacked = torch.empty((world,) + tuple(host.shape), dtype=host.dtype)
+            _p2p_exchange(stacked, host, world, rank)
+            return _settle(stacked.to(share.device), ctx)
         out = [torch.empty_like(host) for _ in range(world)]
         dist.all_gather(out, host)
-        return torch.stack(out).to(share.device)
-    # RCCL: one all-gather straight into the (world, ...) result
+        return _settle(torch.stack(out).to(share.device), ctx)
     out = torch.empty((world,) + tuple(share.shape), dtype=share.dtype, device=share.device)
-    dist.all_gather_into_tensor(out, share.contiguous())
-    return _settle(out)
+    if method == "p2p":
+        _p2p_exchange(out, share.contiguous(), world, rank)
+    else:
+        dist.all_gather_into_tensor(out, share.contiguous())   # RCCL: one all-gather straight into the (world, ...) result
+    return _settle(out, ctx)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -186,7 +247,7 @@ def atomic_broadcast(ctx, x: torch.Tensor, rand32: bytes | None = None) -> torch
     digest = hashlib.sha256(wire + rnd).digest()
     dev = x.device
     commits = all_gather_shares(torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(dev))           # round 1: commitments
-    data = all_gather_shares(x)                                                                              # round 2: the vectors ...
+    data = all_gather_shares(x, ctx)                                                                         # round 2: the vectors ...
     rnds = all_gather_shares(torch.frombuffer(bytearray(rnd), dtype=torch.uint8).to(dev))                   # ... and the randomness
     for p in range(world):
         if p == rank:
@@ -206,14 +267,12 @@ def spdz_batch_open(ctx, sh: torch.Tensor, mac: torch.Tensor, mac_share, commit:
     sum must vanish.  MAC shares themselves never leave the party.  sh, mac: (n, 4) device tensors; mac_share: (4,) uint64."""
     world, _ = _world_rank()
     n = sh.shape[0]
-    ctx.sync()   # `sh` / `mac` may still be in flight on the context's stream
-    gathered = all_gather_shares(sh)                                       # Net::broadcast(&s_vals)
+    gathered = all_gather_shares(sh, ctx)                                  # Net::broadcast(&s_vals); stream hand-over by events (sh may be in flight)
     vals = torch.empty_like(sh)
     ctx.fr_lanes_sum(gathered.data_ptr(), world, n, out_ptr=vals.data_ptr())
     dx = torch.empty_like(sh)
     ctx.fr_spdz_dx(vals.data_ptr(), mac.data_ptr(), mac_share, dx.data_ptr(), n)
-    ctx.sync()   # the exchange below runs on torch's stream (or through the host): the context's kernels must have finished
-    all_dx = atomic_broadcast(ctx, dx) if commit else all_gather_shares(dx)   # Net::atomic_broadcast(&dx_ts)
+    all_dx = atomic_broadcast(ctx, dx) if commit else all_gather_shares(dx, ctx)   # Net::atomic_broadcast(&dx_ts)
     bad = ctx.fr_lanes_sum(all_dx.contiguous().data_ptr(), world, n, count_nonzero=True)
     if bad != 0:                                                            # assert!(sum.is_zero())
         raise MpcCheckError(f"SPDZ MAC check failed on {bad} of {n} opened values")
@@ -225,10 +284,20 @@ def gsz_batch_open(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
     inverse DFT with the degree check, p(0)."""
     world, _ = _world_rank()
     n = val.shape[0]
-    ctx.sync()   # `val` may still be in flight on the context's stream
-    gathered = all_gather_shares(val)
+    gathered = all_gather_shares(val, ctx)
     out = torch.empty_like(val)
     bad = ctx.fr_gsz_open(gathered.data_ptr(), world, n, out.data_ptr(), degree=degree)
     if bad != 0:                                                            # assert!(p.degree() <= d)
         raise MpcCheckError(f"GSZ open: {bad} of {n} share polynomials exceed their degree bound")
+    return out
+
+
+def additive_batch_open(ctx, val: torch.Tensor) -> torch.Tensor:
+    """AdditiveFieldShare::batch_open (mpc-algebra/src/share/add.rs:256-259; the reference's `--alg hbc`): broadcast the shares,
+    sum them.  No MAC, no check.  val: (n, 4) device tensor."""
+    world, _ = _world_rank()
+    n = val.shape[0]
+    gathered = all_gather_shares(val, ctx)
+    out = torch.empty_like(val)
+    ctx.fr_lanes_sum(gathered.contiguous().data_ptr(), world, n, out_ptr=out.data_ptr())
     return out

@@ -65,12 +65,19 @@ class Groth16Local:
     circuit (squaring chain, mpc-snarks/src/proof.rs:304-344), SPDZ shares of `parties` parties."""
 
     def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None, no_tables: bool = False,
-                 mac_msm_from_sh: bool = False):
+                 mac_msm_from_sh: bool = False, scheme: str = "spdz"):
         """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
         configs[1]); with one party per rank the two opens of the witness map run the reference's two broadcast rounds
         over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused.  no_tables:
         register the proving key with CZK_MEM_NO_TABLES (what a prover that runs once should do)."""
         self.czk, self.ctx = czk, ctx
+        # scheme "spdz": two lanes per party (sh, mac; share/spdz.rs:50-53), opens carry the MAC check.  scheme "hbc": the reference's
+        # honest-but-curious additive sharing (mpc-snarks/src/proof.rs:379-387 `--alg hbc`; AdditiveFieldShare, share/add.rs:26-29):
+        # ONE lane per party, an open is the sum of the parties' lanes (add.rs:256-259), no MAC lane and no check.
+        assert scheme in ("spdz", "hbc")
+        self.scheme = scheme
+        self.lpp = 2 if scheme == "spdz" else 1       # share lanes per party
+        assert not (mac_msm_from_sh and scheme != "spdz")
         # mac_msm_from_sh: the reference's SPDZ multi_scale_pub_group computes BOTH group shares from the `sh` scalars
         # (mpc-algebra/src/share/spdz.rs:440-446: `macs` is built from `s.sh.val` too), so its mac-lane MSM repeats its sh-lane MSM
         # bit for bit.  A caller that binds at that function can run ONE MSM per party and use the result twice; this switch does
@@ -84,7 +91,7 @@ class Groth16Local:
         self.commit_opens = False                     # True: dx_t goes through atomic_broadcast (commit-then-open, channel.rs:50-75)
         # mac_share() = 1 on the king, 0 elsewhere (share/spdz.rs:30-37: the reference's stand-in MAC key is 1)
         self.mac_share = to_mont_limbs([1 if (self.local and self.local[0] == 0) else 0])[0]
-        self.lanes = 2 * len(self.local)              # SPDZ: sh + mac per party (share/spdz.rs:50-53)
+        self.lanes = self.lpp * len(self.local)       # SPDZ: sh + mac per party (share/spdz.rs:50-53); HBC: the additive share alone
         self.log_d = (self.N + 2 - 1).bit_length()    # D = next_pow2(N + num_instance) (r1cs_to_qap.rs:63-65)
         self.D = 1 << self.log_d
         N, D, L = self.N, self.D, self.lanes
@@ -145,9 +152,10 @@ class Groth16Local:
         self.a0, self.b0, self.c0 = lanes_buf(), lanes_buf(), lanes_buf()
         self.wit = torch.zeros((L, N, 4), dtype=torch.int64, device=dev)          # l-MSM scalars: witness
         self.asg = torch.zeros((L, N + 1, 4), dtype=torch.int64, device=dev)      # a/b-MSM scalars: [out, witness]
+        lpp = self.lpp
         for j, p in enumerate(self.local):
-            for m in range(2):                                     # mac lane = sh * mac(), mac() = 1 (spdz.rs:41-47)
-                ln = 2 * j + m
+            for m in range(lpp):                                   # mac lane = sh * mac(), mac() = 1 (spdz.rs:41-47)
+                ln = lpp * j + m
                 self.a0[ln, :N] = sh[p][:N]
                 self.b0[ln, :N] = sh[p][:N]
                 self.c0[ln, :N] = sh[p][1:N + 1]
@@ -160,8 +168,8 @@ class Groth16Local:
         # full assignment [1, out | w_0 .. w_{N-1}] per lane (r1cs_to_qap.rs:56-61); Public(1) lifted to the king's lanes
         self.full = torch.zeros((L, N + 2, 4), dtype=torch.int64, device=dev)
         for j, p in enumerate(self.local):
-            for m in range(2):
-                ln = 2 * j + m
+            for m in range(lpp):
+                ln = lpp * j + m
                 if p == 0:
                     self.full[ln, 0] = one_t
                 self.full[ln, 1] = sh[p][N]
@@ -175,7 +183,7 @@ class Groth16Local:
         self.mat_c = ctx.r1cs_matrix_register(rp[: N + 1], np.concatenate([wcols[1:], np.array([1], dtype=np.uint32)]), ones[:N], N + 2)
         # dummy Beaver triples (wire/field.rs:41-60): king holds (1,1,1), everyone else (0,0,0)
         self.tx, self.ty, self.tz = lanes_buf(), lanes_buf(), lanes_buf()
-        self.king_lanes = [2 * j + m for j, p in enumerate(self.local) if p == 0 for m in range(2)]
+        self.king_lanes = [lpp * j + m for j, p in enumerate(self.local) if p == 0 for m in range(lpp)]
         for t in (self.tx, self.ty, self.tz):
             for ln in self.king_lanes:
                 t[ln, :] = one_t
@@ -193,7 +201,8 @@ class Groth16Local:
         return 7 * self.lanes
 
     def describe(self):
-        return f"{7 * self.lanes} Fr NTT lanes of 2^{self.log_d} + 5 MSMs x {self.lanes} share lanes per GPU"
+        return (f"{7 * self.lanes} Fr NTT lanes of 2^{self.log_d} + 5 MSMs x {self.lanes} share lanes per GPU"
+                + ("" if self.scheme == "spdz" else " (HBC: one additive-share lane per party, no MAC lane)"))
 
     # one open of a share vector: value = sum of sh lanes; MAC check vector = mac_share*value - sum(mac lanes)
     def _open(self, shares, out, chk):
@@ -206,8 +215,16 @@ class Groth16Local:
             # dx_t (atomic_broadcast when self.commit_opens), sum == 0.  MAC shares stay on their party.
             assert len(self.local) == 1
             from . import parallel
-            vals = parallel.spdz_batch_open(ctx, shares[0], shares[1], self.mac_share, commit=self.commit_opens)
+            if self.scheme == "hbc":
+                vals = parallel.additive_batch_open(ctx, shares[0])
+            else:
+                vals = parallel.spdz_batch_open(ctx, shares[0], shares[1], self.mac_share, commit=self.commit_opens)
             out.copy_(vals)
+            return
+        if self.scheme == "hbc":                     # AdditiveFieldShare::batch_open (share/add.rs:256-259): the sum of the parties' lanes
+            ctx.fr_vec_op(ADD, shares[0].data_ptr(), shares[1].data_ptr(), out=out.data_ptr(), n=D, mem=M)
+            for p in range(2, self.P):
+                ctx.fr_vec_op(ADD, out.data_ptr(), shares[p].data_ptr(), out=out.data_ptr(), n=D, mem=M)
             return
         ctx.fr_vec_op(ADD, shares[0].data_ptr(), shares[2].data_ptr(), out=out.data_ptr(), n=D, mem=M)
         for p in range(2, self.P):

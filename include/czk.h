@@ -88,6 +88,9 @@ typedef enum { CZK_G1 = 1, CZK_G2 = 2 } czk_group;
 int czk_ctx_create(czk_ctx** out, int device, void* hip_stream);
 void czk_ctx_destroy(czk_ctx* ctx);
 int czk_ctx_sync(czk_ctx* ctx);
+/* The hipStream_t the context enqueues on (the one given to czk_ctx_create, or its private stream): lets a caller order its own
+ * streams against the context's with events (hipStreamWaitEvent) instead of czk_ctx_sync -- e.g. an RCCL exchange between two opens. */
+void* czk_ctx_stream(const czk_ctx* ctx);
 const char* czk_last_error(const czk_ctx* ctx);
 const char* czk_version(void);
 /* Tuning options of one context.  The library reads NO environment variables: everything a caller may select is named here.

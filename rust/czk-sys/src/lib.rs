@@ -48,6 +48,7 @@ extern "C" {
     pub fn czk_ctx_create(out: *mut *mut czk_ctx, device: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn czk_ctx_destroy(ctx: *mut czk_ctx);
     pub fn czk_ctx_sync(ctx: *mut czk_ctx) -> c_int;
+    pub fn czk_ctx_stream(ctx: *const czk_ctx) -> *mut c_void;
     pub fn czk_last_error(ctx: *const czk_ctx) -> *const c_char;
     pub fn czk_version() -> *const c_char;
     pub fn czk_ctx_set_option(ctx: *mut czk_ctx, name: *const c_char, value: c_long) -> c_int;

@@ -1134,7 +1134,9 @@ def test_g1_full_order_bases_subgroup_check_and_fallback(ctx, czk, orc):
         # two flags exist for -- and the check, run on request, reports both bases
         b = ctx.register_bases(1, pair, inf)
         assert b.arith() == 2 and b.check_subgroup() == 2
-        assert not _same_point(ctx, orc, 1, ctx.msm(b, sc)[0], want), "the default path became complete on E: update czk.h / INTEGRATION.md"
+        if name == "unit":      # the two bases alone in one bucket: the exceptional pair is met for certain (under a random scalar other
+            # window multiples usually reach the bucket first, and the pair never forms)
+            assert not _same_point(ctx, orc, 1, ctx.msm(b, sc)[0], want), "the default path became complete on E: update czk.h / INTEGRATION.md"
         b.release()
     # bases that ARE in G1: the check passes, the fast path stays; mixed with one outsider / one off-curve point it does not
     n = 500
@@ -1207,3 +1209,52 @@ def test_options_are_explicit_and_the_product_library_ignores_the_environment(cz
     assert _same_point(lab, orc, 1, lab.msm(b, sc)[0], orc.msm(1, bases, np.zeros(600, np.uint8), sc))
     b.release()
     lab.close()
+
+
+@pytest.mark.parametrize("n_constraints,parties", [(10, 2), (1000, 3)])
+def test_groth16_local_hbc_scheme_matches_reference(ctx, czk, orc, n_constraints, parties):
+    """The reference's `--alg hbc` (mpc-snarks/src/proof.rs:379-387): AdditiveFieldShare (share/add.rs:26-29), ONE lane per party, an open is
+    the sum of the lanes (add.rs:256-259), no MAC lane.  Groth16Local(scheme="hbc"): the witness map with the Beaver local half on `parties`
+    lanes against the checker's lane-wise sequence, the reconstructed h against the single prover's, the MSMs against the checker's Pippenger."""
+    import torch
+    from czk_amd.provers import Groth16Local
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        c2 = czk.Context(0, ts.cuda_stream)
+        p = Groth16Local(czk, c2, n_constraints, parties, scheme="hbc")
+        assert p.lanes == parties and p.lpp == 1 and p.king_lanes == [0]
+        a0, b0, c0 = (t.cpu().numpy().view(np.uint64).copy() for t in (p.a0, p.b0, p.c0))
+        tx, ty, tz = (t.cpu().numpy().view(np.uint64).copy() for t in (p.tx, p.ty, p.tz))
+        wit, asg = p.wit.cpu().numpy().view(np.uint64).copy(), p.asg.cpu().numpy().view(np.uint64).copy()
+        p.step()
+        torch.cuda.synchronize()
+        h_gpu = p.ab.cpu().numpy().view(np.uint64)
+    L, D, ld, N = parties, p.D, p.log_d, p.N
+    A = [orc.witness_map_pre(a0[ln], b0[ln], ld) for ln in range(L)]
+    sa = [orc.fr_add(A[ln][0], tx[ln]) for ln in range(L)]
+    sb = [orc.fr_add(A[ln][1], ty[ln]) for ln in range(L)]
+    sx, oy = sa[0], sb[0]
+    for ln in range(1, L):
+        sx, oy = orc.fr_add(sx, sa[ln]), orc.fr_add(oy, sb[ln])
+    hs = []
+    for ln in range(L):
+        ab = orc.fr_sub(orc.fr_sub(tz[ln], orc.fr_mul(ty[ln], sx)), orc.fr_mul(tx[ln], oy))
+        if ln == 0:
+            ab = orc.fr_add(ab, orc.fr_mul(sx, oy))                        # the king applies the shift
+        hs.append(orc.witness_map_post(ab, c0[ln], ld))
+        assert np.array_equal(h_gpu[ln], hs[-1]), ln
+
+    def lane_sum(v):
+        t = v[0]
+        for ln in range(1, L):
+            t = orc.fr_add(t, v[ln])
+        return t
+    assert np.array_equal(lane_sum(h_gpu), orc.witness_map_plain(lane_sum(a0), lane_sum(b0), lane_sum(c0), ld))
+    for name, g, n, sd, inf_first, scal in (("h", 1, D - 1, 1, False, h_gpu), ("l", 1, N, 2, False, wit), ("a", 1, N + 1, 3, False, asg),
+                                             ("b_g1", 1, N + 1, 4, True, asg), ("b_g2", 2, N + 1, 5, True, asg)):
+        bases = ctx.fixed_base_points(g, rand_fr_canonical(0xBA5E5 + sd, n))
+        inf = np.zeros(n, dtype=np.uint8)
+        inf[0] = 1 if inf_first else 0
+        for ln in range(L):
+            assert _same_point(ctx, orc, g, p.results[name][ln], orc.multi_scalar_mul(g, bases, inf, scal[ln].reshape(-1, 4))), (name, ln)
+    c2.close()

@@ -193,10 +193,20 @@ def _open_worker(rank, world, port, q, backend, share_device):
     sh = torch.from_numpy(share_of(secret, 10).view(np.int64)).cuda()
     mac = torch.from_numpy(share_of(macv, 50).view(np.int64)).cuda()
     ok = True
-    for commit in (True, False):
-        vals = parallel.spdz_batch_open(ctx, sh, mac, alpha[rank], commit=commit)
+    for method in ("ring", "p2p"):           # the two transports of the share exchange deliver the same bytes
+        parallel.set_exchange(method)
+        for commit in (True, False):
+            vals = parallel.spdz_batch_open(ctx, sh, mac, alpha[rank], commit=commit)
+            ctx.sync()
+            ok = ok and np.array_equal(vals.cpu().numpy().view(np.uint64), secret)
+        # the reference's honest-but-curious additive open (share/add.rs:256-259): the sum of the shares
+        vals = parallel.additive_batch_open(ctx, sh)
         ctx.sync()
         ok = ok and np.array_equal(vals.cpu().numpy().view(np.uint64), secret)
+        g1, g2 = parallel.all_gather_shares(sh, ctx, method="ring"), parallel.all_gather_shares(sh, ctx, method="p2p")
+        ctx.sync()
+        ok = ok and bool(torch.equal(g1, g2))
+    parallel.set_exchange("ring")
     # a wrong MAC share must trip the check on every party
     bad_mac = mac.clone()
     if rank == world - 1:
@@ -250,3 +260,44 @@ def test_opens_over_rccl_when_two_gpus_are_present():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
     _run_open_ranks(2, "nccl", False)
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import torch
+    from czk_amd import parallel
+    parallel.init("gloo")
+    torch.manual_seed(1234 + rank)
+    x = torch.randint(-2**62, 2**62, (257, 4), dtype=torch.int64)
+    ring = parallel.all_gather_shares(x, method="ring")
+    p2p = parallel.all_gather_shares(x, method="p2p")
+    ok = ring.shape == (world, 257, 4) and bool(torch.equal(ring, p2p)) and bool(torch.equal(ring[rank], x))
+    parallel.set_exchange("p2p")
+    ok = ok and parallel.get_exchange() == "p2p" and bool(torch.equal(parallel.all_gather_shares(x), ring))
+    try:
+        parallel.set_exchange("tree")
+        ok = False
+    except ValueError:
+        pass
+    parallel.barrier()
+    q.put((rank, bool(ok)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_p2p_exchange_equals_ring_all_gather_gloo(world):
+    """the opens' share exchange as world - 1 grouped point-to-point copies (batch_isend_irecv; on an MI355X node every
+    pair of GPUs has its own xGMI link) beside the ring all-gather, selectable -- identical bytes on every rank.  CPU, gloo."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    c = mp.get_context("spawn")
+    q = c.Queue()
+    procs = [c.Process(target=_exchange_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(r, True) for r in range(world)]
