@@ -137,7 +137,7 @@ struct czk_table_set {
 };
 
 struct czk_bases {
-    static constexpr int MAX_EXTRA = 6;
+    static constexpr int MAX_EXTRA = 12;
     czk_table_set extra[MAX_EXTRA];
     std::atomic<int> n_extra{0};      // published count: readers scan [0, n_extra) without the lock
     std::mutex build_mu;              // serialises builders (contexts of several threads may share one handle)

@@ -526,7 +526,8 @@ struct MadUS<14> {
 
 // a * b / R' mod p (+ possibly p): operands may be lazy (limbs < 2^30, value < 2^7 p); result limbs normalised
 // (< 2^28, top limb small), value < 1.01 p.
-__device__ __forceinline__ FqU fqu_mul(const FqU& a, const FqU& b) {
+template <bool HI>
+__device__ __forceinline__ FqU fqu_mul_impl(const FqU& a, const FqU& b, const FqU& e) {
     constexpr int N = 14;
     u32 m[N];
     FqU r;
@@ -560,13 +561,17 @@ __device__ __forceinline__ FqU fqu_mul(const FqU& a, const FqU& b) {
             acc += FQU_MASK;                     // == (acc + m[k] * p[0]) after the shift below: carries out of the low 28 bits iff they are non-zero
                                                  // (and needs no zero-extended copy of m[k]: one v_mov per column less)
         } else {
+            if constexpr (HI) acc += e.l[k - N];
             r.l[k - N] = (u32)acc & FQU_MASK;
         }
         acc >>= 28;
     });
     r.l[N - 1] = (u32)acc;
+    if constexpr (HI) r.l[N - 1] += e.l[N - 1];
     return r;
 }
+__device__ __forceinline__ FqU fqu_mul(const FqU& a, const FqU& b) { return fqu_mul_impl<false>(a, b, a); }
+__device__ __forceinline__ FqU fqu_mul_hi(const FqU& a, const FqU& b, const FqU& e) { return fqu_mul_impl<true>(a, b, e); }   // a b / R' + e, normalised (see fqu_mul_add_hi)
 
 // a * a / R' mod p: 105 products instead of 196 (off-diagonal terms once, against the doubled operand).  Same operand
 // range as fqu_mul(a, a): limbs < 2^30, so the doubled limbs fit 31 bits and a column holds at most
@@ -622,7 +627,8 @@ __device__ __forceinline__ FqU fqu_sqr(const FqU& a) {
 // (a * b + c * d) / R' mod p with ONE Montgomery reduction (saves 182 of 756 multiply-adds).  Column capacity: the
 // caller guarantees limb(a) * limb(b) < 2^58 and limb(c) * limb(d) < 2^58 (one factor of each product normalised),
 // so a column holds < 28 * 2^58 + 13 * 2^56 < 2^63.
-__device__ __forceinline__ FqU fqu_mul_add(const FqU& a, const FqU& b, const FqU& c, const FqU& d) {
+template <bool HI>
+__device__ __forceinline__ FqU fqu_mul_add_impl(const FqU& a, const FqU& b, const FqU& c, const FqU& d, const FqU& e) {
     constexpr int N = 14;
     u32 m[N];
     FqU r;
@@ -661,13 +667,20 @@ __device__ __forceinline__ FqU fqu_mul_add(const FqU& a, const FqU& b, const FqU
             m[k] = (0u - (u32)acc) & FQU_MASK;
             acc += FQU_MASK;                     // see fqu_mul
         } else {
+            if constexpr (HI) acc += e.l[k - N];   // the addend rides the column carries: no separate add + normalise pass afterwards
             r.l[k - N] = (u32)acc & FQU_MASK;
         }
         acc >>= 28;
     });
     r.l[N - 1] = (u32)acc;
+    if constexpr (HI) r.l[N - 1] += e.l[N - 1];
     return r;
 }
+__device__ __forceinline__ FqU fqu_mul_add(const FqU& a, const FqU& b, const FqU& c, const FqU& d) { return fqu_mul_add_impl<false>(a, b, c, d, a); }
+// (a b + c d) / R' + e with the limbs of e (lazy, < 2^32, any value that keeps the result below 2^392) added into the HIGH columns before they are
+// carried out: the result is the NORMALISED form of mont(a b + c d) + e.  Replaces "multiply, then a limb-wise add / subtract, then a carry pass"
+// (68 instructions per Fq) by 14 limb subtractions that form e and 14 column adds.
+__device__ __forceinline__ FqU fqu_mul_add_hi(const FqU& a, const FqU& b, const FqU& c, const FqU& d, const FqU& e) { return fqu_mul_add_impl<true>(a, b, c, d, e); }
 
 // (a b + c d + e f + g h) / R' mod p with ONE Montgomery reduction.  Column capacity: every limb product < 2^58
 // (at most one lazy factor, < 2^30, per product), so a column holds < 56 * 2^58 + 13 * 2^56 < 2^64.
@@ -1091,31 +1104,65 @@ __device__ __forceinline__ bool fqu_low_in(const FqU& a, u32 lo, u32 hi) { retur
 __device__ __forceinline__ bool fq2u_xyzz_acc_mixed(Fq2U& ax, Fq2U& ay, Fq2U& azz, Fq2U& azzz, const Fq2U& qx, const Fq2U& qy) {
     // value bounds (units of p): table coordinates < 4, multiply outputs < 3, X < 85, Y < 36, H in (43, 131), r < 67
 #ifndef CZK_G2_KARATSUBA   // default: the four-product form with a shared -5 b1 operand (Karatsuba measured no faster: profiles/r03_g2_karatsuba.txt)
+    // pp, r and X3 leave their multiplies already combined with their addends (fqu_mul_add_hi / fqu_mul_hi: the addend's limbs enter the high
+    // columns of the product and ride its carries), so the three "subtract, then carry-propagate" passes of the straightforward form are gone
     const FqU n5zz = fqu_neg5<false>(azz.c1);
-    Fq2U u2 = fq2u_mul_n5(qx, azz, n5zz);
-    Fq2U pp{fqu_subn_128(u2.c0, ax.c0), fqu_subn_128(u2.c1, ax.c1)};
+    FqU e0, e1;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        e0.l[i] = fqu_128p(i) - ax.c0.l[i];              // 128 p - X1, limb-wise non-negative (X1 normalised)
+        e1.l[i] = fqu_128p(i) - ax.c1.l[i];
+    }
+    Fq2U pp{fqu_mul_add_hi(qx.c0, azz.c0, qx.c1, n5zz, e0), fqu_mul_add_hi(qx.c0, azz.c1, qx.c1, azz.c0, e1)};   // H = U2 - X1 + 128 p
     if (fqu_low_in(pp.c0, 40, 150) && fqu_low_in(pp.c1, 40, 150)) return false;
     const FqU n5zzz = fqu_neg5<false>(azzz.c1);
-    Fq2U s2 = fq2u_mul_n5(qy, azzz, n5zzz);
-    Fq2U r{fqu_subn_64(s2.c0, ay.c0), fqu_subn_64(s2.c1, ay.c1)};
+    FqU nay0, nay1;                                      // 64 p - Y1 (Y1 < 36 p), lazy: r's addend here, a factor of Y3 below
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        nay0.l[i] = fqu_64p(i) - ay.c0.l[i];
+        nay1.l[i] = fqu_64p(i) - ay.c1.l[i];
+    }
+    Fq2U r{fqu_mul_add_hi(qy.c0, azzz.c0, qy.c1, n5zzz, nay0), fqu_mul_add_hi(qy.c0, azzz.c1, qy.c1, azzz.c0, nay1)};   // r = S2 - Y1 + 64 p
     Fq2U p2 = fq2u_sqr(pp);                              // c1 = 2 v2 < 3 p
     const FqU n5p2 = fqu_neg5<false>(p2.c1);
     azz = fq2u_mul_n5(p2, azz, n5zz);
     Fq2U p3 = fq2u_mul_n5(pp, p2, n5p2);
     azzz = fq2u_mul_n5(p3, azzz, n5zzz);
     Fq2U qv = fq2u_mul_n5(ax, p2, n5p2);
+    {   // X3 = r^2 - p3 - 2 qv + 64 p with r^2 = ((r0 - r1)(r0 + 5 r1) - 4 r0 r1, 2 r0 r1) (fq2u_sqr): c0 as ONE multiply with everything else as its addend
+        FqU d1, d2;
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            d1.l[i] = r.c0.l[i] + (fqu_256p(i) - r.c1.l[i]);
+            d2.l[i] = r.c0.l[i] + 5u * r.c1.l[i];
+        }
+        d2 = fqu_normalize(d2);
+        const FqU v2 = fqu_mul(r.c0, r.c1);
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            e0.l[i] = (fqu_16p_u4(i) - 4u * v2.l[i]) + (fqu_64p_u3(i) - p3.c0.l[i] - qv.c0.l[i] - qv.c0.l[i]);   // < 2^31.3
+            e1.l[i] = (v2.l[i] + v2.l[i]) + (fqu_64p_u3(i) - p3.c1.l[i] - qv.c1.l[i] - qv.c1.l[i]);
+        }
+        ax.c0 = fqu_mul_hi(d1, d2, e0);
+        ax.c1 = fqu_normalize(e1);
+    }
 #else                      // -DCZK_G2_KARATSUBA: Karatsuba products (fq2u_mul_k): 952 instead of 1148 multiply-adds each, outputs < 2.1 p
     Fq2U u2 = fq2u_mul_k(qx, azz);
     Fq2U pp{fqu_subn_128(u2.c0, ax.c0), fqu_subn_128(u2.c1, ax.c1)};
     if (fqu_low_in(pp.c0, 40, 150) && fqu_low_in(pp.c1, 40, 150)) return false;
     Fq2U s2 = fq2u_mul_k(qy, azzz);
     Fq2U r{fqu_subn_64(s2.c0, ay.c0), fqu_subn_64(s2.c1, ay.c1)};
+    FqU nay0, nay1;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        nay0.l[i] = fqu_64p(i) - ay.c0.l[i];
+        nay1.l[i] = fqu_64p(i) - ay.c1.l[i];
+    }
     Fq2U p2 = fq2u_sqr(pp);                              // c1 = 2 v2 < 3 p
     azz = fq2u_mul_k(p2, azz);
     Fq2U p3 = fq2u_mul_k(pp, p2);
     azzz = fq2u_mul_k(p3, azzz);
     Fq2U qv = fq2u_mul_k(ax, p2);
-#endif
     Fq2U t = fq2u_sqr(r);
 #pragma unroll
     for (int i = 0; i < 14; i++) {                                        // X3 = t - p3 - 2 qv + 64 p
@@ -1124,16 +1171,11 @@ __device__ __forceinline__ bool fq2u_xyzz_acc_mixed(Fq2U& ax, Fq2U& ay, Fq2U& az
     }
     ax.c0 = fqu_normalize(ax.c0);
     ax.c1 = fqu_normalize(ax.c1);
+#endif
     Fq2U d{fqu_subn_128(qv.c0, ax.c0), fqu_subn_128(qv.c1, ax.c1)};
     // Y3 = d r - Y1 PPP, each component four products under one reduction (operands: d, r, p3 normalised; -Y1 lazy)
     const FqU n5r = fqu_neg5<true>(r.c1);
     const FqU n5p3 = fqu_neg5<false>(p3.c1);
-    FqU nay0, nay1;                                      // 64 p - Y1 (Y1 < 36 p)
-#pragma unroll
-    for (int i = 0; i < 14; i++) {
-        nay0.l[i] = fqu_64p(i) - ay.c0.l[i];
-        nay1.l[i] = fqu_64p(i) - ay.c1.l[i];
-    }
     ay.c0 = fqu_mul_add4(d.c0, r.c0, d.c1, n5r, nay0, p3.c0, nay1, n5p3);
     ay.c1 = fqu_mul_add4(d.c0, r.c1, d.c1, r.c0, nay0, p3.c1, nay1, p3.c0);
     return true;

@@ -634,8 +634,16 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
     const size_t n = b->n;
     const unsigned W = b->split ? 1 : b->W;   // windows held as tables
     CZK_HIP(ctx, hipMalloc(&b->pts, (size_t)W * (n ? n : 1) * AW * 8));
+#ifdef CZK_LAB   // keys keep saturated tables / the XYZZ kernels on request (A/B runs of the rejected variants)
+    const bool keep_sat = ctx->msm_sat || (GT<F>::AW != 12 && ctx->msm_sat_g2), no_te = ctx->msm_sat || ctx->msm_no_te || ctx->msm_affine_rounds > 0;
+#else
+    constexpr bool keep_sat = false, no_te = false;
+#endif
     CZK_HIP(ctx, hipMalloc(&b->inf, (size_t)W * (n ? n : 1)));
-    if (!n) return CZK_OK;
+    if (!n) {
+        b->unsat = !keep_sat;   // an empty key runs the same kernels as any other (its MSMs are the neutral element)
+        return CZK_OK;
+    }
     CZK_HIP(ctx, hipMemcpyAsync(b->pts, pts_dev, n * AW * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (inf_dev) CZK_HIP(ctx, hipMemcpyAsync(b->inf, inf_dev, n, hipMemcpyDeviceToDevice, ctx->stream));
     else CZK_HIP(ctx, hipMemsetAsync(b->inf, 0, n, ctx->stream));
@@ -661,25 +669,32 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
         CZK_HIP(ctx, hipFree(jac));
         CZK_HIP(ctx, hipFree(scr));
     }
-#ifdef CZK_LAB   // keys keep saturated tables / the XYZZ kernels on request (A/B runs of the rejected variants)
-    const bool keep_sat = ctx->msm_sat || (GT<F>::AW != 12 && ctx->msm_sat_g2), no_te = ctx->msm_sat || ctx->msm_no_te || ctx->msm_affine_rounds > 0;
-#else
-    constexpr bool keep_sat = false, no_te = false;
-#endif
     if (GT<F>::AW == 12 && b->te_wanted && !no_te) {
         // G1 bases in the prime-order subgroup: window tables as twisted Edwards niels entries (te.h), 7M unified mixed additions
         u64* te = nullptr;
         bool ok = false;
-        CZK_TRY(te_table_from_sw(ctx, b->pts, b->inf, (size_t)W * n, &te, &ok));
+        // The niels table is twice the size of the XYZZ table and is built while that one is still live: a key that fits as XYZZ tables may not fit
+        // here.  Running out of memory is not an error -- the handle keeps the XYZZ kernels (same results, ~23 % more arithmetic per addition).
+        int rc = te_table_from_sw(ctx, b->pts, b->inf, (size_t)W * n, &te, &ok);
+        if (rc == CZK_ERR_NOMEM) {
+            (void)hipGetLastError();
+            ok = false;
+        } else if (rc != CZK_OK) {
+            return rc;
+        }
+        u64* sw0 = nullptr;   // the registered points stay (secondary table sets are built from them)
         if (ok) {
-            u64* sw0 = nullptr;   // the registered points stay (secondary table sets are built from them)
             hipError_t e = hipMalloc(&sw0, n * AW * 8);
             if (e == hipSuccess) e = hipMemcpy(sw0, b->pts, n * AW * 8, hipMemcpyDeviceToDevice);
             if (e != hipSuccess) {
+                (void)hipGetLastError();
                 (void)hipFree(te);
                 if (sw0) (void)hipFree(sw0);
-                return set_err(ctx, CZK_ERR_NOMEM, "hipMalloc registered points");
+                ok = false;
+                if (e != hipErrorOutOfMemory) return set_err(ctx, CZK_ERR_HIP, std::string("registered points: ") + hipGetErrorString(e));
             }
+        }
+        if (ok) {
             (void)hipFree(b->pts);
             b->pts = te;
             b->pts_sw0 = sw0;
@@ -790,11 +805,18 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
         t = find();   // another context may have built it meanwhile
         const int n = b->n_extra.load(std::memory_order_acquire);
         if (!t && n < czk_bases::MAX_EXTRA) {
-            size_t cover = 1;
+            // ONE set per narrow class (c = 13: 2^14 points, c = 15: 2^17 -- they are small), powers of two for c = 17: at most 2 + (log2 n - 16) sets per
+            // key, so a prover that commits polynomials of many different lengths cannot run out of slots and fall back to the wide tables
+            size_t cover = cc == 13 ? ((size_t)1 << 14) : cc == 15 ? ((size_t)1 << 17) : 1;
             while (cover < size) cover <<= 1;
             if (cover > b->n) cover = b->n;
             CZK_TRY(msm_pipeline_sync(ctx));   // (the build synchronises ctx->stream; drain the MSM streams too so that timing stays attributable)
-            CZK_TRY(build_secondary<F>(ctx, b, cc, cover, &b->extra[n]));
+            int rc = build_secondary<F>(ctx, b, cc, cover, &b->extra[n]);
+            if (rc == CZK_ERR_NOMEM) {
+                (void)hipGetLastError();        // no room for another table set: this call (and later ones of its size) runs on the key's own tables
+                return CZK_OK;
+            }
+            CZK_TRY(rc);
             b->n_extra.store(n + 1, std::memory_order_release);
             t = &b->extra[n];
         }

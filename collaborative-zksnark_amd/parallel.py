@@ -72,11 +72,18 @@ def _settle(t: torch.Tensor, ctx=None):
     waits on an event recorded behind the collective (no host synchronisation: the host goes on enqueueing); without it the host waits."""
     if t is not None and t.is_cuda:
         if ctx is not None:
-            cs = _ctx_stream(ctx, t.device)
-            cs.wait_stream(torch.cuda.current_stream(t.device))
-            t.record_stream(cs)      # torch's allocator must not recycle the buffer while the context's kernels read it
+            _ctx_stream(ctx, t.device).wait_stream(torch.cuda.current_stream(t.device))
         else:
             torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
+def _after_consume(ctx, t: torch.Tensor):
+    """The context's kernels have been ENQUEUED on buffers torch allocated (the gathered shares, the result): order torch's current stream
+    behind them, so that (a) torch work on the result and (b) torch's caching allocator re-using a buffer freed by the caller are both ordered
+    after those kernels -- again an event wait, not a host synchronisation.  (No-op when the context shares torch's stream.)"""
+    if t is not None and t.is_cuda and ctx is not None:
+        torch.cuda.current_stream(t.device).wait_stream(_ctx_stream(ctx, t.device))
     return t
 
 
@@ -276,7 +283,7 @@ def spdz_batch_open(ctx, sh: torch.Tensor, mac: torch.Tensor, mac_share, commit:
     bad = ctx.fr_lanes_sum(all_dx.contiguous().data_ptr(), world, n, count_nonzero=True)
     if bad != 0:                                                            # assert!(sum.is_zero())
         raise MpcCheckError(f"SPDZ MAC check failed on {bad} of {n} opened values")
-    return vals
+    return _after_consume(ctx, vals)
 
 
 def gsz_batch_open(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
@@ -289,7 +296,7 @@ def gsz_batch_open(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
     bad = ctx.fr_gsz_open(gathered.data_ptr(), world, n, out.data_ptr(), degree=degree)
     if bad != 0:                                                            # assert!(p.degree() <= d)
         raise MpcCheckError(f"GSZ open: {bad} of {n} share polynomials exceed their degree bound")
-    return out
+    return _after_consume(ctx, out)
 
 
 def additive_batch_open(ctx, val: torch.Tensor) -> torch.Tensor:
@@ -300,4 +307,4 @@ def additive_batch_open(ctx, val: torch.Tensor) -> torch.Tensor:
     gathered = all_gather_shares(val, ctx)
     out = torch.empty_like(val)
     ctx.fr_lanes_sum(gathered.contiguous().data_ptr(), world, n, out_ptr=out.data_ptr())
-    return out
+    return _after_consume(ctx, out)

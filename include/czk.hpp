@@ -26,6 +26,7 @@
 #include <array>
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -188,9 +189,13 @@ class Radix2EvaluationDomain {
     void coset_ifft_in_place(DeviceLanes& v) const { run_device(v, CZK_COSET_IFFT); }
     void divide_by_vanishing_poly_on_coset_in_place(DeviceLanes& evals) const {
         const size_t n = evals.lanes() * evals.capacity();
-        DeviceLanes k(*ctx_, 1, 1);                      // czk_fr_vec_scale reads its constant from the vector's memory space
-        k.upload(0, 0, &vanishing_inv_, 1);
-        ctx_->check(czk_fr_vec_scale(ctx_->raw(), evals.data(), k.data(), evals.data(), n, CZK_MEM_DEVICE));
+        // czk_fr_vec_scale reads its constant from the vector's memory space: the device copy of Z(g)^-1 is made ONCE per domain and kept
+        // (a per-call allocation would cost a hipMalloc / hipFree -- a device-wide synchronisation -- on the path that never leaves HBM)
+        if (!vanishing_inv_dev_) {
+            vanishing_inv_dev_ = std::make_shared<DeviceLanes>(*ctx_, 1, 1);
+            vanishing_inv_dev_->upload(0, 0, &vanishing_inv_, 1);
+        }
+        ctx_->check(czk_fr_vec_scale(ctx_->raw(), evals.data(), vanishing_inv_dev_->data(), evals.data(), n, CZK_MEM_DEVICE));
     }
     const Context& ctx() const { return *ctx_; }
 
@@ -225,6 +230,7 @@ class Radix2EvaluationDomain {
     bool am_king_;
     size_t size_ = 0;
     Fr vanishing_inv_{};
+    mutable std::shared_ptr<DeviceLanes> vanishing_inv_dev_;   // device copy of vanishing_inv_, made on first use
 };
 
 // A proving-key query pinned on the GPU (groth16/src/data_structures.rs:132-149).
