@@ -33,7 +33,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # the MSM pipeline uses 3 internal streams (csrc/core.hip)
+# Hardware queues: a context uses 4 streams (the caller's + the MSM pipeline's sort / accumulate / reduce).  Groth16 runs ONE context: 8 queues.  The
+# Plonk / Marlin workloads keep several proofs in flight, each on its own context: with 8 queues the streams of three or more contexts share
+# queues and serialise (measured round 4: plonk 6.3 proofs/s with 3 in flight on 8 queues, 7.3 with 4 in flight on 24).  Must be set before HIP
+# initialises, hence from argv.
+_POLYIOP = any(a in ("plonk", "marlin") for a in sys.argv)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if _POLYIOP else "8")
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
@@ -116,7 +121,8 @@ def other_workloads_report(device: int) -> dict:
         t0 = time.time()
         try:
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--device", str(device), "--no-cpu-baseline", "--no-other-workloads"] + argv,
-                               capture_output=True, text=True, timeout=600, env={**os.environ, "CZK_BENCH_CHILD": "1"})
+                               capture_output=True, text=True, timeout=600,
+                               env={**{k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}, "CZK_BENCH_CHILD": "1"})
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not line:
                 out[key] = {"error": (r.stdout + r.stderr)[-400:]}
@@ -353,7 +359,7 @@ def _ec_add(F, p, q):
 def verify_openings(czk, ctx, B, out) -> dict:
     """Every KZG opening against its commitment, on the host, with the KNOWN tau of the synthetic SRS (polyvm.GpuBackend):
     C - [v] G == [tau - x] W in affine big-integer arithmetic.  Marlin's batched opening at beta is checked against the folded
-    commitment sum_j ch^j C_j."""
+    commitment sum_j ch^j C_j; hiding commitments (Marlin's w, z_a, z_b, g_1) carry their blinding evaluation `random_v`, checked with the known gamma."""
     t0 = time.perf_counter()
     q_rinv = pow(1 << 384, -1, Q_MOD)
     r_rinv = pow(1 << 256, -1, R_MOD)
@@ -378,6 +384,8 @@ def verify_openings(czk, ctx, B, out) -> dict:
             v = fr(opening["value"][ln])
             W = pt(opening["proof"][0][ln], opening["proof"][1][ln])
             lhs = _ec_add(_Fq, C, neg(_ec_scalar_mul(_Fq, g, v)))
+            if "random_v" in opening:      # a hiding commitment: C - [v] G - [random_v] (gamma G) == [tau - x] W (poly-commit/src/kzg10/mod.rs:296-312)
+                lhs = _ec_add(_Fq, lhs, neg(_ec_scalar_mul(_Fq, g, fr(opening["random_v"][ln]) * B.gamma % R_MOD)))
             rhs = _ec_scalar_mul(_Fq, W, (B.tau - opening["point"]) % R_MOD) if W is not None else None
             assert lhs == rhs, "KZG opening does not verify"
             checked += 1
@@ -464,14 +472,14 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     # Independent proofs in flight on this GPU (replica layout): each prover has its own context, stream and share lanes and
     # shares only the registered SRS.  The reference's transcript forces a drain of the MSM pipeline before every challenge; a
     # second proof fills those bubbles -- the same thing the Groth16 bench does by pipelining consecutive proofs.
-    want_inflight = args.inflight if args.inflight is not None else 2
+    want_inflight = args.inflight if args.inflight is not None else 4
     inflight = 1 if party else max(1, min(want_inflight, args.steps))
     provers = [(ctx, B, inp, torch.cuda.current_stream())]
     dev_index = torch.cuda.current_device()
     for _ in range(inflight - 1):
         ts = torch.cuda.Stream()
         with torch.cuda.stream(ts):
-            c2 = czk.Context(torch.cuda.current_device(), ts.cuda_stream)
+            c2 = czk.Context(torch.cuda.current_device(), ts.cuda_stream, options=args.ctx_options)
             b2 = polyvm.GpuBackend(czk, c2, lanes, max_deg, lift=lift, share_srs=B)
             i2 = make_inputs(b2)
             c2.sync()
@@ -662,12 +670,14 @@ def main():
                                                              "1/13 of the key memory -- what lets 8 party ranks of the 2^22 configuration share ONE GPU")
     ap.add_argument("--commit-opens", action="store_true", help="party layout: dx_t goes through atomic_broadcast (SHA-256 commit-then-open, channel.rs:50-75)")
     ap.add_argument("--inflight", type=int, default=None, help="plonk / marlin, replica layout: independent proofs in flight per GPU, each on its own context "
-                                                                 "(default 2: the transcript points of one proof drain the MSM pipeline, a second proof fills the bubbles -- round 3, "
-                                                                 "twisted Edwards G1 path: plonk 178 / 152 / 163 ms per proof with 1 / 2 / 3 in flight, marlin 231 / 205 with 1 / 2)")
+                                                                 "(default 4 with 24 hardware queues: the transcript points of one proof drain the MSM pipeline, the other proofs fill "
+                                                                 "the bubbles -- round 4: plonk 172 / 151 / 137 ms per proof with 1 / 2 / 4 in flight, marlin 226 / 198 / 184)")
     ap.add_argument("--scheme", choices=("spdz", "hbc"), default="spdz", help="groth16: spdz (default; sh + mac lane per party) or hbc (the reference's honest-but-curious "
                                                                                "additive sharing: one lane per party, mpc-snarks/src/proof.rs:379-387)")
     ap.add_argument("--exchange", choices=("ring", "p2p"), default="ring", help="party layout over RCCL: the opens' share exchange as one ring all-gather or as "
                                                                                  "world - 1 grouped point-to-point copies (parallel.set_exchange)")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE", help="czk_ctx_set_option on every context before any key is registered "
+                                                                                             "(e.g. msm_window_g1=18); repeatable")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
@@ -711,7 +721,9 @@ def main():
     # stream so that torch's copies and the library's kernels are ordered on ONE stream.
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
-    ctx = czk.Context(device, tstream.cuda_stream)
+    ctx_options = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.ctx_option}
+    args.ctx_options = ctx_options
+    ctx = czk.Context(device, tstream.cuda_stream, options=ctx_options)
     assert tstream.cuda_stream != 0
     if args.workload != "groth16":
         return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)

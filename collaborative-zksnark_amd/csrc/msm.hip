@@ -894,10 +894,15 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     }
 #endif
     if (slot.ws_sort.bytes < need_sort || slot.ws_red.bytes < need_red || slot.ws_aff.bytes < need_aff) {
+        // growing drains the pipeline and calls hipMalloc (a device-wide synchronisation): grow EVERY slot of the ring to the new size at once,
+        // so that a prover whose MSMs differ in size (KZG commitments of many lengths) stalls once per new maximum, not once per slot
         CZK_TRY(msm_pipeline_sync(ctx));
-        CZK_TRY(ensure_buf(ctx, slot.ws_sort, need_sort));
-        CZK_TRY(ensure_buf(ctx, slot.ws_red, need_red));
-        if (need_aff) CZK_TRY(ensure_buf(ctx, slot.ws_aff, need_aff));
+        for (int i = 0; i < ctx->msm_slots_in_use; i++) {
+            MsmSlot& sl = ctx->msm_slots[i];
+            CZK_TRY(ensure_buf(ctx, sl.ws_sort, need_sort));
+            CZK_TRY(ensure_buf(ctx, sl.ws_red, need_red));
+            if (need_aff) CZK_TRY(ensure_buf(ctx, sl.ws_aff, need_aff));
+        }
     }
 #ifdef CZK_LAB
     if (aff.rounds) {

@@ -230,6 +230,12 @@ __global__ void k_vec_scale(const u64* a, Fr k, u64* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         gfr_store(out, i, fp_mul(gfr_load(a, i), k));
 }
+// the same with the scalar read from DEVICE memory (czk_fr_vec_scale with CZK_MEM_DEVICE): no host round trip, no stream synchronisation
+__global__ void k_vec_scale_dev(const u64* a, const u64* kp, u64* out, size_t n) {
+    const Fr k = gfr_load(kp, 0);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        gfr_store(out, i, fp_mul(gfr_load(a, i), k));
+}
 // (ab - c) * k  -- r1cs_to_qap.rs:105-109 fused
 __global__ void k_sub_scale(const u64* ab, const u64* c, Fr k, u64* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -600,13 +606,15 @@ extern "C" int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t*
     if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
-    u64 kh[4];
     if (mem == CZK_MEM_DEVICE) {
-        CZK_HIP(ctx, hipMemcpyAsync(kh, k, 32, hipMemcpyDeviceToHost, ctx->stream));
-        CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    } else {
-        for (int i = 0; i < 4; i++) kh[i] = k[i];
+        // the scalar lives in device memory like the vectors: read it in the kernel (a copy to the host would synchronise the stream -- a
+        // full pipeline stall in the middle of a prover's round, which is what this call cost the Plonk / Marlin drivers until round 4)
+        hipLaunchKernelGGL(k_vec_scale_dev, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, a, k, out, n);
+        CZK_HIP(ctx, hipGetLastError());
+        return CZK_OK;
     }
+    u64 kh[4];
+    for (int i = 0; i < 4; i++) kh[i] = k[i];
     Fr kk;
     for (int i = 0; i < 4; i++) {
         kk.l[2 * i] = (u32)kh[i];

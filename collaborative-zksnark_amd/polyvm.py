@@ -52,8 +52,23 @@ class Pending:
         self.value, self._src = None, src
 
 
+class CommitmentSum:
+    """`commitment.add_assign_mixed(&random_commitment)` (poly-commit/src/kzg10/mod.rs:188) / `w += ...` (:246-249): the O(1) group addition of
+    two commitments (each possibly Pending), carried out on the host when the output is resolved."""
+    __slots__ = ("B", "a", "b")
+
+    def __init__(self, B, a, b):
+        self.B, self.a, self.b = B, a, b
+
+
+Q_MOD = 258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177
+_FQ_ONE = np.array([((1 << 384) % Q_MOD >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)], dtype=np.uint64)   # Montgomery one of Fq
+
+
 def resolved(x):
     """x with every Pending replaced by its value (dicts, lists and tuples are walked)."""
+    if isinstance(x, CommitmentSum):
+        return x.B.group_add(resolved(x.a), resolved(x.b))
     if isinstance(x, Pending):
         assert x.value is not None, "Pending read before a transcript_point()"
         return x.value
@@ -103,7 +118,9 @@ class Backend:
     def div_linear(self, a, z: int): raise NotImplementedError       # (quotient array, remainder (lanes, 4) numpy)
     def prefix_product(self, a): raise NotImplementedError
     def inverse(self, a): raise NotImplementedError                  # element-wise, zeros stay zero
-    def commit(self, a): raise NotImplementedError                   # -> ((lanes, 12) affine limbs, (lanes,) infinity flags) numpy
+    def commit(self, a, key="g"): raise NotImplementedError          # -> ((lanes, 12) affine limbs, (lanes,) infinity flags) numpy; key "gamma": over powers_of_gamma_g
+    def jac_add_mixed(self, a_jac, b_aff, b_inf): raise NotImplementedError   # host-side group step on (18,) / (12,) G1 limbs
+    def jac_to_affine(self, jac): raise NotImplementedError          # (k, 18) -> ((k, 12), (k,))
     def random(self, seed: int, n: int): raise NotImplementedError   # public (1, n, 4): rand_fr_canonical(seed, n) in Montgomery form
     def root_of_unity(self, size: int) -> int: raise NotImplementedError   # get_root_of_unity(size), canonical integer
 
@@ -188,6 +205,15 @@ class Backend:
         """a(x) per lane, (lanes, 4) -- the remainder of the division by (X - x)"""
         return self.div_linear(a, x)[1]
 
+    def group_add(self, ca, cb):
+        """lane-wise sum of two commitments ((lanes, 12) affine limbs, (lanes,) infinity flags): GroupProjective::add_assign_mixed
+        (short_weierstrass_jacobian.rs:570-638) on the host, then into_affine"""
+        jacs = []
+        for ln in range(ca[0].shape[0]):
+            a_jac = np.concatenate([_FQ_ONE, _FQ_ONE, np.zeros(6, np.uint64)]) if ca[1][ln] else np.concatenate([ca[0][ln], _FQ_ONE])
+            jacs.append(self.jac_add_mixed(a_jac, cb[0][ln], bool(cb[1][ln])))
+        return self.jac_to_affine(np.stack(jacs))
+
     def transcript_point(self):
         """Called where the reference feeds commitments / evaluations to its Fiat-Shamir transcript before drawing the next
         challenge (mpc-plonk/src/lib.rs:110-113, 343-369; marlin/src/lib.rs:206-260): everything committed or evaluated so far
@@ -237,6 +263,16 @@ class GpuBackend(Backend):
             self.bases = ctx.register_bases(czk.CZK_G1, pts.data_ptr(), None, n=n, mem=czk.CZK_MEM_DEVICE)
             ctx.sync()
             self.bases_host = (lambda: pts.cpu().numpy().view(np.uint64))      # for the checker-side backend of the tests
+        # powers_of_gamma_g = [gamma tau^i] G (poly-commit/src/kzg10/mod.rs:92-101): the bases of the blinding polynomials' commitments; a hiding
+        # bound of 1 needs three of them (data_structures.rs:464-481) -- eight are registered
+        self.gamma = challenge("kzg.gamma.%x" % base_seed)
+        if share_srs is not None:
+            self.bases_gamma, self.bases_gamma_host = share_srs.bases_gamma, share_srs.bases_gamma_host
+        else:
+            kc = np.array([[(self.gamma * pow(self.tau, i, R_MOD) % R_MOD >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for i in range(8)], dtype=np.uint64)
+            gpts = ctx.fixed_base_points(czk.CZK_G1, kc)                      # canonical scalars gamma tau^i
+            self.bases_gamma = ctx.register_bases(czk.CZK_G1, gpts, None)
+            self.bases_gamma_host = (lambda: gpts)
         self.base_seed, self.n_bases = base_seed, n
         self.msm_count = self.ntt_count = 0
         self._pending = []      # commitments / evaluations enqueued since the last transcript_point()
@@ -346,8 +382,10 @@ class GpuBackend(Backend):
         return out
 
     def ntt(self, a, size, kind):
-        buf = self.resized(a, size)
-        self.ctx.ntt_fr_mixed(buf.data_ptr(), size, kind, lanes=buf.shape[0], in_len=min(a.shape[1], size), mem=self.M)
+        m = min(a.shape[1], size)
+        buf = self.torch.empty((a.shape[0], size, 4), dtype=self.torch.int64, device=self.dev)   # not zero-filled: the first pass zero-extends
+        buf[:, :m] = a[:, :m]                                                                   # beyond in_len itself (czk_ntt_fr_mixed)
+        self.ctx.ntt_fr_mixed(buf.data_ptr(), size, kind, lanes=buf.shape[0], in_len=m, mem=self.M)
         self.ntt_count += buf.shape[0]
         return buf
 
@@ -400,14 +438,21 @@ class GpuBackend(Backend):
     def root_of_unity(self, size):
         return unmont(self.ctx.mixed_domain_constants(size)["group_gen"])
 
-    def commit(self, a):
+    def jac_add_mixed(self, a_jac, b_aff, b_inf):
+        return self.ctx.jac_add_mixed(self.czk.CZK_G1, a_jac, b_aff, b_inf)
+
+    def jac_to_affine(self, jac):
+        return self.ctx.jac_to_affine(self.czk.CZK_G1, jac)
+
+    def commit(self, a, key="g"):
         """Enqueues the MSM (czk_msm_async: the sort / accumulate / reduce stages of consecutive commitments overlap on the
         library's streams, and with the NTTs enqueued after them) and returns a Pending; transcript_point() settles it."""
         a = a.contiguous()
         n = a.shape[1]
-        assert n <= self.n_bases, "polynomial longer than powers_of_g"
+        bases = self.bases if key == "g" else self.bases_gamma
+        assert n <= len(bases), "polynomial longer than the committer key"
         jac = np.zeros((a.shape[0], 18), dtype=np.uint64)
-        self.ctx.msm_async(self.bases, a.data_ptr(), n_scalars=n, lanes=a.shape[0], scalar_form=self.czk.CZK_SCALAR_MONTGOMERY, out=jac)
+        self.ctx.msm_async(bases, a.data_ptr(), n_scalars=n, lanes=a.shape[0], scalar_form=self.czk.CZK_SCALAR_MONTGOMERY, out=jac)
         self.msm_count += a.shape[0]
         self.msm_points += a.shape[0] * n
         p = Pending(("commit", jac, a))       # `a` stays referenced until the MSM has read it
@@ -599,9 +644,18 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     and everything in the third round are public, as in the reference."""
     H, K, X, b_size = inp["H"], inp["K"], inp["X"], inp["b_size"]
     out = {}
+    blind = {}      # label -> blinding polynomial of a hiding commitment (share lanes, three coefficients)
 
-    def commit(label, a):
-        out[label + "_cmt"] = B.commit(a)
+    def commit(label, a, hiding=False):
+        """marlin_pc::commit -> KZG10::commit (poly-commit/src/kzg10/mod.rs:141-192).  A hiding bound of Some(1) (prover.rs:386-388, :559) samples a
+        blinding polynomial of degree hiding_bound + 1 (data_structures.rs:464-481), commits it over powers_of_gamma_g (:181-186) and adds the two
+        commitments (:188).  (Without a hiding bound the reference still calls the second MSM with no coefficients: a no-op, not issued here.)  The
+        blinding coefficients are fixed stand-ins, shared like every witness-side vector."""
+        c = B.commit(a)
+        if hiding:
+            blind[label] = shared_copy(B, B.random(0xB11D + sum(map(ord, label)), 3))
+            c = CommitmentSum(B, c, B.commit(blind[label], key="gamma"))
+        out[label + "_cmt"] = c
 
     def mask(a, tag, n_dom):
         """a + rand * v_H: the zk blinding of the first-round polynomials (prover.rs:359-374); the blinding scalar is a fixed
@@ -619,7 +673,7 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     z_b = mask(B.ntt(inp["z_b"], H, IFFT), "zb", H)
     mask_poly = inp["mask_poly"]
     for label, a in (("w", w_poly), ("z_a", z_a), ("z_b", z_b), ("mask_poly", mask_poly)):
-        commit(label, a)
+        commit(label, a, hiding=label != "mask_poly")                             # hiding bounds Some(1), Some(1), Some(1), None (:386-390)
     # ---- second round (:439-556) ----------------------------------------------------------------------------
     B.transcript_point()
     alpha, eta_a, eta_b, eta_c = (challenge("marlin." + t) for t in ("alpha", "eta_a", "eta_b", "eta_c"))
@@ -640,11 +694,12 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     h_1, x_g_1 = B.div_vanishing(q_1, H)
     g_1 = B.drop_first(x_g_1, 1)
     for label, a in (("t", t_poly), ("g_1", g_1), ("h_1", h_1)):
-        commit(label, a)
+        commit(label, a, hiding=label == "g_1")                                    # hiding bounds None, Some(1), None (:558-560)
         if label == "g_1":
             # a degree-bounded oracle (g_1: |H| - 2) carries a second commitment over the shifted powers (marlin_pc/mod.rs commit: `shifted_comm`):
-            # the same scalars, the same length -- the stand-in key commits over the same prefix of powers
-            commit("g_1_shifted", a)
+            # the same scalars, the same length -- the stand-in key commits over the same prefix of powers -- with its own blinding polynomial
+            # (`shifted_rand`, marlin_pc/mod.rs:218-232)
+            commit("g_1_shifted", a, hiding=True)
     # ---- third round (:585-704): everything public ---------------------------------------------------------------
     B.transcript_point()
     beta = challenge("marlin.beta")
@@ -735,11 +790,33 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
         # the shifted-witness opening: (g - g(point)) / (X - point), computed inside the folding loop (:294-299), committed over the
         # shifted powers after the folded polynomial has been opened (:318-330) -- the stand-in key commits over the same prefix of
         # powers (same scalars, same length: same work)
+        # Inside the folding loop the reference computes, for the degree-bounded polynomial, its witness AND the witness of its shifted randomness
+        # (compute_witness_polynomial(polynomial, point, shifted_rand), marlin_pc/mod.rs:294-299 -> kzg10/mod.rs:200-224) ...
         sh = B.open_begin(polys[shifted], point[tag], public=B.lanes_of(polys[shifted]) == 1 and B.lanes > 1)
-        out["open_" + tag] = B.open_at(folded, point[tag])
-        out["open_" + tag]["terms"] = terms                                        # the opened polynomial as sum coef * committed polynomial
-        out["open_" + tag + "_shifted"] = B.open_finish(sh)
-        out["open_" + tag + "_shifted"]["of"] = shifted
+        sh_rand = B.open_begin(blind[shifted + "_shifted"], point[tag]) if shifted + "_shifted" in blind else None
+        # ... then opens the folded polynomial with the folded randomness (`r += (challenge_j, &rand.rand)`, :288; KZG10::open :313): witness and
+        # random witness r / (X - point) (kzg10 :211-218), MSM of the witness, blinding evaluation r(point), MSM of the random witness over
+        # powers_of_gamma_g added to w (:238-249).  Only beta's query set holds hiding polynomials (w, z_a, z_b, g_1).
+        r_fold = None
+        for coef, name in terms:
+            if name in blind:
+                term = blind[name] if coef == 1 else B.scale(blind[name], coef)
+                r_fold = term if r_fold is None else B.add(r_fold, term)
+        o = B.open_begin(folded, point[tag])
+        rw = B.open_begin(r_fold, point[tag]) if r_fold is not None else None
+        o = B.open_finish(o)
+        o["terms"] = terms                                                          # the opened polynomial as sum coef * committed polynomial
+        if rw is not None:
+            o["random_v"] = rw["value"]
+            o["proof"] = CommitmentSum(B, o["proof"], B.commit(rw.pop("_wit"), key="gamma"))
+        out["open_" + tag] = o
+        # ... and the shifted witness over the shifted powers, with the shifted randomness' witness (open_with_witness_polynomial, :318-330)
+        so = B.open_finish(sh)
+        so["of"] = shifted + "_shifted" if sh_rand is not None else shifted
+        if sh_rand is not None:
+            so["random_v"] = sh_rand["value"]
+            so["proof"] = CommitmentSum(B, so["proof"], B.commit(sh_rand.pop("_wit"), key="gamma"))
+        out["open_" + tag + "_shifted"] = so
     B.transcript_point()
     return resolved(out)
 

@@ -5,12 +5,13 @@ import numpy as np
 from util import rand_fr_canonical
 
 
-def make_backend(orc, polyvm, lanes, max_degree, base_seed=0xBA5E5 + 77, lift=None, bases=None):
+def make_backend(orc, polyvm, lanes, max_degree, base_seed=0xBA5E5 + 77, lift=None, bases=None, bases_gamma=None):
     class OracleBackend(polyvm.Backend):
         def __init__(self):
             self.lanes = lanes
             self.lift = tuple([1] * lanes) if lift is None else tuple(lift)
             self.bases = bases          # (n, 12) affine Montgomery limbs of [k_i] G, produced once by the caller
+            self.bases_gamma = bases_gamma   # powers_of_gamma_g (8 points), likewise
 
         def upload(self, a):
             a = np.ascontiguousarray(a, dtype=np.uint64)
@@ -109,12 +110,20 @@ def make_backend(orc, polyvm, lanes, max_degree, base_seed=0xBA5E5 + 77, lift=No
         def root_of_unity(self, size):
             return polyvm.unmont(orc.fr_root_of_unity_mixed(size))
 
-        def commit(self, a):
+        def jac_add_mixed(self, a_jac, b_aff, b_inf):
+            return orc.jac_add_mixed(1, a_jac, b_aff, b_inf)
+
+        def jac_to_affine(self, jac):
+            affs, infs = zip(*(orc.jac_to_affine(1, j) for j in jac))
+            return np.stack(affs), np.array([1 if i else 0 for i in infs], dtype=np.uint8)
+
+        def commit(self, a, key="g"):
             n = a.shape[1]
             inf = np.zeros(n, dtype=np.uint8)
+            bases = self.bases if key == "g" else self.bases_gamma
             affs, infs = [], []
             for l in range(a.shape[0]):
-                jac = orc.multi_scalar_mul(1, self.bases[:n], inf, np.ascontiguousarray(a[l]))
+                jac = orc.multi_scalar_mul(1, bases[:n], inf, np.ascontiguousarray(a[l]))
                 aff, is_inf = orc.jac_to_affine(1, jac)
                 affs.append(aff)
                 infs.append(1 if is_inf else 0)
@@ -175,8 +184,19 @@ def make_lockstep(polyvm, gpu, cpu):
             assert np.array_equal(gr, cr), "div_linear remainder"
             return self._chk("div_linear", gq, cq), cr
 
-        def commit(self, a):
-            g, c = gpu.commit(a[0]), cpu.commit(a[1])
+        def jac_add_mixed(self, a_jac, b_aff, b_inf):
+            g, c = gpu.jac_add_mixed(a_jac, b_aff, b_inf), cpu.jac_add_mixed(a_jac, b_aff, b_inf)
+            ga, ca = gpu.jac_to_affine(g[None]), cpu.jac_to_affine(c[None])
+            assert np.array_equal(ga[1], ca[1]) and (ca[1][0] or np.array_equal(ga[0], ca[0])), "jac_add_mixed"
+            return c
+
+        def jac_to_affine(self, jac):
+            g, c = gpu.jac_to_affine(jac), cpu.jac_to_affine(jac)
+            assert np.array_equal(g[1], c[1]) and np.array_equal(g[0][g[1] == 0], c[0][c[1] == 0]), "jac_to_affine"
+            return c
+
+        def commit(self, a, key="g"):
+            g, c = gpu.commit(a[0], key), cpu.commit(a[1], key)
             gpu.transcript_point()          # the product backend commits asynchronously
             g = g.value
             assert np.array_equal(g[1], c[1]) and np.array_equal(g[0][g[1] == 0], c[0][c[1] == 0]), "commit"

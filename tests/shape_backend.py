@@ -84,8 +84,11 @@ class ShapeBackend(Backend):
         self.log.append(("batch_inverse", a.n, a.lanes))
         return Arr(a.lanes, a.n)
 
-    def commit(self, a):
-        self.log.append(("msm", a.n, a.lanes))
+    def jac_add_mixed(self, a_jac, b_aff, b_inf): return np.zeros(18, dtype=np.uint64)
+    def jac_to_affine(self, jac): return np.zeros((len(jac), 12), dtype=np.uint64), np.zeros(len(jac), dtype=np.uint8)
+
+    def commit(self, a, key="g"):
+        self.log.append(("msm" if key == "g" else "msm_gamma", a.n, a.lanes))
         p = Pending(None)
         p.value = (np.zeros((a.lanes, 12), dtype=np.uint64), np.zeros(a.lanes, dtype=np.uint8))
         return p

@@ -21,6 +21,7 @@ def _compare(got, want):
             assert np.array_equal(got[k]["value"], want[k]["value"]), k
             assert np.array_equal(got[k]["proof"][1], want[k]["proof"][1]), k
             assert np.array_equal(got[k]["proof"][0], want[k]["proof"][0]), k
+            assert ("random_v" in got[k]) == ("random_v" in want[k]) and np.array_equal(got[k].get("random_v"), want[k].get("random_v")), k
 
 
 @pytest.mark.parametrize("n_gates,parties", [(8, 3), (64, 3)])
@@ -32,7 +33,7 @@ def test_plonk_gsz_pipeline_matches_checker(orc, n_gates, parties):
     ctx = polyvm.shared_stream_context(czk_amd)
     md = polyvm.plonk_max_degree(n_gates)
     gpu = polyvm.GpuBackend(czk_amd, ctx, parties, md)
-    cpu = make_backend(orc, polyvm, parties, md, bases=gpu.bases_host())
+    cpu = make_backend(orc, polyvm, parties, md, bases=gpu.bases_host(), bases_gamma=gpu.bases_gamma_host())
     from oracle_backend import make_lockstep
     ls = make_lockstep(polyvm, gpu, cpu)
     polyvm.plonk_prove(ls, polyvm.plonk_inputs(ls, n_gates))   # operation by operation: a divergence names the primitive
@@ -55,7 +56,7 @@ def test_marlin_spdz_pipeline_matches_checker(orc, n_constraints):
     md = polyvm.marlin_max_degree(n_constraints)
     lift = (1, 1, 0, 0)
     gpu = polyvm.GpuBackend(czk_amd, ctx, 4, md, lift=lift)
-    cpu = make_backend(orc, polyvm, 4, md, lift=lift, bases=gpu.bases_host())
+    cpu = make_backend(orc, polyvm, 4, md, lift=lift, bases=gpu.bases_host(), bases_gamma=gpu.bases_gamma_host())
     from oracle_backend import make_lockstep
     ls = make_lockstep(polyvm, gpu, cpu)
     polyvm.marlin_prove(ls, polyvm.marlin_inputs(ls, n_constraints))
