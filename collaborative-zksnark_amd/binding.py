@@ -121,6 +121,11 @@ class Context:
         """hipStream_t of this context as an integer (czk_ctx_stream): torch.cuda.ExternalStream(handle) orders torch work against it"""
         return int(self._L.czk_ctx_stream(self._h) or 0)
 
+    def reserve(self, ntt_log_d: int = 0, ntt_lanes: int = 0, bases=None, n_scalars: int = 0, msm_lanes: int = 0):
+        """czk_ctx_reserve: build NTT tables / size MSM workspaces now instead of inside the first proof"""
+        self._ck(self._L.czk_ctx_reserve(self._h, C.c_uint(ntt_log_d), C.c_size_t(ntt_lanes), bases._h if bases is not None else None, C.c_size_t(n_scalars),
+                                         C.c_size_t(msm_lanes)))
+
     def set_option(self, name: str, value: int):
         self._ck(self._L.czk_ctx_set_option(self._h, name.encode(), C.c_long(int(value))))
 

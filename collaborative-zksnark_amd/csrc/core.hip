@@ -381,6 +381,13 @@ extern "C" int czk_build_is_lab(void) {
 #endif
 }
 
+extern "C" int czk_ctx_reserve(czk_ctx* ctx, unsigned ntt_log_d, size_t ntt_lanes, const czk_bases* bases, size_t n_scalars, size_t msm_lanes) {
+    if (!ctx) return CZK_ERR_ARG;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ntt_lanes) CZK_TRY(ntt_reserve(ctx, ntt_log_d, ntt_lanes));
+    if (bases && msm_lanes) CZK_TRY(msm_reserve(ctx, bases, n_scalars, msm_lanes));
+    return CZK_OK;
+}
 extern "C" void* czk_ctx_stream(const czk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 extern "C" int czk_ctx_sync(czk_ctx* ctx) {
     if (!ctx) return CZK_ERR_ARG;

@@ -255,6 +255,8 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
 int get_mixed_domain(czk_ctx* ctx, unsigned k, MixedDomain** out);
 int ntt_mixed_device(czk_ctx* ctx, u64* data, unsigned k, size_t lanes, int kind, size_t in_len);
 // implemented in msm.hip
+int msm_reserve(czk_ctx* ctx, const czk_bases* bases, size_t n_scalars, size_t lanes);   // czk_ctx_reserve (msm.hip)
+int ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes);                                   // czk_ctx_reserve (ntt.hip)
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
                int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable);
 int msm_pipeline_init(czk_ctx* ctx);

@@ -834,7 +834,7 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
 // buffer by msm_collect() after the streams are synchronised.
 template <class F>
 static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host,
-                       bool scalars_stable) {
+                       bool scalars_stable, bool reserve_only = false) {
     constexpr int JW = GT<F>::JW, XW = GT<F>::XW;   // results leave as Jacobian; buckets are XYZZ internally
     const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
     // Bases without window tables (b->split): the W digit windows of every scalar lane become W "virtual lanes", each a
@@ -857,7 +857,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if ((size_t)W * nb >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
     CZK_TRY(msm_pipeline_init(ctx));
     MsmSlot& slot = ctx->msm_slots[ctx->msm_next_slot];
-    ctx->msm_next_slot = (ctx->msm_next_slot + 1) % ctx->msm_slots_in_use;
+    if (!reserve_only) ctx->msm_next_slot = (ctx->msm_next_slot + 1) % ctx->msm_slots_in_use;
 
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
@@ -904,6 +904,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             if (need_aff) CZK_TRY(ensure_buf(ctx, sl.ws_aff, need_aff));
         }
     }
+    if (reserve_only) return CZK_OK;   // czk_ctx_reserve: table set chosen (and built), streams created, every workspace of the ring sized
 #ifdef CZK_LAB
     if (aff.rounds) {
         Bump ba{(char*)slot.ws_aff.p};
@@ -1175,6 +1176,11 @@ void msm_pipeline_destroy(czk_ctx* ctx) {
     (void)hipStreamDestroy(ctx->s_acc);
     (void)hipStreamDestroy(ctx->s_red);
     ctx->s_sort = nullptr;
+}
+
+int msm_reserve(czk_ctx* ctx, const czk_bases* bases, size_t n_scalars, size_t lanes) {
+    return bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, nullptr, n_scalars, lanes, CZK_SCALAR_CANONICAL, nullptr, false, true)
+                                  : msm_enqueue<Fq2>(ctx, bases, nullptr, n_scalars, lanes, CZK_SCALAR_CANONICAL, nullptr, false, true);
 }
 
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes, int scalar_form,

@@ -601,6 +601,17 @@ extern "C" int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint
     return so.to_host(out, n * 32);
 }
 
+// czk_ctx_reserve: the tables of one radix-2 domain (all four kinds) and the pass scratch for `lanes` lanes, built now instead of by the first transform
+int ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes) {
+    DomainTables* d = nullptr;
+    CZK_TRY(get_domain(ctx, log_d, &d));
+    CZK_TRY(ensure_tables(ctx, d, true, true));
+    const size_t D = (size_t)1 << log_d;
+    if (log_d > 7 && lanes) CZK_TRY(ensure_buf(ctx, ctx->ntt_scratch, lanes * D * (log_d >= NTT2_MIN_LOG ? NTT2_SCRATCH_ELEM_BYTES : 32)));
+    CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CZK_OK;
+}
+
 extern "C" int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n, int mem) {
     if (!ctx || !k || (n && (!a || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "bad vec_scale argument") : CZK_ERR_ARG;
     if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");

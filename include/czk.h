@@ -91,6 +91,11 @@ int czk_ctx_sync(czk_ctx* ctx);
 /* The hipStream_t the context enqueues on (the one given to czk_ctx_create, or its private stream): lets a caller order its own
  * streams against the context's with events (hipStreamWaitEvent) instead of czk_ctx_sync -- e.g. an RCCL exchange between two opens. */
 void* czk_ctx_stream(const czk_ctx* ctx);
+/* What the library otherwise allocates and builds on FIRST use, done now: the twiddle / coset tables of the radix-2 domain 2^ntt_log_d and the
+ * pass scratch for `ntt_lanes` lanes (ntt_lanes = 0: skip), and -- for MSMs of n_scalars scalars x msm_lanes lanes over `bases` (NULL: skip) --
+ * the MSM pipeline's streams, the table set such calls use and every workspace of its ring.  A prover that cares about the latency of its first
+ * proof after loading a key calls this once per (domain, key); results are unaffected.  Blocking. */
+int czk_ctx_reserve(czk_ctx* ctx, unsigned ntt_log_d, size_t ntt_lanes, const czk_bases* bases, size_t n_scalars, size_t msm_lanes);
 const char* czk_last_error(const czk_ctx* ctx);
 const char* czk_version(void);
 /* Tuning options of one context.  The library reads NO environment variables: everything a caller may select is named here.

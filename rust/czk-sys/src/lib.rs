@@ -49,6 +49,7 @@ extern "C" {
     pub fn czk_ctx_destroy(ctx: *mut czk_ctx);
     pub fn czk_ctx_sync(ctx: *mut czk_ctx) -> c_int;
     pub fn czk_ctx_stream(ctx: *const czk_ctx) -> *mut c_void;
+    pub fn czk_ctx_reserve(ctx: *mut czk_ctx, ntt_log_d: c_uint, ntt_lanes: usize, bases: *const czk_bases, n_scalars: usize, msm_lanes: usize) -> c_int;
     pub fn czk_last_error(ctx: *const czk_ctx) -> *const c_char;
     pub fn czk_version() -> *const c_char;
     pub fn czk_ctx_set_option(ctx: *mut czk_ctx, name: *const c_char, value: c_long) -> c_int;
