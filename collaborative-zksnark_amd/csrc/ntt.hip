@@ -602,7 +602,7 @@ extern "C" int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint
 }
 
 // czk_ctx_reserve: the tables of one radix-2 domain (all four kinds) and the pass scratch for `lanes` lanes, built now instead of by the first transform
-int ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes) {
+int czk::ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes) {
     DomainTables* d = nullptr;
     CZK_TRY(get_domain(ctx, log_d, &d));
     CZK_TRY(ensure_tables(ctx, d, true, true));
