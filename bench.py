@@ -678,6 +678,7 @@ def main():
                                                                                  "world - 1 grouped point-to-point copies (parallel.set_exchange)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE", help="czk_ctx_set_option on every context before any key is registered "
                                                                                              "(e.g. msm_window_g1=18); repeatable")
+    ap.add_argument("--no-gate", action="store_true", help="groth16: do not gate the witness map on the proof's own G2 MSM (czk_msm_gate; A/B switch)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
@@ -733,6 +734,8 @@ def main():
         prover.commit_opens = args.commit_opens
     else:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme)
+
+    prover.gate_witness_map = not args.no_gate
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)
