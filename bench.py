@@ -90,15 +90,17 @@ def busy_union_ms(ctxs, names) -> float:
     return float(busy + cur1 - cur0)
 
 
-def csrc_changed_since(commit: str):
-    """Does `git diff <commit>..HEAD -- csrc` touch the kernels?  (None when git or the commit is unavailable, e.g. on the GPU box.)"""
-    try:
-        r = subprocess.run(["git", "-C", ROOT, "diff", "--stat", f"{commit}..HEAD", "--", "collaborative-zksnark_amd/csrc"], capture_output=True, text=True, timeout=20)
-        if r.returncode != 0:
-            return None
-        return [ln.split("|")[0].strip().split("/")[-1] for ln in r.stdout.splitlines() if "|" in ln]
-    except Exception:      # noqa: BLE001
-        return None
+def csrc_digest() -> str:
+    """SHA-256 over the product's kernel sources (csrc/*.hip, *.h, *.inc; not csrc/lab/) in name order: stored with a PMC profile
+    (tools/pmc_summary.py) and recomputed here, so that a bench line can say whether the kernels it ran are the ones the counters were
+    taken from -- without git history (the GPU box has none)."""
+    d = os.path.join(ROOT, "collaborative-zksnark_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".inc")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:16]
 
 
 OTHER_WORKLOADS = (   # (key, bench.py arguments, HBM the run needs in GB) -- BASELINE configs[2], [3] and the configs[4] size on ONE GPU
@@ -678,7 +680,6 @@ def main():
                                                                                  "world - 1 grouped point-to-point copies (parallel.set_exchange)")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE", help="czk_ctx_set_option on every context before any key is registered "
                                                                                              "(e.g. msm_window_g1=18); repeatable")
-    ap.add_argument("--no-gate", action="store_true", help="groth16: do not gate the witness map on the proof's own G2 MSM (czk_msm_gate; A/B switch)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
@@ -734,8 +735,6 @@ def main():
         prover.commit_opens = args.commit_opens
     else:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme)
-
-    prover.gate_witness_map = not args.no_gate
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)
@@ -823,10 +822,9 @@ def main():
                 pmc = json.load(open(tf))
                 traffic = pmc.get("msm_accumulate_g1_bytes_per_launch")
                 traffic_src = f"profiles/{name}" + (f" @ {pmc['commit']}" if "commit" in pmc else "")
-                if "commit" in pmc:
-                    ch = csrc_changed_since(pmc["commit"])
-                    traffic_src += ("; csrc changed since: unknown (no git history here)" if ch is None else
-                                    "; csrc unchanged since" if not ch else f"; csrc files changed since: {', '.join(ch)} (see DESIGN.md for which are on the default path)")
+                if "csrc_sha256" in pmc:
+                    traffic_src += "; kernel sources unchanged since" if pmc["csrc_sha256"] == csrc_digest() else \
+                                   f"; kernel sources CHANGED since (profile {pmc['csrc_sha256']}, now {csrc_digest()})"
                 break
             except Exception:
                 pmc = {}

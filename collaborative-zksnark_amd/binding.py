@@ -270,10 +270,6 @@ class Context:
                                      C.c_int(CZK_MEM_DEVICE | (16 if stable else 0)), _ptr(out)))
         return out
 
-    def msm_gate(self):
-        """czk_msm_gate: later work on this context waits (on the GPU) for the most recently enqueued MSM's accumulate kernel to start"""
-        self._ck(self._L.czk_msm_gate(self._h))
-
     def msm_oneshot(self, group, bases, inf, scalars, lanes=1, scalar_form=CZK_SCALAR_CANONICAL):
         aw, jw = (12, 18) if group == CZK_G1 else (24, 36)
         bases = np.ascontiguousarray(bases, np.uint64)

@@ -63,7 +63,7 @@ struct DeviceBuf {
 };
 struct MsmSlot {
     DeviceBuf ws_sort, ws_red, ws_aff;
-    hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_fix = nullptr, ev_red = nullptr, ev_acc_start = nullptr;
+    hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_fix = nullptr, ev_red = nullptr;
     bool used = false;
 };
 struct MsmPending {
@@ -87,7 +87,6 @@ struct czk_ctx {
     // MSM pipeline (msm.hip)
     hipStream_t s_sort = nullptr, s_acc = nullptr, s_red = nullptr;
     hipEvent_t ev_in = nullptr;
-    hipEvent_t last_acc_start = nullptr;   // recorded on the accumulate stream just before the most recently enqueued MSM's accumulate kernel (czk_msm_gate)
     static constexpr int MSM_SLOTS = 4;   // workspace ring: accumulate(k + MSM_SLOTS) waits for reduce(k)
     czk::MsmSlot msm_slots[MSM_SLOTS];
     int msm_next_slot = 0;

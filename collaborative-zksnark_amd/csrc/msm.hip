@@ -1018,8 +1018,6 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     if (!scalars_stable) CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
     CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
-    CZK_HIP(ctx, hipEventRecord(slot.ev_acc_start, sa));                   // "this MSM's accumulate kernel is next on its stream" (czk_msm_gate)
-    ctx->last_acc_start = slot.ev_acc_start;
     if (te) {
         launch_accumulate_g1_te(ctx, sa, tv.pts, sorted, offsets, counts, perm, B, (size_t)W * size, buckets, (unsigned)lanes);
     } else if (b->unsat) {
@@ -1131,7 +1129,6 @@ int msm_pipeline_init(czk_ctx* ctx) {
     for (auto& s : ctx->msm_slots) {
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_sorted, hipEventDisableTiming));
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_acc, hipEventDisableTiming));
-        CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_acc_start, hipEventDisableTiming));
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_fix, hipEventDisableTiming));
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_red, hipEventDisableTiming));
     }
@@ -1170,7 +1167,6 @@ void msm_pipeline_destroy(czk_ctx* ctx) {
         if (s.ws_aff.p) (void)hipFree(s.ws_aff.p);
         (void)hipEventDestroy(s.ev_sorted);
         (void)hipEventDestroy(s.ev_acc);
-        (void)hipEventDestroy(s.ev_acc_start);
         (void)hipEventDestroy(s.ev_fix);
         (void)hipEventDestroy(s.ev_red);
     }
@@ -1375,11 +1371,6 @@ static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scal
     int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp.p != nullptr, stable && !blocking);
     if (tmp.p) stage_give(ctx, tmp);
     return rc;
-}
-extern "C" int czk_msm_gate(czk_ctx* ctx) {
-    if (!ctx) return CZK_ERR_ARG;
-    if (ctx->last_acc_start) CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->last_acc_start, 0));
-    return CZK_OK;
 }
 extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form, int mem,
                        uint64_t* out_jac) {

@@ -203,7 +203,6 @@ class Groth16Local:
             self.ab_sh = torch.zeros((L // 2, D, 4), dtype=torch.int64, device=dev)
         self.results = {}
         self.all_results = []
-        self.gate_witness_map = True
 
     def ntt_lanes_per_step(self):
         return 7 * self.lanes
@@ -266,9 +265,6 @@ class Groth16Local:
         # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
         # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
         ctx.msm_async(self.b_g2_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g2"], stable=True)
-        if self.gate_witness_map:
-            ctx.msm_gate()      # the witness map below runs under THIS proof's G2 accumulate kernel (which has issue slots to spare), not under the
-            #                     previous proof's power-limited G1 kernels
         ctx.msm_async(self.l_query, self.wit.data_ptr(), N, L, MONT, r["l"], stable=True)
         ctx.msm_async(self.a_query, self.asg.data_ptr(), N + 1, L, MONT, r["a"], stable=True)
         ctx.msm_async(self.b_g1_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g1"], stable=True)

@@ -288,13 +288,6 @@ int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_
 int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
                   int scalar_form, int mem, uint64_t* out_jac);
 
-/* Scheduling hint: work enqueued on the context AFTER this call starts no earlier than the bucket-accumulation kernel of the most recently
- * enqueued czk_msm_async (a stream-side event wait; the host does not block; no-op before the first MSM).  The accumulate kernels are the
- * critical stream of a prover and differ in how well they tolerate company: the G2 kernel runs one wave per SIMD and leaves issue slots
- * free, the G1 kernel is power-limited.  A pipelined Groth16 prover gates the NEXT proof's witness map on its own b_g2 MSM so that the NTTs run
- * under the G2 kernel instead of stretching the previous proof's G1 kernels (provers.py). */
-int czk_msm_gate(czk_ctx* ctx);
-
 /* One-shot forms with the reference's argument order (bases not kept on the GPU).  These are VariableBaseMSM::multi_scalar_mul's
  * signature, which is complete on every curve point, so they make NO subgroup assumption: the bases are registered with
  * CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS for the call (G1: XYZZ bucket arithmetic with the reference's case analysis). */

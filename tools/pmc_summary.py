@@ -44,5 +44,14 @@ for tag, key, prefix in (("g1", "k_accumulate_u", g1_prefix), ("g2", "k_accumula
                                 "SQ_WAVES": wv and wv["avg_per_dispatch"]}
     if g:
         summary[f"{key}_effective_clock_ghz"] = g["avg_per_dispatch"] / XCDS / g["avg_duration_ns"]
+import hashlib
+import os
+_d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "collaborative-zksnark_amd", "csrc")
+_h = hashlib.sha256()
+for _fn in sorted(os.listdir(_d)):
+    if _fn.endswith((".hip", ".h", ".inc")):
+        _h.update(_fn.encode())
+        _h.update(open(os.path.join(_d, _fn), "rb").read())
+summary["csrc_sha256"] = _h.hexdigest()[:16]      # bench.py csrc_digest(): were the counters taken at the kernels a bench line ran?
 json.dump(summary, open(out_path, "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k != "counters"}, indent=1))
