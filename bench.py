@@ -663,9 +663,11 @@ def main():
     ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
                     help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "
                          "--parties 3 --log-n 18); marlin: AHP rounds + commitments + batched openings, SPDZ lanes (configs[3]: --log-n 20)")
-    ap.add_argument("--layout", choices=("replica", "party"), default="replica",
+    ap.add_argument("--layout", choices=("replica", "party", "split"), default="replica",
                     help="replica (default, BASELINE configs[1]): every GPU proves independently with all parties' lanes on it; "
-                         "party: ONE proof, party p's lanes on rank p (--gpus == --parties), opens all-gathered over RCCL")
+                         "party: ONE proof, party p's lanes on rank p (--gpus == --parties), opens all-gathered over RCCL; "
+                         "split: ONE proof, all lanes on every rank, every MSM split by base range over the ranks (latency when GPUs outnumber "
+                         "parties: 1 / N of the accumulation and of the window tables per GPU, partial results added on rank 0)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only for rigs with fewer GPUs than ranks)")
     ap.add_argument("--device", type=int, default=None, help="GPU index for this rank (default LOCAL_RANK)")
     ap.add_argument("--no-tables", action="store_true", help="groth16: register the proving key with CZK_MEM_NO_TABLES (points only, one bucket set per window): "
@@ -717,6 +719,7 @@ def main():
     ranks_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
     assert ranks_seen == world == args.gpus, (ranks_seen, world, args.gpus)
     party_layout = args.layout == "party"
+    split_layout = args.layout == "split" and world > 1
     n_constraints = args.constraints if args.constraints is not None else 1 << args.log_n
     size_txt = f"2^{args.log_n}" if args.constraints is None else str(args.constraints)
     # torch's default stream has handle 0, which the C ABI reads as "make a private stream": use an explicit torch
@@ -734,7 +737,8 @@ def main():
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables, scheme=args.scheme)
         prover.commit_opens = args.commit_opens
     else:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme)
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme,
+                              base_split=(rank, world) if split_layout else None)
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)
@@ -758,17 +762,24 @@ def main():
     for _ in range(args.steps):
         prover.step(sync=False)     # consecutive proofs pipeline on the context's streams
     ctx.sync()                      # delivers every proof's MSM results to its own host buffers
+    if split_layout:                # the K partial sums of every MSM -> rank 0, added there (inside the timed region: it is part of a proof)
+        combined = parallel.combine_split_results(ctx, czk, prover.all_results)
     barrier()
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     assert len(prover.all_results) == args.steps and all(r["h"].any() and r["b_g2"].any() for r in prover.all_results)
     dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
-    proofs = args.steps if party_layout else world * args.steps      # party layout: all ranks work on the same proof
+    proofs = args.steps if (party_layout or split_layout) else world * args.steps      # party / split layout: all ranks work on the same proof
+    if split_layout:
+        if rank == 0:
+            prover.all_results[:] = combined     # from here on rank 0 holds the proofs' group elements; the other ranks only partial sums
+        else:
+            args.no_result_check = True
 
     # every pipelined proof works on the same inputs, so all of them must yield the same group elements (compared in
     # affine: summation order inside buckets is not deterministic, Jacobian triples differ) -- guards the pipelining
     ref_aff = None
-    for r in prover.all_results:
+    for r in (prover.all_results if (rank == 0 or not split_layout) else []):
         aff = {k: ctx.jac_to_affine(czk.CZK_G2 if k == "b_g2" else czk.CZK_G1, v) for k, v in r.items()}
         if ref_aff is None:
             ref_aff = aff
@@ -785,7 +796,7 @@ def main():
     # digest of the proof's group elements (affine, key order, party order, sh then mac): equal across layouts
     import hashlib
     mine = b"".join(ref_aff[k][0][ln].tobytes() + bytes([int(ref_aff[k][1][ln])]) for k in ("h", "l", "a", "b_g1", "b_g2")
-                    for ln in range(prover.lanes)) if not party_layout else None
+                    for ln in range(prover.lanes)) if (not party_layout and ref_aff is not None) else (None if party_layout else b"")
     if party_layout:
         per_key = {k: b"".join(ref_aff[k][0][ln].tobytes() + bytes([int(ref_aff[k][1][ln])]) for ln in range(prover.lanes))
                    for k in ("h", "l", "a", "b_g1", "b_g2")}
@@ -865,7 +876,7 @@ def main():
         "register_key_s": prover.register_s,
         "reserve_s": prover.reserve_s,     # czk_ctx_reserve at key load: NTT tables + MSM workspaces that the first proof would otherwise build
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if (party_layout or split_layout) else "weak",
         # Groth16 SPDZ 2 parties 2^20 on 2x GCP n2-standard-2 (1 core each): 328.957 / 317.213 /
         # 320.422 s per proof (mpc-snarks/analysis/data/weak_1_20.csv:21-23) -> 1 / mean = 0.003104 proofs/s
         "vs_baseline": (proofs / dt) / REF_PROOFS_PER_S if n_constraints == 1 << 20 and args.parties == 2 and args.scheme == "spdz" else None,
@@ -876,7 +887,10 @@ def main():
                                + ("both parties' share-local NTT+MSM on one GPU" if not party_layout else "one party per GPU") +
                                ": " + prover.describe(),
                    "constraints": n_constraints, "domain": prover.D, "parties": args.parties, "share_lanes": prover.lanes,
-                   "parallelism": (f"{world} independent proofs (one per GPU), no data-path collective; consecutive proofs on a GPU are "
+                   "parallelism": (f"ONE proof over {world} GPUs, all share lanes on every rank: the witness map runs in full on each (9 % of a proof, no "
+                                   "exchange), every MSM is split by base range (1 / N of the window tables and of the accumulation per GPU), the partial "
+                                   "sums are gathered and added on rank 0 (SURVEY.md section 8e: intra-party split for latency)") if split_layout else
+                                  (f"{world} independent proofs (one per GPU), no data-path collective; consecutive proofs on a GPU are "
                                    "pipelined (ms_per_step = throughput; latency_ms_single_proof = one proof alone)") if not party_layout else
                                   (f"ONE proof over {world} GPUs, party p's two share lanes on rank p; each of the two opens of the witness map is the "
                                    f"reference's two broadcast rounds (sh lanes, then dx_t = mac_share * value - mac) as all-gathers over {args.backend}, "
@@ -933,7 +947,7 @@ def main():
                                              "what a prove-once caller should use"}
         if r1 is not None and not args.no_result_check:
             out["one_shot_no_tables"]["results_checked"] = bool(check_results(czk, ctx1, p1, r1)["results_checked"])
-    if (rank == 0 and world == 1 and not args.no_other_workloads and not party_layout and not args.no_tables and n_constraints == 1 << 20 and args.parties == 2
+    if (rank == 0 and world == 1 and not args.no_other_workloads and not party_layout and not split_layout and not args.no_tables and n_constraints == 1 << 20 and args.parties == 2
             and args.scheme == "spdz" and not os.environ.get("CZK_BENCH_CHILD")):
         try:
             del p1

@@ -308,3 +308,38 @@ def additive_batch_open(ctx, val: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(val)
     ctx.fr_lanes_sum(gathered.contiguous().data_ptr(), world, n, out_ptr=out.data_ptr())
     return _after_consume(ctx, out)
+
+
+def combine_split_results(ctx, czk, per_proof: list, keys=("h", "l", "a", "b_g1", "b_g2"), device=None):
+    """Intra-party split (provers.Groth16Local base_split): every rank holds, per proof and query, the MSM over ITS base range as Jacobian
+    limbs (lanes, 18 | 36).  One gather of all of them to rank 0, which adds the K partial sums of every (proof, query, lane) with the
+    reference's GroupProjective::add_assign (czk_jac_add, host side: K - 1 additions per element -- "one extra point-add" per range).
+    Returns the combined list on rank 0, None elsewhere."""
+    import numpy as np
+    world, rank = _world_rank()
+    flat = np.concatenate([np.ascontiguousarray(r[k], dtype=np.uint64).reshape(-1) for r in per_proof for k in keys]) if per_proof else np.zeros(0, np.uint64)
+    if world == 1:
+        return per_proof
+    t = torch.from_numpy(flat.view(np.int64).copy())
+    if dist.get_backend() != "gloo":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    got = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, got, dst=0)
+    if rank != 0:
+        return None
+    parts = [g.cpu().numpy().view(np.uint64) for g in got]
+    out, at = [], 0
+    for r in per_proof:
+        comb = {}
+        for k in keys:
+            lanes, jw = r[k].shape
+            group = czk.CZK_G2 if jw == 36 else czk.CZK_G1
+            acc = parts[0][at:at + lanes * jw].reshape(lanes, jw).copy()
+            for p in parts[1:]:
+                add = p[at:at + lanes * jw].reshape(lanes, jw)
+                for ln in range(lanes):
+                    acc[ln] = ctx.jac_add(group, acc[ln], add[ln])
+            comb[k] = acc
+            at += lanes * jw
+        out.append(comb)
+    return out

@@ -65,12 +65,17 @@ class Groth16Local:
     circuit (squaring chain, mpc-snarks/src/proof.rs:304-344), SPDZ shares of `parties` parties."""
 
     def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None, no_tables: bool = False,
-                 mac_msm_from_sh: bool = False, scheme: str = "spdz"):
+                 mac_msm_from_sh: bool = False, scheme: str = "spdz", base_split=None):
         """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
         configs[1]); with one party per rank the two opens of the witness map run the reference's two broadcast rounds
         over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused.  no_tables:
         register the proving key with CZK_MEM_NO_TABLES (what a prover that runs once should do)."""
         self.czk, self.ctx = czk, ctx
+        # base_split = (k, K): the intra-party split for latency when GPUs outnumber parties (SURVEY.md section 8e: "MSM by base range -> one extra
+        # point-add").  This rank registers and sums only bases [n k / K, n (k + 1) / K) of every query -- 1 / K of the window tables and of the
+        # accumulation -- and runs the (cheap: 9 % of a proof) witness map in full, so no exchange is needed inside a proof; the K partial results of
+        # each MSM are gathered and added on rank 0 (parallel.combine_split_results).  A range's results are partial sums, not proof elements.
+        self.base_split = None if base_split is None else (int(base_split[0]), int(base_split[1]))
         # scheme "spdz": two lanes per party (sh, mac; share/spdz.rs:50-53), opens carry the MAC check.  scheme "hbc": the reference's
         # honest-but-curious additive sharing (mpc-snarks/src/proof.rs:379-387 `--alg hbc`; AdditiveFieldShare, share/add.rs:26-29):
         # ONE lane per party, an open is the sum of the parties' lanes (add.rs:256-259), no MAC lane and no check.
@@ -99,12 +104,14 @@ class Groth16Local:
 
         # ---- synthetic proving key: P_i = [k_i] G ----------------------------------------------------------
         def mk_bases(group, n, sd, inf_first=False):
-            k = torch.from_numpy(rand_fr_canonical(BASE_SEED + sd, n).view(np.int64)).to(dev)
+            lo, hi = self.base_range(n)
+            k = torch.from_numpy(rand_fr_canonical(BASE_SEED + sd, n)[lo:hi].copy().view(np.int64)).to(dev)   # the same bases in every layout
+            n = hi - lo
             aw = 12 if group == czk.CZK_G1 else 24
             pts = torch.empty((n, aw), dtype=torch.int64, device=dev)
             ctx.fixed_base_points(group, k.data_ptr(), out=pts.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
             inf = torch.zeros(n, dtype=torch.uint8, device=dev)
-            if inf_first:
+            if inf_first and lo == 0:
                 inf[0] = 1   # b_query[1] (the public output has no B entry) is infinity in the real key
             ctx.sync()
             t_reg = time.time()
@@ -201,8 +208,21 @@ class Groth16Local:
         if self.mac_msm_from_sh:
             self.wit_sh, self.asg_sh = self.wit[0::2].contiguous(), self.asg[0::2].contiguous()
             self.ab_sh = torch.zeros((L // 2, D, 4), dtype=torch.int64, device=dev)
+        self.wit_q, self.asg_q = self._sl(self.wit, N), self._sl(self.asg, N + 1)     # this rank's share of the witness-only MSMs' scalars
         self.results = {}
         self.all_results = []
+
+    def base_range(self, n: int):
+        """[lo, hi) of a query of n bases this rank sums (everything without base_split)"""
+        if self.base_split is None:
+            return 0, n
+        k, K = self.base_split
+        return n * k // K, n * (k + 1) // K
+
+    def _sl(self, t, n):
+        """the scalars of this rank's base range, contiguous per lane (the MSM entry points take lanes x n_scalars without a stride)"""
+        lo, hi = self.base_range(n)
+        return t if (lo, hi) == (0, n) and t.shape[1] == n else t[:, lo:hi].contiguous()
 
     def ntt_lanes_per_step(self):
         return 7 * self.lanes
@@ -264,10 +284,11 @@ class Groth16Local:
             return self._step_mac_from_sh(r, sync)
         # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
         # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
-        ctx.msm_async(self.b_g2_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g2"], stable=True)
-        ctx.msm_async(self.l_query, self.wit.data_ptr(), N, L, MONT, r["l"], stable=True)
-        ctx.msm_async(self.a_query, self.asg.data_ptr(), N + 1, L, MONT, r["a"], stable=True)
-        ctx.msm_async(self.b_g1_query, self.asg.data_ptr(), N + 1, L, MONT, r["b_g1"], stable=True)
+        na, nw = self.asg_q.shape[1], self.wit_q.shape[1]          # N + 1 and N, or this rank's base range of them (base_split)
+        ctx.msm_async(self.b_g2_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g2"], stable=True)
+        ctx.msm_async(self.l_query, self.wit_q.data_ptr(), nw, L, MONT, r["l"], stable=True)
+        ctx.msm_async(self.a_query, self.asg_q.data_ptr(), na, L, MONT, r["a"], stable=True)
+        ctx.msm_async(self.b_g1_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g1"], stable=True)
         # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
         # constraint evaluation <A_i, z>, <B_i, z>, <C_i, z> over the share lanes of the full assignment (r1cs_to_qap.rs:
         # 67-83, 95-100); A carries the two instance-copy rows (:79-83).  Rows beyond each matrix are zero padding that the
@@ -287,7 +308,11 @@ class Groth16Local:
         ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L, c_len=N)     # h = ab
         # --- the h MSM (prover.rs:104) needs the witness map's output; NOT flagged stable: the next proof's witness
         # map overwrites `ab`, so the context's stream waits for this MSM's digit extraction (library-side ordering)
-        ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"])
+        if self.base_split is None:
+            ctx.msm_async(self.h_query, self.ab.data_ptr(), D, L, MONT, r["h"])
+        else:
+            self.h_q = self._sl(self.ab[:, :D - 1], D - 1)         # kept referenced until the MSM has read it
+            ctx.msm_async(self.h_query, self.h_q.data_ptr(), self.h_q.shape[1], L, MONT, r["h"])
         if sync:
             ctx.sync()
 
@@ -342,11 +367,12 @@ class Groth16Local:
         return (time.perf_counter() - t0) / reps
 
     def g1_accumulate_algorithmic_bytes(self):
-        """an MSM of n points moves n*(96 B base) once + n*32 B of scalars per lane."""
+        """an MSM of n points moves n*(96 B base) once + n*32 B of scalars per lane (n = this rank's base range)."""
         tot = 0
         for n in (self.D - 1, self.N, self.N + 1, self.N + 1):
-            tot += n * 96 + self.lanes * n * 32
+            lo, hi = self.base_range(n)
+            tot += (hi - lo) * 96 + self.lanes * (hi - lo) * 32
         return tot, 4   # bytes per step, launches per step
 
     def g1_mixed_additions_per_step(self, windows: int):
-        return windows * self.lanes * ((self.D - 1) + self.N + 2 * (self.N + 1))
+        return windows * self.lanes * sum(hi - lo for lo, hi in (self.base_range(n) for n in (self.D - 1, self.N, self.N + 1, self.N + 1)))

@@ -1258,3 +1258,29 @@ def test_groth16_local_hbc_scheme_matches_reference(ctx, czk, orc, n_constraints
         for ln in range(L):
             assert _same_point(ctx, orc, g, p.results[name][ln], orc.multi_scalar_mul(g, bases, inf, scal[ln].reshape(-1, 4))), (name, ln)
     c2.close()
+
+
+@pytest.mark.parametrize("ranks,size", [(2, ["--constraints", "1000"]), (3, ["--log-n", "12"])])
+def test_groth16_intra_party_split_matches_the_one_gpu_layout(ranks, size):
+    """SURVEY.md section 8e, "optional intra-party split (MSM by base range -> one extra point-add)": bench.py --layout split runs ONE proof over N
+    ranks -- the witness map in full on every rank, every MSM over that rank's range of the bases (1 / N of the window tables), the N partial
+    sums of each MSM gathered and added on rank 0 (parallel.combine_split_results, czk_jac_add).  The 20 group elements must equal the
+    one-GPU layout's (digest over their affine forms) and verify against the known discrete logs.  The ranks share this box's GPU: gloo."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = size + ["--parties", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-seam-report", "--no-other-workloads"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    many = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--layout", "split", "--backend", "gloo",
+                           "--device", "0"] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert many.returncode == 0, many.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    d2 = json.loads(many.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == ranks and d2["ranks_seen_by_backend"] == ranks and d2["config"]["layout"] == "split" and d2["scaling"] == "strong"
+    assert d1["results_checked"] and d2["results_checked"]
+    assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
