@@ -237,7 +237,8 @@ class Radix2EvaluationDomain {
 template <int GROUP>
 class Bases {
   public:
-    // mem_flags: 0, or CZK_MEM_NO_TABLES for a key that is used once (see czk.h)
+    // mem_flags: 0, CZK_MEM_NO_TABLES for a key that is used once, CZK_MEM_ANY_POINTS for points of unknown origin (complete XYZZ formulas),
+    // CZK_MEM_CHECK_SUBGROUP to verify [r] P = 0 at registration and fall back to them when a base fails (see czk.h)
     Bases(const Context& ctx, const uint64_t* xy, const uint8_t* inf, size_t n, int mem_flags = 0) : ctx_(&ctx) {
         ctx.check(czk_bases_register(ctx.raw(), GROUP, xy, inf, n, CZK_MEM_HOST | mem_flags, &b_));
     }
@@ -245,6 +246,12 @@ class Bases {
     Bases(const Bases&) = delete;
     Bases& operator=(const Bases&) = delete;
     size_t len() const { return czk_bases_len(b_); }
+    // GroupAffine::is_in_correct_subgroup_assuming_on_curve over the whole query (short_weierstrass_jacobian.rs:131): number of bases that fail
+    size_t bases_outside_subgroup() const {
+        size_t bad = 0;
+        ctx_->check(czk_bases_check_subgroup(ctx_->raw(), b_, &bad));
+        return bad;
+    }
     czk_bases* raw() const { return b_; }
     const Context& ctx() const { return *ctx_; }
 
