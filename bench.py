@@ -468,6 +468,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         else:
             mac_share = polyvm.mont(1 if rank == 0 else 0)
             B.opener = lambda bk, v: parallel.spdz_batch_open(ctx, v[:, 0].contiguous(), v[:, 1].contiguous(), mac_share, commit=args.commit_opens)
+    B.prepare(polyvm.plonk_commit_sizes(n) if plonk else polyvm.marlin_commit_sizes(n))   # secondary table sets built at SRS load (czk_bases_prepare)
     inp = make_inputs(B)                                            # circuit / index and share lanes: resident in HBM before the timed region
     ctx.sync()
     setup_s = time.time() - t0

@@ -283,6 +283,12 @@ class GpuBackend(Backend):
 
     M = 1   # CZK_MEM_DEVICE
 
+    def prepare(self, sizes):
+        """czk_bases_prepare for the commitment lengths a prover will use: the narrower secondary table sets short polynomials run on are built at SRS
+        load instead of inside the first proof's czk_msm_async (which would drain the MSM pipeline mid-proof to build them)."""
+        for n in sorted(set(int(x) for x in sizes if 0 < int(x) <= self.n_bases)):
+            self.bases.prepare(n)
+
     def upload(self, a):
         a = np.ascontiguousarray(a, dtype=np.uint64)
         if a.ndim == 2:
@@ -606,6 +612,13 @@ def _padded_add(B, a, b):
     return B.plus(B.resized(a, n), B.resized(b, n))
 
 
+def plonk_commit_sizes(n_gates: int):
+    """lengths of the polynomials plonk_prove commits (for GpuBackend.prepare): p / l1 / t / q_up / l2_q (3 G), the public quotient and the opening
+    witnesses (one shorter), gates_q (6 G - 2), the selector's witness (G - 1)"""
+    G, W = n_gates, 3 * n_gates
+    return [W, W - 1, 6 * G - 2, 6 * G - 3, G - 1]
+
+
 def plonk_max_degree(n_gates: int) -> int:
     """Longest committed polynomial: gates_q has (G + 2 W - 2) - G = 6 G - 2 coefficients."""
     return 6 * n_gates
@@ -825,6 +838,12 @@ def _mul_by_vanishing(B, a, n):
     """a * (X^n - 1) (dense.rs mul_by_vanishing_poly): a shifted up by n, minus a"""
     m = B.length(a)
     return B.sub(B.concat([B.zeros(B.lanes_of(a), n), a]), B.resized(a, m + n))
+
+
+def marlin_commit_sizes(n_constraints: int):
+    """lengths of the polynomials marlin_prove commits (for GpuBackend.prepare)"""
+    H = K = next_pow2(n_constraints)
+    return [H - 1, H + 1, 3 * H, H, H - 1, 2 * H, K - 1, 3 * K - 4, 3 * H - 1, H - 2, 3 * K - 5, K - 2, K]
 
 
 def marlin_max_degree(n_constraints: int) -> int:
