@@ -381,47 +381,75 @@ __global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t 
         part_lb[dst] = (uint16_t)(b >> part_shift);
     }
 }
-// one workgroup per (partition, lane): bucket counts, offsets and the final placement of the partition's entries
-__global__ __launch_bounds__(256) void k_part_sort(const u32* part_idx, const uint16_t* part_lb, const u32* part_base, unsigned n_parts, unsigned part_shift,
-                                                   size_t total, size_t B, u32* sorted, u32* offsets, u32* counts) {
-    __shared__ u32 cnt[PART_BUCKETS], cur[PART_BUCKETS], red[256];
+// one workgroup per (partition, lane): bucket counts, offsets and the final placement of the partition's entries.  The placement is staged
+// in LDS when the partition fits (`cap` entries of dynamic LDS behind the counters): 4-byte stores to random positions of the partition's
+// output cost a sector write each, the staged copy leaves as coalesced 4 KiB rows.  Larger partitions (the 2^21-point `h` query: 53 k
+// entries) place directly, as rounds 1 - 3 did for every partition.
+constexpr unsigned PSORT_THREADS = 1024;
+__global__ __launch_bounds__(PSORT_THREADS) void k_part_sort(const u32* part_idx, const uint16_t* part_lb, const u32* part_base, unsigned n_parts, unsigned part_shift,
+                                                             size_t total, size_t B, u32* sorted, u32* offsets, u32* counts, u32 cap) {
+    extern __shared__ u32 psort_lds[];
+    u32 *cnt = psort_lds, *cur = psort_lds + PART_BUCKETS, *red = psort_lds + 2 * PART_BUCKETS, *stage = psort_lds + 2 * PART_BUCKETS + PSORT_THREADS;
     const unsigned p = blockIdx.x, lane = blockIdx.y, tid = threadIdx.x;
     const u32 r0 = part_base[(size_t)lane * (n_parts + 1) + p], r1 = part_base[(size_t)lane * (n_parts + 1) + p + 1];
-    for (unsigned t = tid; t < PART_BUCKETS; t += 256) cnt[t] = 0;
+    for (unsigned t = tid; t < PART_BUCKETS; t += PSORT_THREADS) cnt[t] = 0;
     __syncthreads();
     const uint16_t* lb = part_lb + (size_t)lane * total;
     const u32* idx = part_idx + (size_t)lane * total;
-    for (u32 j = r0 + tid; j < r1; j += 256) atomicAdd(&cnt[lb[j]], 1u);
-    __syncthreads();
-    // exclusive scan of cnt[0..1024): 4 consecutive entries per thread
-    u32 v[4], s = 0;
-#pragma unroll
-    for (unsigned k = 0; k < 4; k++) {
-        v[k] = cnt[tid * 4 + k];
-        s += v[k];
+    // four entries per thread and iteration, loads issued together
+    for (u32 j = r0 + tid; j < r1; j += 4 * PSORT_THREADS) {
+        const bool h1 = j + PSORT_THREADS < r1, h2 = j + 2 * PSORT_THREADS < r1, h3 = j + 3 * PSORT_THREADS < r1;
+        const uint16_t l0 = lb[j], l1 = h1 ? lb[j + PSORT_THREADS] : (uint16_t)0, l2 = h2 ? lb[j + 2 * PSORT_THREADS] : (uint16_t)0,
+                       l3 = h3 ? lb[j + 3 * PSORT_THREADS] : (uint16_t)0;
+        atomicAdd(&cnt[l0], 1u);
+        if (h1) atomicAdd(&cnt[l1], 1u);
+        if (h2) atomicAdd(&cnt[l2], 1u);
+        if (h3) atomicAdd(&cnt[l3], 1u);
     }
-    red[tid] = s;
     __syncthreads();
-    for (unsigned d = 1; d < 256; d <<= 1) {
+    // exclusive scan of cnt[0..1024): one entry per thread
+    const u32 v = tid < PART_BUCKETS ? cnt[tid] : 0u;
+    red[tid] = v;
+    __syncthreads();
+    for (unsigned d = 1; d < PSORT_THREADS; d <<= 1) {
         u32 x = tid >= d ? red[tid - d] : 0;
         __syncthreads();
         red[tid] += x;
         __syncthreads();
     }
-    u32 run = r0 + (tid ? red[tid - 1] : 0);
-#pragma unroll
-    for (unsigned k = 0; k < 4; k++) {
-        size_t b = ((size_t)(tid * 4 + k) << part_shift) | p;   // bucket = (index inside the partition, partition)
-        cur[tid * 4 + k] = run;
+    if (tid < PART_BUCKETS) {
+        const u32 run = red[tid] - v;                      // exclusive prefix, relative to the partition
+        size_t b = ((size_t)tid << part_shift) | p;          // bucket = (index inside the partition, partition)
+        cur[tid] = run;
         if (b < B) {
-            offsets[(size_t)lane * B + b] = run;
-            counts[(size_t)lane * B + b] = v[k];
+            offsets[(size_t)lane * B + b] = r0 + run;
+            counts[(size_t)lane * B + b] = v;
         }
-        run += v[k];
     }
     __syncthreads();
     u32* out = sorted + (size_t)lane * total;
-    for (u32 j = r0 + tid; j < r1; j += 256) out[atomicAdd(&cur[lb[j]], 1u)] = idx[j];
+    const bool staged = r1 - r0 <= cap;
+    for (u32 j = r0 + tid; j < r1; j += 4 * PSORT_THREADS) {
+        const bool h1 = j + PSORT_THREADS < r1, h2 = j + 2 * PSORT_THREADS < r1, h3 = j + 3 * PSORT_THREADS < r1;
+        const uint16_t l0 = lb[j], l1 = h1 ? lb[j + PSORT_THREADS] : (uint16_t)0, l2 = h2 ? lb[j + 2 * PSORT_THREADS] : (uint16_t)0,
+                       l3 = h3 ? lb[j + 3 * PSORT_THREADS] : (uint16_t)0;
+        const u32 v0 = idx[j], v1 = h1 ? idx[j + PSORT_THREADS] : 0u, v2 = h2 ? idx[j + 2 * PSORT_THREADS] : 0u, v3 = h3 ? idx[j + 3 * PSORT_THREADS] : 0u;
+        if (staged) {
+            stage[atomicAdd(&cur[l0], 1u)] = v0;
+            if (h1) stage[atomicAdd(&cur[l1], 1u)] = v1;
+            if (h2) stage[atomicAdd(&cur[l2], 1u)] = v2;
+            if (h3) stage[atomicAdd(&cur[l3], 1u)] = v3;
+        } else {
+            out[r0 + atomicAdd(&cur[l0], 1u)] = v0;
+            if (h1) out[r0 + atomicAdd(&cur[l1], 1u)] = v1;
+            if (h2) out[r0 + atomicAdd(&cur[l2], 1u)] = v2;
+            if (h3) out[r0 + atomicAdd(&cur[l3], 1u)] = v3;
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (u32 k = tid; k < r1 - r0; k += PSORT_THREADS) out[r0 + k] = stage[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -990,8 +1018,14 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                 hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((total + 256 * PS_TILE - 1) / (256 * PS_TILE)), (unsigned)lanes), dim3(256), 0, ss, digits,
                                    size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
             }
-            hipLaunchKernelGGL(k_part_sort, dim3(n_parts, (unsigned)lanes), dim3(256), 0, ss, ranks, part_lb, part_base, n_parts, part_shift, total, B, sorted,
-                               offsets, counts);
+            {
+                // dynamic LDS: counters + scan scratch + as large a staging area as the device's per-workgroup limit allows (gfx950: 160 KiB -> 36 k entries)
+                const size_t fixed = (2 * PART_BUCKETS + PSORT_THREADS) * 4;
+                const size_t lds = ctx->lds_per_block > fixed + 4096 ? ctx->lds_per_block : fixed + 4096;
+                const u32 cap = (u32)((lds - fixed) / 4);
+                hipLaunchKernelGGL(k_part_sort, dim3(n_parts, (unsigned)lanes), dim3(PSORT_THREADS), lds, ss, ranks, part_lb, part_base, n_parts, part_shift, total, B,
+                                   sorted, offsets, counts, cap);
+            }
         }
         CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
         hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
