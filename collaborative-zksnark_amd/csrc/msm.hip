@@ -889,7 +889,15 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 
     // workspaces (grow-only; growing synchronises the pipeline first)
     size_t lvl0 = (B + L - 1) / L;
-    const unsigned n_parts = (unsigned)((B + PART_BUCKETS - 1) >> PART_LOG);   // B is a power of two
+    unsigned n_parts = (unsigned)((B + PART_BUCKETS - 1) >> PART_LOG);   // B is a power of two
+    // k_part_sort stages a partition's placement in LDS when it fits (~36 k entries on gfx950): long calls get more, smaller partitions (a partition is
+    // the set of buckets with equal LOW index bits, so any power of two up to MAX_PARTS works; the 2^21-point h query: 1024 partitions of 27 k entries)
+    bool grow_parts = !b->split;
+#ifdef CZK_LAB
+    grow_parts = grow_parts && ctx->msm_affine_rounds == 0;   // the batched-affine record builders assume 1024-bucket partitions
+#endif
+    if (grow_parts)
+        while (n_parts < MAX_PARTS && n_parts < B && ((size_t)W * size) / n_parts > 30000) n_parts <<= 1;
     unsigned part_shift = 0;
     while ((1u << part_shift) < n_parts) part_shift++;
     size_t need_sort = lanes * ((size_t)W * size * (4 * 3 + 2) + B * 4 * 4 + CNT_BINS * 4 + (size_t)n_parts * 12 + 64) + (1 << 16);
