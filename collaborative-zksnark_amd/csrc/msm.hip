@@ -354,31 +354,60 @@ __global__ __launch_bounds__(1024) void k_part_scan(const u32* part_counts, u32*
 constexpr unsigned PS_TILE = CZK_PS_TILE;   // entries per thread
 __global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* part_base, u32* part_cursor,
                                                       unsigned n_parts, unsigned part_shift, u32* part_idx, uint16_t* part_lb) {
-    __shared__ u32 h[MAX_PARTS], base[MAX_PARTS];
+    // The tile is ordered by partition in LDS first and leaves as runs: consecutive lanes then write consecutive addresses of a partition's region
+    // (a store instruction touches ~8 sectors instead of 64 partial ones).
+    __shared__ u32 h[MAX_PARTS], base[MAX_PARTS], lofs[MAX_PARTS], red[256];
+    __shared__ u32 st_idx[256 * PS_TILE];
+    __shared__ uint16_t st_lb[256 * PS_TILE], st_pt[256 * PS_TILE];
     for (unsigned t = threadIdx.x; t < n_parts; t += 256) h[t] = 0;
     __syncthreads();
-    const unsigned lane = blockIdx.y;
+    const unsigned lane = blockIdx.y, tid = threadIdx.x;
     const size_t total = (size_t)W * size, tile0 = (size_t)blockIdx.x * 256 * PS_TILE;
     u32 code[PS_TILE], rank[PS_TILE];
 #pragma unroll
     for (unsigned k = 0; k < PS_TILE; k++) {
-        size_t e = tile0 + (size_t)k * 256 + threadIdx.x;
+        size_t e = tile0 + (size_t)k * 256 + tid;
         code[k] = e < total ? digits[(size_t)lane * total + e] : 0u;
         if (code[k]) rank[k] = atomicAdd(&h[((code[k] & 0x7fffffffu) - 1) & (n_parts - 1)], 1u);
     }
     __syncthreads();
-    for (unsigned t = threadIdx.x; t < n_parts; t += 256)
-        if (h[t]) base[t] = part_base[(size_t)lane * (n_parts + 1) + t] + atomicAdd(&part_cursor[(size_t)lane * n_parts + t], h[t]);
+    // exclusive scan of h over the partitions (n_parts <= 2048: up to 8 per thread) -> lofs; global bases
+    const unsigned per = (n_parts + 255) / 256;
+    u32 sum = 0;
+    for (unsigned i = tid * per; i < tid * per + per && i < n_parts; i++) sum += h[i];
+    red[tid] = sum;
+    __syncthreads();
+    for (unsigned d = 1; d < 256; d <<= 1) {
+        u32 x = tid >= d ? red[tid - d] : 0;
+        __syncthreads();
+        red[tid] += x;
+        __syncthreads();
+    }
+    u32 run = tid ? red[tid - 1] : 0;
+    for (unsigned i = tid * per; i < tid * per + per && i < n_parts; i++) {
+        lofs[i] = run;
+        run += h[i];
+        if (h[i]) base[i] = part_base[(size_t)lane * (n_parts + 1) + i] + atomicAdd(&part_cursor[(size_t)lane * n_parts + i], h[i]);
+    }
+    const u32 n_tile = red[255];
     __syncthreads();
 #pragma unroll
     for (unsigned k = 0; k < PS_TILE; k++) {
         if (!code[k]) continue;
-        size_t e = tile0 + (size_t)k * 256 + threadIdx.x;
+        size_t e = tile0 + (size_t)k * 256 + tid;
         size_t w = e / size, i = e - w * size;
         u32 b = (code[k] & 0x7fffffffu) - 1;
-        size_t dst = (size_t)lane * total + base[b & (n_parts - 1)] + rank[k];
-        part_idx[dst] = (u32)(w * n_bases + i) | (code[k] & 0x80000000u);
-        part_lb[dst] = (uint16_t)(b >> part_shift);
+        const u32 pt = b & (n_parts - 1), slot = lofs[pt] + rank[k];
+        st_idx[slot] = (u32)(w * n_bases + i) | (code[k] & 0x80000000u);
+        st_lb[slot] = (uint16_t)(b >> part_shift);
+        st_pt[slot] = (uint16_t)pt;
+    }
+    __syncthreads();
+    for (u32 sl = tid; sl < n_tile; sl += 256) {
+        const u32 pt = st_pt[sl];
+        const size_t dst = (size_t)lane * total + base[pt] + (sl - lofs[pt]);
+        part_idx[dst] = st_idx[sl];
+        part_lb[dst] = st_lb[sl];
     }
 }
 // one workgroup per (partition, lane): bucket counts, offsets and the final placement of the partition's entries.  The placement is staged
