@@ -11,6 +11,13 @@
 
 namespace czk {
 
+// blocks per lane of the fix-up kernels (see k_accumulate_u_fix)
+constexpr unsigned FIX_GRID = 128;
+static inline unsigned fix_grid(size_t B) {
+    size_t g = (B + 127) / 128;
+    return (unsigned)(g < FIX_GRID ? g : FIX_GRID);
+}
+
 // sorted[off .. off+cnt) lists this bucket's points as (w * n_bases + i) | sign<<31; pts holds the window
 // multiples 2^(c*w) * P_i in affine Montgomery form.  acc += (+/-) P in XYZZ coordinates (curve.h; same edge cases as
 // short_weierstrass_jacobian.rs:570-597).
@@ -389,16 +396,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // (Normally no bucket is dirty and every block returns at once; at ~250 VGPRs each block still has to wait for a drained SIMD
 // next to the accumulate kernels -- 2.3 ms on average per empty launch in the pipeline, profiles/r02_kernel_trace_stats.txt.
 // Limiting it to 128 VGPRs (-DCZK_FIX_NARROW) removes that wait and shortens one proof's latency by ~1 ms, but the blocks then
-// run BESIDE the accumulate waves and cost 0.8 % of throughput (A/B on one box: 89.8 vs 89.1 ms per proof): not adopted.)
+// run BESIDE the accumulate waves and cost 0.8 % of throughput (A/B on one box: 89.8 vs 89.1 ms per proof): not adopted.
+// What is adopted: a grid of at most FIX_GRID blocks per lane striding over the buckets, so an all-clean launch places a few
+// hundred wide waves instead of tens of thousands.)
 __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                          size_t sorted_stride, u64* buckets, const uint8_t* dirty, int ubuckets) {
-    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
     const unsigned lane = blockIdx.y;
-    if (!dirty[(size_t)lane * B + b]) return;
     const u32* srt = sorted + (size_t)lane * sorted_stride;
-    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     const Fq kf = fqu_k_from_u();
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (size_t)gridDim.x * blockDim.x) {
+    if (!dirty[(size_t)lane * B + b]) continue;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     Fq ax = Fq::one(), ay = Fq::one(), azz = Fq::zero(), azzz = Fq::zero();
     for (u32 e = 0; e < cnt; e++) {
         u32 code = srt[off + e];
@@ -408,6 +416,7 @@ __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u_fix(const u64
         xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy);
     }
     bucket_store_sat<Fq>(buckets + (size_t)24 * ((size_t)lane * B + b), XYZZ<Fq>{ax, ay, azz, azzz}, ubuckets);
+    }
 }
 
 // adds the deferred points into the finished buckets (sequentially: several may hit one bucket); buckets that were
@@ -770,11 +779,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, WA
 
 __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u2_fix(const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B,
                                                           size_t sorted_stride, u64* buckets, const uint8_t* dirty, int ubuckets) {
-    size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
     const unsigned lane = blockIdx.y;
-    if (!dirty[(size_t)lane * B + b]) return;
     const u32* srt = sorted + (size_t)lane * sorted_stride;
+    for (size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (size_t)gridDim.x * blockDim.x) {
+    if (!dirty[(size_t)lane * B + b]) continue;
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
     Fq2 ax = Fq2::one(), ay = Fq2::one(), azz = Fq2::zero(), azzz = Fq2::zero();
     for (u32 e = 0; e < cnt; e++) {
@@ -785,6 +793,7 @@ __global__ __launch_bounds__(128) CZK_FIX_ATTR void k_accumulate_u2_fix(const u6
         xyzz_acc_mixed(ax, ay, azz, azzz, qx, qy);
     }
     bucket_store_sat<Fq2>(buckets + (size_t)48 * ((size_t)lane * B + b), XYZZ<Fq2>{ax, ay, azz, azzz}, ubuckets);
+    }
 }
 
 __global__ void k_accumulate_u2_cleanup(const u64* pts, size_t B, u64* buckets, const uint8_t* dirty, const u32* exc_count, const u32* exc_list,

@@ -46,7 +46,7 @@ void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sor
                                   u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets) {
     size_t flags = ((size_t)lanes * B + 15) & ~(size_t)15;
     u32* exc = (u32*)(dirty + flags);
-    hipLaunchKernelGGL(k_accumulate_u2_fix, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
+    hipLaunchKernelGGL(k_accumulate_u2_fix, dim3(fix_grid(B), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, B,
                        sorted_stride, buckets, dirty, ubuckets);
     hipLaunchKernelGGL(k_accumulate_u2_cleanup, dim3(1), dim3(64), 0, st, pts, B, buckets, dirty, exc, exc + 4, G2_EXC_CAP, ubuckets);
 }
