@@ -24,20 +24,21 @@ def opaque_types(text: str):
 
 
 def rust_type(c: str) -> str:
+    """C declarator type -> Rust.  Each `*` takes the constness of what stands to its LEFT: `const T*` -> *const T, `T* const*` ->
+    *const *mut T, `const T* const*` -> *const *const T (a `const` right of the last star qualifies the parameter itself: dropped)."""
     c = c.strip()
-    stars = c.count("*")
-    base = c.replace("*", " ").split()
+    parts = [p.strip() for p in c.split("*")]
+    base = parts[0].split()
     const = "const" in base
-    base = [b for b in base if b != "const"]
-    t = TYPES[" ".join(base)]
-    if stars == 0:
+    t = TYPES[" ".join(b for b in base if b != "const")]
+    if len(parts) == 1:
         return t
     if t == "()":
         t = "c_void"
     out = t
-    for level in range(stars):
-        # only the innermost pointer carries the C `const`
-        out = ("*const " if (const and level == 0) else "*mut ") + out
+    for level in range(1, len(parts)):
+        out = ("*const " if const else "*mut ") + out
+        const = "const" in parts[level].split()
     return out
 
 
