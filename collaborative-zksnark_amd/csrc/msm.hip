@@ -979,6 +979,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         // growing drains the pipeline and calls hipMalloc (a device-wide synchronisation): grow EVERY slot of the ring to the new size at once,
         // so that a prover whose MSMs differ in size (KZG commitments of many lengths) stalls once per new maximum, not once per slot
         CZK_TRY(msm_pipeline_sync(ctx));
+        if (share && slot.ws_sort.bytes < need_sort) share->valid = false;   // the sort workspaces move: a lender's bucket lists go with them
         for (int i = 0; i < ctx->msm_slots_in_use; i++) {
             MsmSlot& sl = ctx->msm_slots[i];
             CZK_TRY(ensure_buf(ctx, sl.ws_sort, need_sort));

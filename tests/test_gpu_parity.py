@@ -280,6 +280,23 @@ def test_msm_multi_one_scalar_vector_against_several_keys(ctx, czk, orc, n, lane
         assert _same_point(ctx, orc, 1, one[ln], outs[2][ln])
     with pytest.raises(Exception):
         ctx.msm_multi_async([keys["a"]], sd.data_ptr(), n, lanes, 7, [outs[1]])
+    # a longer key in the middle of a call grows (and moves) the sort workspaces: the lender's lists must not be borrowed afterwards
+    c2 = czk.Context()
+    kb = rand_fr_canonical(0x57, 2 * n)
+    big = c2.register_bases(1, c2.fixed_base_points(1, kb), None)
+    s2 = rand_fr_canonical(0x58, 2 * n).reshape(1, 2 * n, 4)
+    sd2 = torch.from_numpy(s2.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    small = {nm: c2.register_bases(1, c2.fixed_base_points(1, ks[nm]), None) for nm in ("a", "b")}
+    o3 = [np.zeros((1, 18), dtype=np.uint64) for _ in range(3)]
+    c2.msm_multi_async([small["a"], big, small["b"]], sd2.data_ptr(), 2 * n, 1, czk.CZK_SCALAR_CANONICAL, o3)
+    c2.sync()
+    for out, k in zip(o3, (ks["a"], kb, ks["b"])):
+        e = dot_mod_r(k, s2[0, :len(k)])
+        assert _same_point(c2, orc, 1, out[0], orc.scalar_mul(1, gen[1], False, ints_to_limbs([e], 4)[0]))
+    for b in list(small.values()) + [big]:
+        b.release()
+    c2.close() if hasattr(c2, "close") else None
     for b in keys.values():
         b.release()
 
