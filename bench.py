@@ -664,7 +664,6 @@ def main():
     ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
                     help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "
                          "--parties 3 --log-n 18); marlin: AHP rounds + commitments + batched openings, SPDZ lanes (configs[3]: --log-n 20)")
-    ap.add_argument("--no-shared-sort", action="store_true", help="A/B: the three assignment MSMs as separate czk_msm_async calls (one digit sort each)")
     ap.add_argument("--layout", choices=("replica", "party", "split"), default="replica",
                     help="replica (default, BASELINE configs[1]): every GPU proves independently with all parties' lanes on it; "
                          "party: ONE proof, party p's lanes on rank p (--gpus == --parties), opens all-gathered over RCCL; "
@@ -736,12 +735,11 @@ def main():
         return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)
     parallel.set_exchange(args.exchange)
     if party_layout:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables, scheme=args.scheme,
-                              shared_sort=not args.no_shared_sort)
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables, scheme=args.scheme)
         prover.commit_opens = args.commit_opens
     else:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme,
-                              base_split=(rank, world) if split_layout else None, shared_sort=not args.no_shared_sort)
+                              base_split=(rank, world) if split_layout else None)
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)

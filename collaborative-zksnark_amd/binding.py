@@ -270,17 +270,6 @@ class Context:
                                      C.c_int(CZK_MEM_DEVICE | (16 if stable else 0)), _ptr(out)))
         return out
 
-    def msm_multi_async(self, bases_list, scalars_ptr, n_scalars: int, lanes: int, scalar_form: int, outs, stable: bool = False):
-        """czk_msm_multi_async: ONE device scalar vector against several registered arrays (Groth16's assignment against a_query, b_g1_query,
-        b_g2_query); outs[k] (numpy, lanes x 18|36) is valid after sync()."""
-        n = len(bases_list)
-        assert n == len(outs)
-        hb = (C.c_void_p * n)(*[b._h.value for b in bases_list])
-        ho = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
-        self._ck(self._L.czk_msm_multi_async(self._h, hb, C.c_size_t(n), _ptr(scalars_ptr), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
-                                           C.c_int(CZK_MEM_DEVICE | (16 if stable else 0)), ho))
-        return outs
-
     def msm_oneshot(self, group, bases, inf, scalars, lanes=1, scalar_form=CZK_SCALAR_CANONICAL):
         aw, jw = (12, 18) if group == CZK_G1 else (24, 36)
         bases = np.ascontiguousarray(bases, np.uint64)

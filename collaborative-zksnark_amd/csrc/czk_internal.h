@@ -66,17 +66,6 @@ struct MsmSlot {
     hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_fix = nullptr, ev_red = nullptr;
     bool used = false;
 };
-// czk_msm_multi_async: the digit sort of one MSM lent to the following ones of the same call (same scalars; table sets of the same
-// shape and without infinity flags give the same bucket lists).  `slot` owns the arrays until a later sort overwrites them.
-struct MsmShare {
-    bool valid = false;
-    MsmSlot* slot = nullptr;
-    const uint64_t* scalars = nullptr;
-    size_t size = 0, lanes = 0, nb = 0;
-    int form = 0;
-    unsigned c = 0, W = 0;
-    uint32_t *sorted = nullptr, *offsets = nullptr, *counts = nullptr, *perm = nullptr;
-};
 struct MsmPending {
     const char* src;
     void* dst;
@@ -145,7 +134,6 @@ struct czk_table_set {
     size_t cover = 0;          // points covered = stride between windows
     uint64_t* pts = nullptr;   // W x cover x (12|24) u64
     uint8_t* inf = nullptr;    // W x cover
-    size_t n_inf = 0;          // number of set flags (a set without any can lend its digit sort to another: czk_msm_multi_async)
 };
 
 struct czk_bases {
@@ -171,7 +159,6 @@ struct czk_bases {
                                // extra lanes of the same kernels) and the per-window results are combined afterwards
     uint64_t* pts = nullptr;   // device, W x n x (12|24) u64: window w holds 2^(c*w) * P_i, affine Montgomery
     uint8_t* inf = nullptr;    // device, W x n infinity flags (never null)
-    size_t n_inf = 0;          // number of set flags in the key's own tables
 };
 
 namespace czk {
@@ -271,7 +258,7 @@ int ntt_mixed_device(czk_ctx* ctx, u64* data, unsigned k, size_t lanes, int kind
 int msm_reserve(czk_ctx* ctx, const czk_bases* bases, size_t n_scalars, size_t lanes);   // czk_ctx_reserve (msm.hip)
 int ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes);                                   // czk_ctx_reserve (ntt.hip)
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
-               int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable, MsmShare* share = nullptr);
+               int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable);
 int msm_pipeline_init(czk_ctx* ctx);
 // sum_w 2^(c w) R[lane][w] on the host (Horner: c doublings per window); src: lanes x W Jacobian triples, out: lanes triples
 void host_combine_windows(int group, const char* src, unsigned W, unsigned c, size_t lanes, uint64_t* out);

@@ -685,16 +685,6 @@ static int subgroup_check_impl(czk_ctx* ctx, const u64* pts, const uint8_t* inf,
     return CZK_OK;
 }
 
-// number of set infinity flags of a table set (host count: once per set, a few MB)
-static int count_flags(czk_ctx* ctx, const uint8_t* inf_dev, size_t bytes, size_t* out) {
-    std::vector<uint8_t> h(bytes);
-    if (bytes) CZK_HIP(ctx, hipMemcpy(h.data(), inf_dev, bytes, hipMemcpyDeviceToHost));
-    size_t k = 0;
-    for (uint8_t f : h) k += f != 0;
-    *out = k;
-    return CZK_OK;
-}
-
 template <class F>
 static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const uint8_t* inf_dev) {
     constexpr int AW = GT<F>::AW, JW = GT<F>::JW, FW = GT<F>::FW;
@@ -795,7 +785,6 @@ struct TableView {
     const u64* pts;
     const uint8_t* inf;
     size_t stride;   // points per window
-    size_t n_inf;    // infinity flags set in the table set
 };
 constexpr double REDUCE_COST_PER_BUCKET = 6.0;   // in mixed additions (measured: profiles/r03_window_classes.txt)
 static double msm_cost(unsigned c, size_t size) { return (double)num_windows(c) * (double)size + REDUCE_COST_PER_BUCKET * (double)((size_t)1 << (c - 1)); }
@@ -848,12 +837,6 @@ static int build_secondary(czk_ctx* ctx, const czk_bases* b, unsigned c, size_t 
         if (t.inf) (void)hipFree(t.inf);
         return set_err(ctx, e == hipErrorOutOfMemory ? CZK_ERR_NOMEM : CZK_ERR_HIP, std::string("secondary window tables: ") + hipGetErrorString(e));
     }
-    int rcc = count_flags(ctx, t.inf, (size_t)W * cover, &t.n_inf);
-    if (rcc != CZK_OK) {
-        (void)hipFree(t.pts);
-        (void)hipFree(t.inf);
-        return rcc;
-    }
     *out = t;
     return CZK_OK;
 }
@@ -862,7 +845,7 @@ static int build_secondary(czk_ctx* ctx, const czk_bases* b, unsigned c, size_t 
 template <class F>
 static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView* tv, bool build) {
     czk_bases* b = const_cast<czk_bases*>(cb);   // the secondary sets are a cache behind the const handle
-    *tv = TableView{b->c, b->W, b->pts, b->inf, b->n, b->n_inf};
+    *tv = TableView{b->c, b->W, b->pts, b->inf, b->n};
     if (b->split || !b->per_call_width || size == 0) return CZK_OK;
     const unsigned cc = width_class(size);
     if (cc >= b->c || msm_cost(b->c, size) < 1.12 * msm_cost(cc, size)) return CZK_OK;
@@ -895,7 +878,7 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
             t = &b->extra[n];
         }
     }
-    if (t) *tv = TableView{t->c, t->W, t->pts, t->inf, t->cover, t->n_inf};
+    if (t) *tv = TableView{t->c, t->W, t->pts, t->inf, t->cover};
     return CZK_OK;
 }
 
@@ -908,7 +891,7 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
 // buffer by msm_collect() after the streams are synchronised.
 template <class F>
 static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host,
-                       bool scalars_stable, bool reserve_only = false, MsmShare* share = nullptr) {
+                       bool scalars_stable, bool reserve_only = false) {
     constexpr int JW = GT<F>::JW, XW = GT<F>::XW;   // results leave as Jacobian; buckets are XYZZ internally
     const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
     // Bases without window tables (b->split): the W digit windows of every scalar lane become W "virtual lanes", each a
@@ -979,7 +962,6 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         // growing drains the pipeline and calls hipMalloc (a device-wide synchronisation): grow EVERY slot of the ring to the new size at once,
         // so that a prover whose MSMs differ in size (KZG commitments of many lengths) stalls once per new maximum, not once per slot
         CZK_TRY(msm_pipeline_sync(ctx));
-        if (share && slot.ws_sort.bytes < need_sort) share->valid = false;   // the sort workspaces move: a lender's bucket lists go with them
         for (int i = 0; i < ctx->msm_slots_in_use; i++) {
             MsmSlot& sl = ctx->msm_slots[i];
             CZK_TRY(ensure_buf(ctx, sl.ws_sort, need_sort));
@@ -1031,21 +1013,6 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     u32* heavy_hdr = br.take<u32>(4);
     uint8_t* dirty = br.take<uint8_t>(lanes * B + 64 + 3 * 4096 * 4 + 64);   // unsaturated kernel: dirty flags + exception list
 
-    // czk_msm_multi_async: the same scalars against another table set of the same shape (and neither with infinity flags, which drop entries): the
-    // lender's bucket lists ARE this call's -- no digits, no sort
-    bool can_lend = !b->split && tv.n_inf == 0 && size > 0;
-#ifdef CZK_LAB
-    can_lend = can_lend && aff.rounds == 0;
-#endif
-    const bool borrow = share && share->valid && can_lend && share->scalars == scalars && share->size == size && share->lanes == lanes && share->form == form &&
-                        share->c == c && share->W == W && share->nb == nb;
-    if (borrow) {
-        sorted = share->sorted;
-        offsets = share->offsets;
-        counts = share->counts;
-        perm = share->perm;
-    }
-
     // pinned staging for the result
     const size_t out_bytes = lanes * JW * 8;
     if (ctx->msm_pinned_used + out_bytes > ctx->msm_pinned_bytes) {
@@ -1063,9 +1030,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     {
         ProfScope ps(ctx, "msm_sort", ss);
         const bool one_pass = one_pass_sort;
-        if (borrow) {
-            // (ss is in order: the lender's sort is ahead of this call's ev_sorted)
-        } else if (one_pass) {
+        if (one_pass) {
             CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
             if (size) {
                 hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
@@ -1099,16 +1064,10 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                                    sorted, offsets, counts, cap);
             }
         }
-        if (!borrow) {
-            CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
-            hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
-            hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
-            hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
-            if (share) {
-                if (can_lend) *share = MsmShare{true, &slot, scalars, size, lanes, nb, form, c, W, sorted, offsets, counts, perm};
-                else if (share->slot == &slot) share->valid = false;   // the lender's arrays have just been overwritten
-            }
-        }
+        CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
+        hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
+        hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
+        hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
 #ifdef CZK_LAB
         if (aff.rounds) {
             aff.sorted = sorted;
@@ -1170,7 +1129,6 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         else launch_accumulate_g2_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
-    if (borrow && share->slot != &slot) CZK_HIP(ctx, hipEventRecord(share->slot->ev_fix, sr));   // ... and the lender's not before
     {
         ProfScope ps(ctx, "msm_reduce", sr);
         const u64 *P = buckets, *E = nullptr;
@@ -1297,9 +1255,9 @@ int msm_reserve(czk_ctx* ctx, const czk_bases* bases, size_t n_scalars, size_t l
 }
 
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes, int scalar_form,
-               u64* out_jac_host, bool blocking, bool scalars_stable, MsmShare* share) {
-    int rc = bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable, false, share)
-                                    : msm_enqueue<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable, false, share);
+               u64* out_jac_host, bool blocking, bool scalars_stable) {
+    int rc = bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable)
+                                    : msm_enqueue<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable);
     if (rc != CZK_OK || !blocking) return rc;
     return msm_pipeline_sync(ctx);
 }
@@ -1377,7 +1335,6 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     }
     if (rc == CZK_OK) rc = group == CZK_G1 ? register_impl<Fq>(ctx, b, pts_dev, inf_dev) : register_impl<Fq2>(ctx, b, pts_dev, inf_dev);
     (void)hipStreamSynchronize(ctx->stream);
-    if (rc == CZK_OK && b->n) rc = count_flags(ctx, b->inf, (size_t)(b->split ? 1 : b->W) * b->n, &b->n_inf);
     if (tmp_p) (void)hipFree(tmp_p);
     if (tmp_i) (void)hipFree(tmp_i);
     if (rc != CZK_OK) {
@@ -1493,24 +1450,6 @@ extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* sca
 extern "C" int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form,
                              int mem, uint64_t* out_jac) {
     return msm_common(ctx, bases, scalars, n_scalars, lanes, scalar_form, mem, out_jac, false);
-}
-
-extern "C" int czk_msm_multi_async(czk_ctx* ctx, const czk_bases* const* bases, size_t n_bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
-                                   int scalar_form, int mem, uint64_t* const* out_jac) {
-    if (!ctx) return CZK_ERR_ARG;
-    if (!bases || !out_jac) return set_err(ctx, CZK_ERR_ARG, "null msm argument");
-    for (size_t k = 0; k < n_bases; k++)
-        if (!bases[k] || !out_jac[k]) return set_err(ctx, CZK_ERR_ARG, "null msm argument");
-    if (n_scalars && !scalars) return set_err(ctx, CZK_ERR_ARG, "null scalars");
-    if (scalar_form != CZK_SCALAR_CANONICAL && scalar_form != CZK_SCALAR_MONTGOMERY) return set_err(ctx, CZK_ERR_ARG, "bad scalar_form");
-    if ((mem & ~CZK_MEM_STABLE) != CZK_MEM_DEVICE) return set_err(ctx, CZK_ERR_ARG, "czk_msm_multi_async takes device scalars (CZK_MEM_DEVICE, optionally | CZK_MEM_STABLE)");
-    if (!lanes || !n_bases) return CZK_OK;
-    CZK_HIP(ctx, hipSetDevice(ctx->device));
-    const bool stable = (mem & CZK_MEM_STABLE) != 0;
-    MsmShare share;
-    for (size_t k = 0; k < n_bases; k++)
-        CZK_TRY(msm_device(ctx, bases[k], scalars, n_scalars, lanes, scalar_form, out_jac[k], false, stable, &share));
-    return CZK_OK;
 }
 
 static int msm_oneshot(czk_ctx* ctx, int group, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t lanes,

@@ -65,13 +65,12 @@ class Groth16Local:
     circuit (squaring chain, mpc-snarks/src/proof.rs:304-344), SPDZ shares of `parties` parties."""
 
     def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None, no_tables: bool = False,
-                 mac_msm_from_sh: bool = False, scheme: str = "spdz", base_split=None, shared_sort: bool = True):
+                 mac_msm_from_sh: bool = False, scheme: str = "spdz", base_split=None):
         """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
         configs[1]); with one party per rank the two opens of the witness map run the reference's two broadcast rounds
         over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused.  no_tables:
         register the proving key with CZK_MEM_NO_TABLES (what a prover that runs once should do)."""
         self.czk, self.ctx = czk, ctx
-        self.shared_sort = shared_sort      # False: the three assignment MSMs as separate czk_msm_async calls (A/B runs)
         # base_split = (k, K): the intra-party split for latency when GPUs outnumber parties (SURVEY.md section 8e: "MSM by base range -> one extra
         # point-add").  This rank registers and sums only bases [n k / K, n (k + 1) / K) of every query -- 1 / K of the window tables and of the
         # accumulation -- and runs the (cheap: 9 % of a proof) witness map in full, so no exchange is needed inside a proof; the K partial results of
@@ -286,13 +285,10 @@ class Groth16Local:
         # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
         # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
         na, nw = self.asg_q.shape[1], self.wit_q.shape[1]          # N + 1 and N, or this rank's base range of them (base_split)
-        # the three MSMs over the full assignment (prover.rs:132, :143, :155) share one digit sort
-        if self.shared_sort:
-            ctx.msm_multi_async([self.b_g2_query, self.a_query, self.b_g1_query], self.asg_q.data_ptr(), na, L, MONT, [r["b_g2"], r["a"], r["b_g1"]], stable=True)
-        else:
-            for q, k in ((self.b_g2_query, "b_g2"), (self.a_query, "a"), (self.b_g1_query, "b_g1")):
-                ctx.msm_async(q, self.asg_q.data_ptr(), na, L, MONT, r[k], stable=True)
+        ctx.msm_async(self.b_g2_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g2"], stable=True)
         ctx.msm_async(self.l_query, self.wit_q.data_ptr(), nw, L, MONT, r["l"], stable=True)
+        ctx.msm_async(self.a_query, self.asg_q.data_ptr(), na, L, MONT, r["a"], stable=True)
+        ctx.msm_async(self.b_g1_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g1"], stable=True)
         # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
         # constraint evaluation <A_i, z>, <B_i, z>, <C_i, z> over the share lanes of the full assignment (r1cs_to_qap.rs:
         # 67-83, 95-100); A carries the two instance-copy rows (:79-83).  Rows beyond each matrix are zero padding that the
@@ -325,8 +321,10 @@ class Groth16Local:
         czk, ctx = self.czk, self.ctx
         D, N, L, ld = self.D, self.N, self.lanes, self.log_d
         M, ADD, MONT, P = czk.CZK_MEM_DEVICE, 0, czk.CZK_SCALAR_MONTGOMERY, self.lanes // 2
-        ctx.msm_multi_async([self.b_g2_query, self.a_query, self.b_g1_query], self.asg_sh.data_ptr(), N + 1, P, MONT, [r["b_g2"], r["a"], r["b_g1"]], stable=True)
+        ctx.msm_async(self.b_g2_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["b_g2"], stable=True)
         ctx.msm_async(self.l_query, self.wit_sh.data_ptr(), N, P, MONT, r["l"], stable=True)
+        ctx.msm_async(self.a_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["a"], stable=True)
+        ctx.msm_async(self.b_g1_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["b_g1"], stable=True)
         ctx.r1cs_matvec(self.mat_a, self.full.data_ptr(), lanes=L, out=self.a.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
         ctx.r1cs_matvec(self.mat_b, self.full.data_ptr(), lanes=L, out=self.b.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
         ctx.r1cs_matvec(self.mat_c, self.full.data_ptr(), lanes=L, out=self.c.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)

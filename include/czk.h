@@ -288,15 +288,6 @@ int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_
 int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
                   int scalar_form, int mem, uint64_t* out_jac);
 
-/* ONE scalar vector against several base arrays: equivalent to n_bases czk_msm_async calls with the same scalar arguments, results in
- * out_jac[k] after the next czk_ctx_sync().  The Groth16 prover multiplies the full assignment by a_query, b_g1_query and b_g2_query
- * (mpc-snarks/src/groth/prover.rs:216-232 `calculate_coeff`, called at :132, :143, :155; groth16/src/data_structures.rs:132-149), three
- * multi_scalar_mul calls over the same scalars; their signed digits and bucket lists depend on the scalars and the table shape only, so
- * they are extracted and sorted once for consecutive arrays whose tables have the same shape (equal length and window layout) and hold no
- * point at infinity.  Arrays that do not qualify simply run their own sort.  Scalars: device memory (CZK_MEM_DEVICE [| CZK_MEM_STABLE]). */
-int czk_msm_multi_async(czk_ctx* ctx, const czk_bases* const* bases, size_t n_bases, const uint64_t* scalars, size_t n_scalars,
-                        size_t lanes, int scalar_form, int mem, uint64_t* const* out_jac);
-
 /* One-shot forms with the reference's argument order (bases not kept on the GPU).  These are VariableBaseMSM::multi_scalar_mul's
  * signature, which is complete on every curve point, so they make NO subgroup assumption: the bases are registered with
  * CZK_MEM_NO_TABLES | CZK_MEM_ANY_POINTS for the call (G1: XYZZ bucket arithmetic with the reference's case analysis). */

@@ -307,29 +307,6 @@ inline void multi_scalar_mul_async(const Bases<GROUP>& bases, const DeviceLanes&
                                     CZK_MEM_DEVICE | (stable ? CZK_MEM_STABLE : 0), reinterpret_cast<uint64_t*>(out)));
 }
 
-// The same resident scalars against a G1 and / or G2 array each (czk_msm_multi_async): create_proof multiplies the assignment by
-// a_query, b_g1_query and b_g2_query (prover.rs:132, :143, :155); the digit sort is done once for arrays of the same table shape.
-struct MsmTarget {
-    const czk_bases* bases;
-    uint64_t* out;
-};
-template <int GROUP, class Projective>
-inline MsmTarget msm_target(const Bases<GROUP>& bases, Projective* out) {
-    static_assert(sizeof(Projective) == (GROUP == CZK_G1 ? 18 : 36) * 8, "Projective does not match the group");
-    return MsmTarget{bases.raw(), reinterpret_cast<uint64_t*>(out)};
-}
-inline void multi_scalar_mul_multi_async(const Context& ctx, std::initializer_list<MsmTarget> targets, const DeviceLanes& scalars, size_t n_scalars,
-                                         bool stable = false) {
-    std::vector<const czk_bases*> b;
-    std::vector<uint64_t*> o;
-    for (const MsmTarget& t : targets) {
-        b.push_back(t.bases);
-        o.push_back(t.out);
-    }
-    ctx.check(czk_msm_multi_async(ctx.raw(), b.data(), b.size(), scalars.data(), n_scalars, scalars.lanes(), CZK_SCALAR_MONTGOMERY,
-                                  CZK_MEM_DEVICE | (stable ? CZK_MEM_STABLE : 0), o.data()));
-}
-
 // mpc-algebra/src/share/spdz.rs:440-446 -- SPDZ multi_scale_pub_group.  The reference builds BOTH scalar vectors from `s.sh.val`
 // (:441 and :442), so its second MSM repeats the first bit for bit: one MSM is run and its result returned for `sh` and `mac` --
 // identical to the reference's output at half its work.  (A caller with distinct MAC scalars uses multi_scale_pub_group_lanes.)

@@ -93,7 +93,6 @@ extern "C" {
     pub fn czk_bases_prepare(ctx: *mut czk_ctx, b: *const czk_bases, n_scalars: usize) -> c_int;
     pub fn czk_msm(ctx: *mut czk_ctx, bases: *const czk_bases, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *mut u64) -> c_int;
     pub fn czk_msm_async(ctx: *mut czk_ctx, bases: *const czk_bases, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *mut u64) -> c_int;
-    pub fn czk_msm_multi_async(ctx: *mut czk_ctx, bases: *const *const czk_bases, n_bases: usize, scalars: *const u64, n_scalars: usize, lanes: usize, scalar_form: c_int, mem: c_int, out_jac: *const *mut u64) -> c_int;
     pub fn czk_msm_g1(ctx: *mut czk_ctx, bases_xy: *const u64, inf: *const u8, scalars: *const u64, n: usize, lanes: usize, scalar_form: c_int, out_jac: *mut u64) -> c_int;
     pub fn czk_msm_g2(ctx: *mut czk_ctx, bases_xy: *const u64, inf: *const u8, scalars: *const u64, n: usize, lanes: usize, scalar_form: c_int, out_jac: *mut u64) -> c_int;
     pub fn czk_bases_check_subgroup(ctx: *mut czk_ctx, bases: *const czk_bases, out_bad: *mut usize) -> c_int;

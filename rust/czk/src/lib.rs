@@ -354,22 +354,6 @@ pub mod msm {
         }
     }
 
-    /// ONE resident scalar vector against several pinned arrays (czk_msm_multi_async): the assignment against a_query, b_g1_query and
-    /// b_g2_query (prover.rs:132, :143, :155).  Same ownership rules as [`Pinned::msm_resident`]; one guard per array, in order.
-    pub fn msm_resident_multi<'a>(bases: &[&'a Pinned], scalars: &super::resident::DeviceLanes, n_scalars: usize) -> Vec<PendingMsm<'a>> {
-        let mut bufs: Vec<Box<[u64]>> =
-            bases.iter().map(|b| vec![0u64; (if b.group == sys::CZK_G1 { 18 } else { 36 }) * scalars.lanes()].into_boxed_slice()).collect();
-        let handles: Vec<*const sys::czk_bases> = bases.iter().map(|b| b.handle as *const sys::czk_bases).collect();
-        let outs: Vec<*mut u64> = bufs.iter_mut().map(|b| b.as_mut_ptr()).collect();
-        let ctx = CTX.lock().unwrap();
-        let rc = unsafe {
-            sys::czk_msm_multi_async(ctx.as_ptr(), handles.as_ptr(), handles.len(), scalars.data(0, 0), n_scalars, scalars.lanes(),
-                                     sys::CZK_SCALAR_MONTGOMERY, sys::CZK_MEM_DEVICE, outs.as_ptr())
-        };
-        ctx.expect(rc, "czk_msm_multi_async");
-        bufs.into_iter().map(|b| PendingMsm { buf: Some(b), _bases: std::marker::PhantomData }).collect()
-    }
-
     /// Results of an enqueued MSM (see [`Pinned::msm_resident`]).
     pub struct PendingMsm<'a> {
         buf: Option<Box<[u64]>>,

@@ -231,76 +231,6 @@ def test_msm_empty_and_all_zero(ctx, czk, orc):
     b0.release()
 
 
-@pytest.mark.parametrize("n,lanes", [((1 << 16) + 1, 2), (700, 3), ((1 << 19) + 5, 4)])
-def test_msm_multi_one_scalar_vector_against_several_keys(ctx, czk, orc, n, lanes):
-    """czk_msm_multi_async (the assignment against a_query, b_g1_query, b_g2_query: prover.rs:132, :143, :155): results equal the
-    separate calls' -- for keys that share one digit sort (same length and layout, G1 and G2), for a key with a point at infinity and a
-    shorter key (each sorts for itself), and for more keys than the pipeline has workspace slots (the lender's arrays are re-used
-    after later sorts went through the ring)."""
-    import torch
-    gen = {g: ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0] for g in (1, 2)}
-    ks, keys = {}, {}
-
-    def make(name, g, m, seed, inf_at=None):
-        k = rand_fr_canonical(seed, m)
-        pts = ctx.fixed_base_points(g, k)
-        inf = None
-        if inf_at is not None:
-            inf = np.zeros(m, dtype=np.uint8)
-            inf[inf_at] = 1
-            k = k.copy()
-            k[inf_at] = 0
-        ks[name] = k
-        keys[name] = ctx.register_bases(g, pts, inf)
-
-    make("g2", 2, n, 0x51)
-    make("a", 1, n, 0x52)
-    make("b", 1, n, 0x53)
-    make("hole", 1, n, 0x54, inf_at=5)
-    make("short", 1, n - 3, 0x55)
-    s = rand_fr_canonical(0x56, lanes * n).reshape(lanes, n, 4)
-    s[0, 1] = 0
-    s[1 % lanes, 2] = ints_to_limbs([R_MOD - 1], 4)[0]
-    sm = orc.fr_from_repr(s.reshape(-1, 4)).reshape(lanes, n, 4)
-    sd = torch.from_numpy(np.ascontiguousarray(sm).view(np.int64)).cuda()
-    torch.cuda.synchronize()
-    order = ["g2", "a", "b", "hole", "short", "a", "b", "g2"]      # 8 MSMs through a ring of 4 slots
-    outs = [np.zeros((lanes, 18 * keys[nm].group), dtype=np.uint64) for nm in order]
-    ctx.msm_multi_async([keys[nm] for nm in order], sd.data_ptr(), n, lanes, czk.CZK_SCALAR_MONTGOMERY, outs, stable=True)
-    ctx.sync()
-    for nm, out in zip(order, outs):
-        g = keys[nm].group
-        m = len(ks[nm])
-        for ln in range(lanes):
-            e = dot_mod_r(ks[nm], s[ln, :m])
-            assert _same_point(ctx, orc, g, out[ln], orc.scalar_mul(g, gen[g], False, ints_to_limbs([e], 4)[0])), (nm, ln)
-    # ... and the one-at-a-time entry point still agrees after a multi call went through the same slots
-    one = ctx.msm(keys["b"], sd.data_ptr(), n_scalars=n, lanes=lanes, scalar_form=czk.CZK_SCALAR_MONTGOMERY, mem=czk.CZK_MEM_DEVICE)
-    for ln in range(lanes):
-        assert _same_point(ctx, orc, 1, one[ln], outs[2][ln])
-    with pytest.raises(Exception):
-        ctx.msm_multi_async([keys["a"]], sd.data_ptr(), n, lanes, 7, [outs[1]])
-    # a longer key in the middle of a call grows (and moves) the sort workspaces: the lender's lists must not be borrowed afterwards
-    c2 = czk.Context()
-    kb = rand_fr_canonical(0x57, 2 * n)
-    big = c2.register_bases(1, c2.fixed_base_points(1, kb), None)
-    s2 = rand_fr_canonical(0x58, 2 * n).reshape(1, 2 * n, 4)
-    sd2 = torch.from_numpy(s2.view(np.int64)).cuda()
-    torch.cuda.synchronize()
-    small = {nm: c2.register_bases(1, c2.fixed_base_points(1, ks[nm]), None) for nm in ("a", "b")}
-    o3 = [np.zeros((1, 18), dtype=np.uint64) for _ in range(3)]
-    c2.msm_multi_async([small["a"], big, small["b"]], sd2.data_ptr(), 2 * n, 1, czk.CZK_SCALAR_CANONICAL, o3)
-    c2.sync()
-    for out, k in zip(o3, (ks["a"], kb, ks["b"])):
-        e = dot_mod_r(k, s2[0, :len(k)])
-        assert _same_point(c2, orc, 1, out[0], orc.scalar_mul(1, gen[1], False, ints_to_limbs([e], 4)[0]))
-    for b in list(small.values()) + [big]:
-        b.release()
-    c2.close() if hasattr(c2, "close") else None
-    for b in keys.values():
-        b.release()
-
-
 @pytest.mark.parametrize("g,n", [(1, (1 << 20) + 1), (1, (1 << 21) - 1), (2, (1 << 17) + 1), (2, (1 << 20) + 1), (1, 1 << 18), (1, 3 * (1 << 20) + 7), (1, (1 << 22) + 1),
                                  (2, (1 << 22) + 1), (1, (1 << 23) - 1)])
 def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, n):

@@ -233,9 +233,10 @@ class Groth16Host {
         results.emplace_back(L);
         ProofElements& r = results.back();
         // create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): they overlap the witness map below
-        czk::multi_scalar_mul_multi_async(b_g2_query_->ctx(), {czk::msm_target(*b_g2_query_, r.b_g2.data()), czk::msm_target(*a_query_, r.a.data()),
-                                                               czk::msm_target(*b_g1_query_, r.b_g1.data())}, *asg_, N + 1, true);
+        czk::multi_scalar_mul_async(*b_g2_query_, *asg_, N + 1, r.b_g2.data(), true);
         czk::multi_scalar_mul_async(*l_query_, *wit_, N, r.l.data(), true);
+        czk::multi_scalar_mul_async(*a_query_, *asg_, N + 1, r.a.data(), true);
+        czk::multi_scalar_mul_async(*b_g1_query_, *asg_, N + 1, r.b_g1.data(), true);
         // evaluate_constraint over the share lanes of the full assignment (r1cs_to_qap.rs:67-83, 95-100)
         mat_a_->evaluate(*full_, *a_);
         mat_b_->evaluate(*full_, *b_);
