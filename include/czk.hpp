@@ -64,6 +64,11 @@ class Context {
         if (rc != CZK_OK) throw Panic(rc, czk_last_error(ctx_));
     }
     void sync() const { check(czk_ctx_sync(ctx_)); }
+    // czk_ctx_reserve: twiddle tables of a 2^ntt_log_d domain (0: none) and the MSM workspaces for calls of `n_scalars` x `msm_lanes` on
+    // `bases` (nullptr: none), at key load instead of inside the first proof
+    void reserve(unsigned ntt_log_d, size_t ntt_lanes, const czk_bases* bases = nullptr, size_t n_scalars = 0, size_t msm_lanes = 0) const {
+        check(czk_ctx_reserve(ctx_, ntt_log_d, ntt_lanes, bases, n_scalars, msm_lanes));
+    }
 
   private:
     czk_ctx* ctx_ = nullptr;

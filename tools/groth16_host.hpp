@@ -166,6 +166,10 @@ class Groth16Host {
         a_query_ = mk_bases<CZK_G1>(N + 1, 3, false, no_tables);
         b_g1_query_ = mk_bases<CZK_G1>(N + 1, 4, true, no_tables);
         b_g2_query_ = mk_bases<CZK_G2>(N + 1, 5, true, no_tables);
+        // NTT tables of the witness-map domain and the MSM workspaces of this key's largest G1 and G2 calls: at key load, not inside the first proof
+        ctx.reserve(log_d, L, h_query_->raw(), D, L);
+        ctx.reserve(0, 0, b_g2_query_->raw(), N + 1, L);
+        ctx.sync();
         // ---- squaring-circuit witness (mpc-snarks/src/proof.rs:304-344) and its additive shares (share/spdz.rs:150-162) -------
         std::vector<Fr> w(N + 1);
         w[0] = hostfr::from_repr(rand_fr_canonical(seed, 1)[0]);
