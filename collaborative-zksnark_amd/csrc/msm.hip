@@ -352,32 +352,38 @@ __global__ __launch_bounds__(1024) void k_part_scan(const u32* part_counts, u32*
 #define CZK_PS_TILE 16
 #endif
 constexpr unsigned PS_TILE = CZK_PS_TILE;   // entries per thread
-__global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* part_base, u32* part_cursor,
-                                                      unsigned n_parts, unsigned part_shift, u32* part_idx, uint16_t* part_lb) {
+// NT threads x PS_TILE entries per tile.  A tile leaves as one run per partition, so a run is tile / n_parts entries long: 256 threads (8-entry
+// runs at 512 partitions) for the common case, 1024 threads for calls with 2048 partitions (3 * 2^20-point commitments, 2^22-point queries), whose
+// runs would otherwise be 2 entries: partial sectors again (same-box: Marlin 5.67 -> 6.01 proofs/s, Groth16 at 2^22 3.12 -> 3.28; at 1024 partitions --
+// the 2^21-point h query -- the large tile measured no better, so it keeps the small one).
+static size_t part_scatter_lds(unsigned nt, unsigned n_parts) { return (size_t)(3 * n_parts + nt) * 4 + (size_t)nt * PS_TILE * (4 + 2 + 2); }
+template <unsigned NT>
+__global__ __launch_bounds__(NT) void k_part_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* part_base, u32* part_cursor,
+                                                     unsigned n_parts, unsigned part_shift, u32* part_idx, uint16_t* part_lb) {
     // The tile is ordered by partition in LDS first and leaves as runs: consecutive lanes then write consecutive addresses of a partition's region
     // (a store instruction touches ~8 sectors instead of 64 partial ones).
-    __shared__ u32 h[MAX_PARTS], base[MAX_PARTS], lofs[MAX_PARTS], red[256];
-    __shared__ u32 st_idx[256 * PS_TILE];
-    __shared__ uint16_t st_lb[256 * PS_TILE], st_pt[256 * PS_TILE];
-    for (unsigned t = threadIdx.x; t < n_parts; t += 256) h[t] = 0;
+    extern __shared__ u32 pscat_lds[];
+    u32 *h = pscat_lds, *base = h + n_parts, *lofs = base + n_parts, *red = lofs + n_parts, *st_idx = red + NT;
+    uint16_t *st_lb = (uint16_t*)(st_idx + NT * PS_TILE), *st_pt = st_lb + NT * PS_TILE;
+    for (unsigned t = threadIdx.x; t < n_parts; t += NT) h[t] = 0;
     __syncthreads();
     const unsigned lane = blockIdx.y, tid = threadIdx.x;
-    const size_t total = (size_t)W * size, tile0 = (size_t)blockIdx.x * 256 * PS_TILE;
+    const size_t total = (size_t)W * size, tile0 = (size_t)blockIdx.x * NT * PS_TILE;
     u32 code[PS_TILE], rank[PS_TILE];
 #pragma unroll
     for (unsigned k = 0; k < PS_TILE; k++) {
-        size_t e = tile0 + (size_t)k * 256 + tid;
+        size_t e = tile0 + (size_t)k * NT + tid;
         code[k] = e < total ? digits[(size_t)lane * total + e] : 0u;
         if (code[k]) rank[k] = atomicAdd(&h[((code[k] & 0x7fffffffu) - 1) & (n_parts - 1)], 1u);
     }
     __syncthreads();
     // exclusive scan of h over the partitions (n_parts <= 2048: up to 8 per thread) -> lofs; global bases
-    const unsigned per = (n_parts + 255) / 256;
+    const unsigned per = (n_parts + NT - 1) / NT;
     u32 sum = 0;
     for (unsigned i = tid * per; i < tid * per + per && i < n_parts; i++) sum += h[i];
     red[tid] = sum;
     __syncthreads();
-    for (unsigned d = 1; d < 256; d <<= 1) {
+    for (unsigned d = 1; d < NT; d <<= 1) {
         u32 x = tid >= d ? red[tid - d] : 0;
         __syncthreads();
         red[tid] += x;
@@ -389,12 +395,12 @@ __global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t 
         run += h[i];
         if (h[i]) base[i] = part_base[(size_t)lane * (n_parts + 1) + i] + atomicAdd(&part_cursor[(size_t)lane * n_parts + i], h[i]);
     }
-    const u32 n_tile = red[255];
+    const u32 n_tile = red[NT - 1];
     __syncthreads();
 #pragma unroll
     for (unsigned k = 0; k < PS_TILE; k++) {
         if (!code[k]) continue;
-        size_t e = tile0 + (size_t)k * 256 + tid;
+        size_t e = tile0 + (size_t)k * NT + tid;
         size_t w = e / size, i = e - w * size;
         u32 b = (code[k] & 0x7fffffffu) - 1;
         const u32 pt = b & (n_parts - 1), slot = lofs[pt] + rank[k];
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void k_part_scatter(const u32* digits, size_t 
         st_pt[slot] = (uint16_t)pt;
     }
     __syncthreads();
-    for (u32 sl = tid; sl < n_tile; sl += 256) {
+    for (u32 sl = tid; sl < n_tile; sl += NT) {
         const u32 pt = st_pt[sl];
         const size_t dst = (size_t)lane * total + base[pt] + (sl - lofs[pt]);
         part_idx[dst] = st_idx[sl];
@@ -1052,8 +1058,12 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             }
             hipLaunchKernelGGL(k_part_scan, dim3((unsigned)lanes), dim3(1024), 0, ss, part_counts, part_base, part_cursor, n_parts);
             if (size) {
-                hipLaunchKernelGGL(k_part_scatter, dim3((unsigned)((total + 256 * PS_TILE - 1) / (256 * PS_TILE)), (unsigned)lanes), dim3(256), 0, ss, digits,
-                                   size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
+                if (n_parts >= 2048 && part_scatter_lds(1024, n_parts) <= ctx->lds_per_block)
+                    hipLaunchKernelGGL(k_part_scatter<1024>, dim3((unsigned)((total + 1024 * PS_TILE - 1) / (1024 * PS_TILE)), (unsigned)lanes), dim3(1024),
+                                       part_scatter_lds(1024, n_parts), ss, digits, size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
+                else
+                    hipLaunchKernelGGL(k_part_scatter<256>, dim3((unsigned)((total + 256 * PS_TILE - 1) / (256 * PS_TILE)), (unsigned)lanes), dim3(256),
+                                       part_scatter_lds(256, n_parts), ss, digits, size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
             }
             {
                 // dynamic LDS: counters + scan scratch + as large a staging area as the device's per-workgroup limit allows (gfx950: 160 KiB -> 36 k entries)
