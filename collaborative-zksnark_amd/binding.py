@@ -368,6 +368,17 @@ class Context:
         self._ck(self._L.czk_poly_div_linear(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(qp), _ptr(remainder), C.c_int(mem)))
         return quotient, remainder
 
+    def poly_evaluate(self, coeffs, z, lanes: int = 1, n=None, values=None, mem=CZK_MEM_HOST):
+        """p(z) per lane (czk_poly_evaluate); host mode returns (lanes, 4)."""
+        z = np.ascontiguousarray(z, np.uint64).reshape(4)
+        if mem == CZK_MEM_HOST:
+            coeffs = np.ascontiguousarray(coeffs, np.uint64).reshape(lanes, -1, 4)
+            n = coeffs.shape[1]
+            values = np.zeros((lanes, 4), dtype=np.uint64)
+        cp = coeffs if not (isinstance(coeffs, np.ndarray) and coeffs.size == 0) else None
+        self._ck(self._L.czk_poly_evaluate(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(values), C.c_int(mem)))
+        return values
+
     def fr_prefix_product(self, x, out=None, n=None, mem=CZK_MEM_HOST):
         """Running products of a public Fr vector (partial_products' local loop)."""
         if mem == CZK_MEM_HOST:

@@ -128,6 +128,26 @@ static int suffix_horner(czk_ctx* ctx, const u64* in, size_t in_stride, size_t n
     return CZK_OK;
 }
 
+// p(x) alone (no quotient): the per-segment Horner values are the coefficients of a polynomial in x^SEG, SEG times shorter; the last
+// level (one segment) writes the value.  Reads the input once and writes n / SEG elements, where the division writes n.
+static size_t eval_horner_scratch(size_t n, size_t lanes) {
+    size_t tot = 0;
+    for (size_t n_seg = (n + SEG - 1) / SEG; n_seg > 1; n_seg = (n_seg + SEG - 1) / SEG) tot += lanes * n_seg * 32;
+    return tot;
+}
+static int eval_horner(czk_ctx* ctx, const u64* in, size_t in_stride, size_t n, size_t lanes, Fr x, u64* value, char*& ws) {
+    const size_t n_seg = (n + SEG - 1) / SEG;
+    u64* H = value;   // one segment: its Horner value is p(x) (lanes x 1 elements: the layout of `value`)
+    if (n_seg > 1) {
+        H = (u64*)ws;
+        ws += lanes * n_seg * 32;
+    }
+    hipLaunchKernelGGL(k_seg_horner, dim3((unsigned)((n_seg + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, in, in_stride, n, x, H, n_seg);
+    CZK_HIP(ctx, hipGetLastError());
+    if (n_seg > 1) return eval_horner(ctx, H, n_seg, n_seg, lanes, host_pow(x, SEG), value, ws);
+    return CZK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Running products out[i] = x_0 * ... * x_i of a public vector: the local loop of partial_products between its open and
 // the final scale (mpc-algebra/src/share/field.rs:169-172; Plonk's grand product).  Same three-phase segment scheme as
@@ -325,6 +345,30 @@ extern "C" int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t 
     }
     CZK_TRY(sq.to_host(quotient, lanes * qn * 32));
     if (remainder) CZK_TRY(sr.to_host(remainder, lanes * 32));
+    return CZK_OK;
+}
+
+extern "C" int czk_poly_evaluate(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* values, int mem) {
+    if (!ctx || !z || (lanes && n && !coeffs) || (lanes && !values)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null poly_evaluate argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
+    if (!lanes) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    if (n == 0) {   // the zero polynomial
+        if (mem == CZK_MEM_HOST) memset(values, 0, lanes * 32);
+        else CZK_HIP(ctx, hipMemsetAsync(values, 0, lanes * 32, ctx->stream));
+        return CZK_OK;
+    }
+    const Fr x = host_fr(z);   // host pointer, 8-byte aligned only
+    Staged sp{ctx}, sv{ctx};
+    CZK_TRY(sp.to_device(coeffs, lanes * n * 32, mem));
+    CZK_TRY(sv.to_device(mem == CZK_MEM_HOST ? nullptr : values, lanes * 32, mem));
+    CZK_TRY(ensure_buf(ctx, ctx->poly_scratch, eval_horner_scratch(n, lanes) + 256));
+    char* ws = (char*)ctx->poly_scratch.p;
+    {
+        ProfScope ps(ctx, "poly_evaluate");
+        CZK_TRY(eval_horner(ctx, (const u64*)sp.dev, n, n, lanes, x, (u64*)sv.dev, ws));
+    }
+    CZK_TRY(sv.to_host(values, lanes * 32));
     return CZK_OK;
 }
 

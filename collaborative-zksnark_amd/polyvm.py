@@ -312,9 +312,11 @@ class GpuBackend(Backend):
         return self.torch.cat(parts, dim=0).contiguous()
 
     def resized(self, a, n):
-        out = self.torch.zeros((a.shape[0], n, 4), dtype=self.torch.int64, device=self.dev)
+        out = self.torch.empty((a.shape[0], n, 4), dtype=self.torch.int64, device=self.dev)
         m = min(n, a.shape[1])
         out[:, :m] = a[:, :m]
+        if n > m:
+            out[:, m:].zero_()      # only the tail is cleared (a full zero fill + copy moved every byte twice)
         return out
 
     def drop_first(self, a, k):
@@ -416,8 +418,16 @@ class GpuBackend(Backend):
             public = a.shape[0] == 1 and self.lanes > 1
         return "value" if public else "open_value"      # evaluations of share polynomials are publicized (mpc-plonk/src/lib.rs:362-365, marlin/src/lib.rs:283-292)
 
+    def _evaluate_dev(self, a, x):
+        a = a.contiguous()
+        val = self.torch.empty((a.shape[0], 4), dtype=self.torch.int64, device=self.dev)
+        self.ctx.poly_evaluate(a.data_ptr(), mont(x), lanes=a.shape[0], n=a.shape[1], values=val.data_ptr(), mem=self.M)
+        return val
+
+    evaluate_by_division = False     # A/B switch (bench.py --eval-by-division): p(x) as the remainder of czk_poly_div_linear, as rounds 2 - 3 did
+
     def evaluate(self, a, x, public=None):
-        p = Pending((self._value_kind(a, public), self._div_linear_dev(a, x)[1]))
+        p = Pending((self._value_kind(a, public), self._div_linear_dev(a, x)[1] if self.evaluate_by_division else self._evaluate_dev(a, x)))
         self._pending.append(p)
         return p
 

@@ -233,6 +233,11 @@ int czk_r1cs_matvec(czk_ctx* ctx, const czk_r1cs_matrix* a, const uint64_t* z, s
  * Polynomial::evaluate (kzg10/mod.rs:247).  z: one Montgomery Fr in HOST memory. */
 int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* quotient,
                         uint64_t* remainder, int mem);
+/* DensePolynomial::evaluate (algebra/poly/src/polynomial/univariate/dense.rs:59-96, Horner) per lane, without the quotient: the
+ * evaluations a prover publishes at its challenge points (mpc-plonk/src/lib.rs:273, :360; poly-commit/src/kzg10/mod.rs:246, :525;
+ * Marlin's evaluation round).  coeffs: lanes x n Fr, low degree first; values: lanes Fr = p(z); z: one Montgomery Fr in HOST
+ * memory.  Same result as czk_poly_div_linear's remainder, at half its memory traffic. */
+int czk_poly_evaluate(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* values, int mem);
 
 /* out[i] = x[0] * x[1] * ... * x[i] over a PUBLIC vector: the sequential loop of partial_products between its
  * batch_open and the final scale (mpc-algebra/src/share/field.rs:169-172; Plonk's grand product).  The share-side

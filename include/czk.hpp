@@ -364,6 +364,12 @@ struct KZG10 {
         if (evaluation) *evaluation = rem;
         return w;
     }
+    // Polynomial::evaluate (algebra/poly/src/polynomial/univariate/dense.rs:59-96; kzg10/mod.rs:246, :525): p(point), no quotient written
+    static Fr evaluate(const Context& ctx, const std::vector<Fr>& p, const Fr& point) {
+        Fr v{{0, 0, 0, 0}};
+        ctx.check(czk_poly_evaluate(ctx.raw(), p.empty() ? nullptr : p[0].l, p.size(), 1, point.l, v.l, CZK_MEM_HOST));
+        return v;
+    }
     // KZG10::open_with_witness_polynomial (kzg10/mod.rs:225-265): proof.w before into_affine; with hiding the second MSM
     // runs over powers_of_gamma_g and random_v = blinding_p(point).
     struct Proof {

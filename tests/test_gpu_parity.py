@@ -599,6 +599,10 @@ def test_poly_div_linear_matches_oracle(ctx, czk, orc, n):
     for ln in range(lanes):
         qw, rw = orc.poly_div_linear(p[ln], z)
         assert np.array_equal(q[ln], qw) and np.array_equal(r[ln], rw), (n, ln)
+    # czk_poly_evaluate (DensePolynomial::evaluate, no quotient): the same values
+    v = ctx.poly_evaluate(p, z, lanes=lanes)
+    for ln in range(lanes):
+        assert np.array_equal(v[ln], orc.fr_horner(p[ln], z) if n else np.zeros(4, dtype=np.uint64)), (n, ln)
 
 
 def test_poly_div_linear_full_size_identity(ctx, czk, orc):
@@ -616,6 +620,11 @@ def test_poly_div_linear_full_size_identity(ctx, czk, orc):
     ctx.poly_div_linear(pt.data_ptr(), z, lanes=lanes, n=n, quotient=q.data_ptr(), remainder=r.data_ptr(), mem=czk.CZK_MEM_DEVICE)
     ctx.sync()
     ph, qh, rh = pt.cpu().numpy().view(np.uint64).reshape(lanes, n, 4), q.cpu().numpy().view(np.uint64), r.cpu().numpy().view(np.uint64)
+    v = torch.zeros((lanes, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.poly_evaluate(pt.data_ptr(), z, lanes=lanes, n=n, values=v.data_ptr(), mem=czk.CZK_MEM_DEVICE)
+    ctx.sync()
+    assert np.array_equal(v.cpu().numpy().view(np.uint64), rh)     # evaluation without the quotient: the remainder, bit for bit
     for ln in range(lanes):
         assert np.array_equal(rh[ln], orc.fr_horner(ph[ln], z))
         lhs = orc.fr_horner(ph[ln], x)
@@ -686,6 +695,9 @@ def test_poly_and_scan_entry_points_reject_bad_arguments(ctx, czk, orc):
     z = one.ctypes.data_as(C.c_void_p)
     assert L.czk_poly_div_linear(h, p, C.c_size_t(8), C.c_size_t(1), null, p, null, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG      # no point
     assert L.czk_poly_div_linear(h, null, C.c_size_t(8), C.c_size_t(1), z, p, null, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG   # no coefficients
+    assert L.czk_poly_evaluate(h, p, C.c_size_t(8), C.c_size_t(1), null, p, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG           # no point
+    assert L.czk_poly_evaluate(h, p, C.c_size_t(8), C.c_size_t(1), z, null, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG           # no destination
+    assert L.czk_poly_evaluate(h, null, C.c_size_t(8), C.c_size_t(1), z, p, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG        # no coefficients
     assert L.czk_fr_batch_inverse(h, p, C.c_size_t(8), null, p, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG                        # in-place on device
     assert L.czk_fr_prefix_product(h, null, C.c_size_t(8), p, C.c_int(czk.CZK_MEM_DEVICE)) == ERR_ARG
     assert L.czk_fr_prefix_product(h, null, C.c_size_t(0), null, C.c_int(czk.CZK_MEM_DEVICE)) == OK                            # empty vector
