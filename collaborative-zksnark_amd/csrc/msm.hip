@@ -355,7 +355,8 @@ constexpr unsigned PS_TILE = CZK_PS_TILE;   // entries per thread
 // NT threads x PS_TILE entries per tile.  A tile leaves as one run per partition, so a run is tile / n_parts entries long: 256 threads (8-entry
 // runs at 512 partitions) for the common case, 1024 threads for calls with 2048 partitions (3 * 2^20-point commitments, 2^22-point queries), whose
 // runs would otherwise be 2 entries: partial sectors again (same-box: Marlin 5.67 -> 6.01 proofs/s, Groth16 at 2^22 3.12 -> 3.28; at 1024 partitions --
-// the 2^21-point h query, Plonk's 3 * 2^19-point commitments -- 512 threads: the isolated sort of 2^21 x 4 lanes 2.74 -> 1.73 ms, per proof unchanged).
+// the 2^21-point h query, Plonk's 3 * 2^19-point commitments -- and at 512 (2^20 points) 512 threads: the isolated sort of 2^21 x 4 lanes 2.74 -> 1.73 ms,
+// of 2^20 x 4 lanes 1.03 -> 0.87 ms, per proof within noise).
 static size_t part_scatter_lds(unsigned nt, unsigned n_parts) { return (size_t)(3 * n_parts + nt) * 4 + (size_t)nt * PS_TILE * (4 + 2 + 2); }
 template <unsigned NT>
 __global__ __launch_bounds__(NT) void k_part_scatter(const u32* digits, size_t size, unsigned W, size_t n_bases, const u32* part_base, u32* part_cursor,
@@ -1061,7 +1062,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                 if (n_parts >= 2048 && part_scatter_lds(1024, n_parts) <= ctx->lds_per_block)
                     hipLaunchKernelGGL(k_part_scatter<1024>, dim3((unsigned)((total + 1024 * PS_TILE - 1) / (1024 * PS_TILE)), (unsigned)lanes), dim3(1024),
                                        part_scatter_lds(1024, n_parts), ss, digits, size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
-                else if (n_parts == 1024 && part_scatter_lds(512, n_parts) <= ctx->lds_per_block)
+                else if ((n_parts == 1024 || n_parts == 512) && part_scatter_lds(512, n_parts) <= ctx->lds_per_block)
                     hipLaunchKernelGGL(k_part_scatter<512>, dim3((unsigned)((total + 512 * PS_TILE - 1) / (512 * PS_TILE)), (unsigned)lanes), dim3(512),
                                        part_scatter_lds(512, n_parts), ss, digits, size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
                 else
