@@ -461,6 +461,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         scheme, what = "SPDZ", f"Marlin AHP rounds + commitments + batched openings, {n} constraints"
     t0 = time.time()
     polyvm.GpuBackend.evaluate_by_division = bool(getattr(args, "eval_by_division", False))
+    polyvm.GpuBackend.ntt_copy_first = bool(getattr(args, "ntt_copy_first", False))
     B = polyvm.GpuBackend(czk, ctx, lanes, max_deg, lift=lift)
     if party:
         # one party per rank: every batch of evaluations made between two challenges is opened over torch.distributed
@@ -665,6 +666,7 @@ def main():
     ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
                     help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "
                          "--parties 3 --log-n 18); marlin: AHP rounds + commitments + batched openings, SPDZ lanes (configs[3]: --log-n 20)")
+    ap.add_argument("--ntt-copy-first", action="store_true", help="A/B (plonk / marlin): radix-2 transforms as copy + czk_ntt_fr instead of czk_ntt_fr_to")
     ap.add_argument("--eval-by-division", action="store_true", help="A/B (plonk / marlin): evaluations as remainders of czk_poly_div_linear instead of czk_poly_evaluate")
     ap.add_argument("--layout", choices=("replica", "party", "split"), default="replica",
                     help="replica (default, BASELINE configs[1]): every GPU proves independently with all parties' lanes on it; "

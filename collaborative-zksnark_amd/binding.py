@@ -155,6 +155,15 @@ class Context:
         return Lanes(self, h)
 
     # ---- NTT ------------------------------------------------------------------------------------
+    def ntt_fr_to(self, src, src_stride: int, dst, log_d: int, kind: int, lanes: int = 1, in_len: int | None = None):
+        """EvaluationDomain::{fft,ifft,coset_fft,coset_ifft} (not in place): device pointers; reads in_len elements per source lane (stride
+        src_stride elements), writes 2^log_d per lane to dst."""
+        if in_len is None:
+            in_len = min(src_stride, 1 << log_d)
+        self._ck(self._L.czk_ntt_fr_to(self._h, _ptr(src), C.c_size_t(src_stride), _ptr(dst), C.c_uint(log_d), C.c_size_t(lanes), C.c_int(kind),
+                                     C.c_size_t(in_len), C.c_int(CZK_MEM_DEVICE)))
+        return dst
+
     def ntt_fr(self, data, log_d: int, kind: int, lanes: int = 1, in_len: int | None = None, mem: int = CZK_MEM_HOST):
         """EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place on `lanes` Fr lanes (in place)."""
         d = 1 << log_d

@@ -250,7 +250,7 @@ void xfer_destroy(czk_ctx* ctx);
 int upload_pageable(czk_ctx* ctx, void* dev, const void* host, size_t bytes);
 int download_pageable(czk_ctx* ctx, void* host, const void* dev, size_t bytes);
 // implemented in ntt.hip
-int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len);
+int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len, const u64* src = nullptr, size_t src_stride = 0);
 // implemented in ntt_mixed.hip
 int get_mixed_domain(czk_ctx* ctx, unsigned k, MixedDomain** out);
 int ntt_mixed_device(czk_ctx* ctx, u64* data, unsigned k, size_t lanes, int kind, size_t in_len);

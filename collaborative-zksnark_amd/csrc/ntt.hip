@@ -67,6 +67,7 @@ struct PassArgs {
     size_t in_len;        // elements >= in_len read as zero (only honoured when `first`)
     int first;
     size_t lane_stride;   // elements between lanes (= D)
+    size_t in_lane_stride;   // ... of `in` in the first pass (out-of-place transforms read the caller's source lanes)
 };
 
 // One strided pass: stage bits [s_lo, s_lo + K), s_lo > 0.
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void k_ntt_strided(PassArgs a) {
     const unsigned Lb = B & ((1u << lb_bits) - 1u);
     const size_t H = B >> lb_bits;
     const size_t base = (H << (a.s_lo + a.K)) | ((size_t)Lb << a.logT);
-    const u64* in = a.in + 4 * a.lane_stride * blockIdx.y;
+    const u64* in = a.in + 4 * (a.first ? a.in_lane_stride : a.lane_stride) * blockIdx.y;
     u64* out = a.out + 4 * a.lane_stride * blockIdx.y;
 
     for (unsigned e = tid; e < rows * T; e += 256) {
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_ntt_final(PassArgs a) {
     uint4* tw_lds = smem + 2 * (size_t)RS * T;
     const unsigned hb = a.n - c;   // bits of the chunk id
     const unsigned B = blockIdx.x;
-    const u64* in = a.in + 4 * a.lane_stride * blockIdx.y;
+    const u64* in = a.in + 4 * (a.first ? a.in_lane_stride : a.lane_stride) * blockIdx.y;
     u64* out = a.out + 4 * a.lane_stride * blockIdx.y;
 
     for (unsigned e = tid; e + 1 < len; e += 256) lds_put(tw_lds, e, gfr_load(a.tw, e));   // stages 0..c-1: 2^c - 1 entries
@@ -394,8 +395,12 @@ static int ensure_tables(czk_ctx* ctx, DomainTables* d, bool need_coset_fwd, boo
 // ------------------------------------------------------------------------------------------------
 // driver
 // ------------------------------------------------------------------------------------------------
-int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len) {
+int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, size_t in_len, const u64* src, size_t src_stride) {
     if (kind < 0 || kind > 3) return set_err(ctx, CZK_ERR_ARG, "bad ntt kind");
+    if (!src) {   // in place
+        src = data;
+        src_stride = (size_t)1 << log_d;
+    }
     DomainTables* d = nullptr;
     CZK_TRY(get_domain(ctx, log_d, &d));
     const size_t D = (size_t)1 << log_d;
@@ -416,6 +421,7 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
     a.n = n;
     a.in_len = in_len;
     a.lane_stride = D;
+    a.in_lane_stride = src_stride;
     a.postconst = d->size_inv;
 
     u64* scratch = nullptr;
@@ -431,6 +437,7 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
         b.n = n;
         b.in_len = in_len;
         b.lane_stride = D;
+        b.in_lane_stride = src_stride;
         b.postconst = host_fr_to_u(d->size_inv);
         for (unsigned p = 0; p < m; p++) {
             const bool first = (p == 0), last = (p == m - 1);
@@ -441,7 +448,7 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
             b.prescale = (first && kind == CZK_COSET_FFT) ? d->cosetu_fwd : nullptr;
             b.posttab = (last && kind == CZK_COSET_IFFT) ? d->cosetu_inv : nullptr;
             b.post_mode = !last ? 0 : (kind == CZK_IFFT ? 1 : (kind == CZK_COSET_IFFT ? 2 : 0));
-            b.in = first ? data : scratch;
+            b.in = first ? src : scratch;
             b.out = last ? data : scratch;
             ProfScope ps(ctx, "ntt_pass");
             CZK_TRY(launch_ntt2_pass(ctx, b, K, last, lanes));
@@ -457,7 +464,7 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
         a.prescale = (first && kind == CZK_COSET_FFT) ? d->coset_fwd : nullptr;
         a.posttab = nullptr;
         a.post_mode = 0;
-        a.in = first ? data : scratch;
+        a.in = first ? src : scratch;
         a.out = last ? data : scratch;
         ProfScope ps(ctx, "ntt_pass");
         if (!last) {
@@ -561,6 +568,17 @@ static int ntt_host_lanes_pipelined(czk_ctx* ctx, uint64_t* data, unsigned log_d
     if (down) (void)hipStreamDestroy(down);
     stage_give(ctx, buf);
     return rc;
+}
+
+extern "C" int czk_ntt_fr_to(czk_ctx* ctx, const uint64_t* src, size_t src_stride, uint64_t* dst, unsigned log_d, size_t lanes, int kind, size_t in_len,
+                             int mem) {
+    if (!ctx) return CZK_ERR_ARG;
+    if (!dst || (in_len && !src)) return set_err(ctx, CZK_ERR_ARG, "null ntt argument");
+    if (mem != CZK_MEM_DEVICE) return set_err(ctx, CZK_ERR_ARG, "czk_ntt_fr_to takes device memory (host callers copy and use czk_ntt_fr)");
+    if (log_d > 47) return set_err(ctx, CZK_ERR_SIZE, "domain too large: log2 D exceeds TWO_ADICITY = 47 (radix2/mod.rs:61-63)");
+    if (in_len > src_stride && lanes > 1) return set_err(ctx, CZK_ERR_ARG, "in_len exceeds the source lane stride");
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    return ntt_device(ctx, (u64*)dst, log_d, lanes, kind, in_len, in_len ? (const u64*)src : (const u64*)dst, in_len ? src_stride : ((size_t)1 << log_d));
 }
 
 extern "C" int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int kind, size_t in_len, int mem) {

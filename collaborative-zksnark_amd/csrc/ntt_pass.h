@@ -31,6 +31,7 @@ struct Pass2Args {
     size_t in_len;        // elements >= in_len read as zero (only honoured when `first`)
     int first;
     size_t lane_stride;   // elements between lanes (= D)
+    size_t in_lane_stride;   // ... of `in` in the first pass (out-of-place transforms read the caller's source lanes)
 };
 
 int launch_ntt2_pass(czk_ctx* ctx, const Pass2Args& a, unsigned K, bool last, size_t lanes);

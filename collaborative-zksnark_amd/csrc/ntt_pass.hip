@@ -248,7 +248,7 @@ __global__ __launch_bounds__((1 << K) * 2) void k_ntt2_strided(Pass2Args a) {
     const size_t base = (H << (a.s_lo + K)) | ((size_t)Lb << NTT2_LOGT);
     const unsigned low0 = Lb << NTT2_LOGT;
     constexpr int W = LAZY_IN ? 2 : 1;   // inputs < 2 r instead of < 1.003 r: constants one power of two up
-    const u64* in = (const u64*)((const char*)a.in + (LAZY_IN ? NTT2_SCRATCH_ELEM_BYTES : 32) * a.lane_stride * blockIdx.y);
+    const u64* in = (const u64*)((const char*)a.in + (a.first ? 32 * a.in_lane_stride : (LAZY_IN ? NTT2_SCRATCH_ELEM_BYTES : 32) * a.lane_stride) * blockIdx.y);
     u64* out = (u64*)((char*)a.out + NTT2_SCRATCH_ELEM_BYTES * a.lane_stride * blockIdx.y);
     if constexpr (K == 7) {
         strided_step<7, 4, 3, 2 * W, true, false, LAZY_IN>(a, smem2, in, out, base, low0);

@@ -392,6 +392,12 @@ class GpuBackend(Backend):
     def ntt(self, a, size, kind):
         m = min(a.shape[1], size)
         buf = self.torch.empty((a.shape[0], size, 4), dtype=self.torch.int64, device=self.dev)   # not zero-filled: the first pass zero-extends
+        if size & (size - 1) == 0 and m > 0 and not self.ntt_copy_first:
+            # radix-2 domain: the transform reads the source lanes itself (EvaluationDomain::fft(&coeffs) -> Vec: no copy of the operand)
+            a = a.contiguous()
+            self.ctx.ntt_fr_to(a.data_ptr(), a.shape[1], buf.data_ptr(), size.bit_length() - 1, kind, lanes=buf.shape[0], in_len=m)
+            self.ntt_count += buf.shape[0]
+            return buf
         buf[:, :m] = a[:, :m]                                                                   # beyond in_len itself (czk_ntt_fr_mixed)
         self.ctx.ntt_fr_mixed(buf.data_ptr(), size, kind, lanes=buf.shape[0], in_len=m, mem=self.M)
         self.ntt_count += buf.shape[0]
@@ -424,6 +430,7 @@ class GpuBackend(Backend):
         self.ctx.poly_evaluate(a.data_ptr(), mont(x), lanes=a.shape[0], n=a.shape[1], values=val.data_ptr(), mem=self.M)
         return val
 
+    ntt_copy_first = False           # A/B switch (bench.py --ntt-copy-first): copy the operand, then transform in place, as rounds 2 - 3 did
     evaluate_by_division = False     # A/B switch (bench.py --eval-by-division): p(x) as the remainder of czk_poly_div_linear, as rounds 2 - 3 did
 
     def evaluate(self, a, x, public=None):

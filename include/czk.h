@@ -147,6 +147,12 @@ int czk_lanes_zero(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t elem, size_
  * On an error return `data` is undefined (host memory: lanes are written back as they finish, so some may already hold their
  * transform); the reference panics at the corresponding points, so no caller continues with the vector. */
 int czk_ntt_fr(czk_ctx* ctx, uint64_t* data, unsigned log_d, size_t lanes, int kind, size_t in_len, int mem);
+/* The non-in-place forms EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}(&self, coeffs: &[T]) -> Vec<T> (algebra/poly/src/domain/mod.rs:
+ * 72-76, 83-87, 130-134, 146-150: `coeffs.to_vec()` then the in-place transform): reads in_len elements per lane from src (lane k at
+ * src + 4 * k * src_stride u64) and writes the 2^log_d results per lane to dst (lane stride 2^log_d); the copy the reference makes is the
+ * transform's first load.  src and dst must not overlap unless they are equal with src_stride = 2^log_d.  DEVICE memory only. */
+int czk_ntt_fr_to(czk_ctx* ctx, const uint64_t* src, size_t src_stride, uint64_t* dst, unsigned log_d, size_t lanes, int kind,
+                  size_t in_len, int mem);
 
 /* Domain constants as the reference's Radix2EvaluationDomain::new computes them (radix2/mod.rs:51-82), Montgomery
  * limbs: out[0..4) size_inv, [4..8) group_gen, [8..12) group_gen_inv, [12..16) generator (22), [16..20) generator_inv,

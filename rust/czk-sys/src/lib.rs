@@ -64,6 +64,7 @@ extern "C" {
     pub fn czk_lanes_copy(ctx: *mut czk_ctx, dst: *mut czk_lanes, dst_lane: usize, dst_elem: usize, src: *const czk_lanes, src_lane: usize, src_elem: usize, n: usize) -> c_int;
     pub fn czk_lanes_zero(ctx: *mut czk_ctx, dst: *mut czk_lanes, lane: usize, elem: usize, n: usize) -> c_int;
     pub fn czk_ntt_fr(ctx: *mut czk_ctx, data: *mut u64, log_d: c_uint, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
+    pub fn czk_ntt_fr_to(ctx: *mut czk_ctx, src: *const u64, src_stride: usize, dst: *mut u64, log_d: c_uint, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
     pub fn czk_domain_constants(ctx: *mut czk_ctx, log_d: c_uint, out24: *mut u64) -> c_int;
     pub fn czk_ntt_fr_mixed(ctx: *mut czk_ctx, data: *mut u64, size: usize, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
     pub fn czk_mixed_domain_constants(ctx: *mut czk_ctx, size: usize, out24: *mut u64) -> c_int;

@@ -588,6 +588,35 @@ def test_r1cs_matrix_rejects_malformed_input(ctx, czk, orc):
     mat.release()
 
 
+@pytest.mark.parametrize("log_d,in_len,stride", [(3, 8, 8), (6, 40, 50), (10, 1024, 1024), (11, 2000, 2048), (13, 5000, 5003), (16, 1 << 16, 1 << 16), (18, 200001, 262144 + 64),
+                                                  (21, (1 << 20) + 2, (1 << 20) + 2)])
+def test_ntt_out_of_place_equals_in_place(ctx, czk, orc, log_d, in_len, stride):
+    """czk_ntt_fr_to (EvaluationDomain::fft(&coeffs) -> Vec, domain/mod.rs:72-76 and its three siblings): every kind, 3 lanes, a source whose lane
+    stride differs from the domain size and whose tail beyond in_len is garbage -- bit-exact against czk_ntt_fr on a zero-extended copy (itself
+    checked against the oracle), source untouched."""
+    import torch
+    lanes, D = 3, 1 << log_d
+    src = torch.from_numpy(orc.fr_from_repr(rand_fr_canonical(900 + log_d, lanes * stride)).view(np.int64).copy()).reshape(lanes, stride, 4).cuda()
+    src[:, in_len:] = 0x5A5A5A5A5A5A5A5A                              # garbage beyond in_len: must not be read
+    keep = src.clone()
+    for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
+        ref = torch.zeros((lanes, D, 4), dtype=torch.int64, device="cuda")
+        ref[:, :in_len] = src[:, :in_len]
+        dst = torch.full((lanes, D, 4), 0x7777777777777777, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.ntt_fr(ref.data_ptr(), log_d, kind, lanes=lanes, in_len=in_len, mem=czk.CZK_MEM_DEVICE)
+        ctx.ntt_fr_to(src.data_ptr(), stride, dst.data_ptr(), log_d, kind, lanes=lanes, in_len=in_len)
+        ctx.sync()
+        assert torch.equal(dst, ref), (log_d, kind)
+        assert torch.equal(src, keep)
+    if log_d <= 13:                                                   # and against the checker directly
+        x = src[1, :in_len].cpu().numpy().view(np.uint64)
+        dst = torch.empty((lanes, D, 4), dtype=torch.int64, device="cuda")
+        ctx.ntt_fr_to(src.data_ptr(), stride, dst.data_ptr(), log_d, czk.CZK_COSET_FFT, lanes=lanes, in_len=in_len)
+        ctx.sync()
+        assert np.array_equal(dst[1].cpu().numpy().view(np.uint64), orc.ntt_fr(x, log_d, orc.COSET_FFT, in_len))
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 31, 32, 33, 127, 129, 32 * 32 + 5, 32 * 32 * 32 + 7, (1 << 17) + 3])   # around the 32-coefficient segment levels
 def test_poly_div_linear_matches_oracle(ctx, czk, orc, n):
     lanes = 2
