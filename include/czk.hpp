@@ -192,6 +192,12 @@ class Radix2EvaluationDomain {
     void ifft_in_place(DeviceLanes& v) const { run_device(v, CZK_IFFT); }
     void coset_fft_in_place(DeviceLanes& v) const { run_device(v, CZK_COSET_FFT); }
     void coset_ifft_in_place(DeviceLanes& v) const { run_device(v, CZK_COSET_IFFT); }
+    // the non-in-place forms (domain/mod.rs:72-76, 83-87, 130-134, 146-150: `coeffs.to_vec()` + the in-place transform): the copy is the first
+    // pass's load (czk_ntt_fr_to); `v` is left as it was and may be shorter or longer-strided than the domain
+    DeviceLanes fft(const DeviceLanes& v) const { return run_device_to(v, CZK_FFT); }
+    DeviceLanes ifft(const DeviceLanes& v) const { return run_device_to(v, CZK_IFFT); }
+    DeviceLanes coset_fft(const DeviceLanes& v) const { return run_device_to(v, CZK_COSET_FFT); }
+    DeviceLanes coset_ifft(const DeviceLanes& v) const { return run_device_to(v, CZK_COSET_IFFT); }
     void divide_by_vanishing_poly_on_coset_in_place(DeviceLanes& evals) const {
         const size_t n = evals.lanes() * evals.capacity();
         // czk_fr_vec_scale reads its constant from the vector's memory space: the device copy of Z(g)^-1 is made ONCE per domain and kept
@@ -224,6 +230,12 @@ class Radix2EvaluationDomain {
         if (v.len > size_ || v.capacity() != size_) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");   // radix2/mod.rs:100
         ctx_->check(czk_ntt_fr(ctx_->raw(), v.data(), log_size_of_group, v.lanes(), kind, v.len, CZK_MEM_DEVICE));
         v.len = size_;                                                                                                              // :101
+    }
+    DeviceLanes run_device_to(const DeviceLanes& v, int kind) const {
+        if (v.len > size_) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");   // radix2/mod.rs:100
+        DeviceLanes out(*ctx_, v.lanes(), size_);
+        ctx_->check(czk_ntt_fr_to(ctx_->raw(), v.data(), v.capacity(), out.data(), log_size_of_group, v.lanes(), kind, v.len, CZK_MEM_DEVICE));
+        return out;
     }
     void run_shared(std::vector<MpcField>& v, int kind) const {
         if (v.size() > size_) throw Panic(CZK_ERR_SIZE, "assertion failed: coeffs.len() <= self.size()");

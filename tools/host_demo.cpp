@@ -220,6 +220,17 @@ int main(int argc, char** argv) {
         dom->coset_ifft_in_place(cp);
         g1 = cp.to_host(0);
         for (size_t i = 0; i < 13; i++) REQUIRE(eq(g1[i], x[i]));
+        // the non-in-place form (domain/mod.rs:130-134): a shorter source with its own lane stride, left untouched
+        DeviceLanes src(ctx, 2, x.size());
+        src.upload(0, x);
+        src.upload(1, x);
+        DeviceLanes out = dom->coset_fft(src);
+        std::vector<Fr> want2 = x;
+        dom->coset_fft_in_place(want2);
+        std::vector<Fr> o1 = out.to_host(1), s0 = src.to_host(0);
+        REQUIRE(out.capacity() == 16 && src.capacity() == x.size());
+        for (size_t i = 0; i < 16; i++) REQUIRE(eq(o1[i], want2[i]));
+        for (size_t i = 0; i < x.size(); i++) REQUIRE(eq(s0[i], x[i]));
     }
 
     // MSM: P_i = [i] G, scalars all one  =>  [n(n+1)/2] G ; and the two SPDZ lanes agree (spdz.rs:441-442)
