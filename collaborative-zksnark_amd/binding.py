@@ -20,7 +20,10 @@ CZK_MEM_CHECK_SUBGROUP = 128  # czk_bases_register: verify [r] P == infinity; a 
 CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY = 0, 1
 CZK_G1, CZK_G2 = 1, 2
 CZK_OP_ADD, CZK_OP_SUB, CZK_OP_MUL = 0, 1, 2
-_STATUS = {1: "CZK_ERR_SIZE", 2: "CZK_ERR_HIP", 3: "CZK_ERR_ARG", 4: "CZK_ERR_NOMEM"}
+CZK_NET_RCCL, CZK_NET_SHM = 1, 2
+CZK_OPEN_COMMIT = 1
+CZK_ERR_NET, CZK_ERR_CHECK = 5, 6
+_STATUS = {1: "CZK_ERR_SIZE", 2: "CZK_ERR_HIP", 3: "CZK_ERR_ARG", 4: "CZK_ERR_NOMEM", 5: "CZK_ERR_NET", 6: "CZK_ERR_CHECK"}
 
 
 class CzkError(RuntimeError):
@@ -58,6 +61,10 @@ def _load(path):
     L.czk_lanes_len.restype = C.c_size_t
     L.czk_lanes_data.restype = C.c_void_p
     L.czk_ctx_stream.restype = C.c_void_p
+    L.czk_net_last_error.restype = C.c_char_p
+    L.czk_net_destroy.restype = None
+    L.czk_net_stats_reset.restype = None
+    L.czk_sha256.restype = None
     return L
 
 
@@ -246,6 +253,25 @@ class Context:
             out = np.empty_like(a) if out is None else out
         self._ck(self._L.czk_fr_from_repr(self._h, _ptr(a), _ptr(out), C.c_size_t(n), C.c_int(mem)))
         return out
+
+    def fr_vec_serialize(self, a, n=None, mem=CZK_MEM_HOST) -> bytes:
+        """`Vec<Fr>::serialize`: u64 length prefix + 32 little-endian bytes of into_repr() per element"""
+        if mem == CZK_MEM_HOST:
+            a = np.ascontiguousarray(a, np.uint64)
+            n = a.size // 4
+        out = np.zeros(8 + 32 * n, dtype=np.uint8)
+        self._ck(self._L.czk_fr_vec_serialize(self._h, _ptr(a if n else None), C.c_size_t(n), C.c_int(mem), _ptr(out)))
+        return out.tobytes()
+
+    def fr_vec_deserialize(self, data: bytes, out=None, cap=None, mem=CZK_MEM_HOST):
+        """inverse of fr_vec_serialize; host mode returns (n, 4) Montgomery limbs, device mode the element count"""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        if mem == CZK_MEM_HOST:
+            cap = max(0, (len(data) - 8) // 32)
+            out = np.zeros((cap, 4), dtype=np.uint64)
+        n = C.c_size_t(0)
+        self._ck(self._L.czk_fr_vec_deserialize(self._h, _ptr(buf), C.c_size_t(len(data)), _ptr(out if cap else None), C.c_size_t(cap), C.c_int(mem), C.byref(n)))
+        return out[: n.value] if mem == CZK_MEM_HOST else n.value
 
     # ---- MSM ------------------------------------------------------------------------------------
     def register_bases(self, group: int, bases, inf=None, n: int | None = None, mem: int = CZK_MEM_HOST) -> "Bases":
@@ -455,6 +481,133 @@ class Context:
     def witness_map_post(self, ab_ptr, c_ptr, log_d, lanes, c_len=None):
         self._ck(self._L.czk_witness_map_post(self._h, _ptr(ab_ptr), _ptr(c_ptr), C.c_size_t((1 << log_d) if c_len is None else c_len),
                                             C.c_uint(log_d), C.c_size_t(lanes)))
+
+
+class Net:
+    """czk_net: mpc-net between czk contexts (include/czk.h): RCCL for one party per GPU, SHM for parties that are processes of one node in
+    any assignment to GPUs.  `ctx` may be None for the SHM transport (host-memory primitives only).  Device buffers are raw pointers."""
+
+    STATS = ("bytes_sent", "bytes_recv", "broadcasts", "to_king", "from_king")
+
+    def __init__(self, ctx, transport: int, rank: int, world: int, id_bytes: bytes, options: dict | None = None, lab: bool = False):
+        self.ctx = ctx
+        self._L = ctx._L if ctx is not None else (lab_lib() if lab else lib())
+        self._h = C.c_void_p(0)
+        self.rank, self.world, self.transport = rank, world, transport
+        idb = (C.c_uint8 * len(id_bytes)).from_buffer_copy(bytes(id_bytes))
+        rc = self._L.czk_net_create(ctx._h if ctx is not None else None, C.c_int(transport), C.c_int(rank), C.c_int(world), idb, C.c_size_t(len(id_bytes)),
+                                    C.byref(self._h))
+        if rc:
+            raise CzkError(rc, (self._L.czk_last_error(ctx._h) or b"").decode() if ctx is not None else "czk_net_create failed")
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    @staticmethod
+    def unique_id(transport: int, lab: bool = False) -> bytes:
+        """czk_net_unique_id: rank 0 calls this and hands the bytes to the other ranks (RCCL: ncclGetUniqueId; SHM: 16 random bytes)"""
+        L = lab_lib() if lab else lib()
+        buf = (C.c_uint8 * 128)()
+        n = C.c_size_t(0)
+        rc = L.czk_net_unique_id(C.c_int(transport), buf, C.c_size_t(128), C.byref(n))
+        if rc:
+            raise CzkError(rc, "czk_net_unique_id failed (RCCL: librccl.so.1 not loadable)")
+        return bytes(buf[: n.value])
+
+    def _ck(self, rc):
+        if rc:
+            raise CzkError(rc, (self._L.czk_net_last_error(self._h) or b"").decode())
+
+    def set_option(self, name: str, value: int):
+        self._ck(self._L.czk_net_set_option(self._h, name.encode(), C.c_long(int(value))))
+
+    def stats(self) -> dict:
+        out = (C.c_uint64 * 5)()
+        self._ck(self._L.czk_net_stats(self._h, out))
+        return dict(zip(self.STATS, [int(v) for v in out]))
+
+    def stats_reset(self):
+        self._L.czk_net_stats_reset(self._h)
+
+    def barrier(self):
+        self._ck(self._L.czk_net_barrier(self._h))
+
+    # ---- byte primitives: host numpy uint8 arrays (returned), or device pointers with `nbytes` given -------------------------
+    def broadcast(self, send, nbytes: int | None = None, recv=None, mem: int = CZK_MEM_HOST):
+        if mem == CZK_MEM_HOST:
+            send = np.ascontiguousarray(send).view(np.uint8).reshape(-1)
+            nbytes = send.size
+            recv = np.zeros((self.world, nbytes), dtype=np.uint8)
+        self._ck(self._L.czk_net_broadcast(self._h, _ptr(send if nbytes else None), C.c_size_t(nbytes), _ptr(recv if nbytes else None), C.c_int(mem)))
+        return recv
+
+    def send_to_king(self, send, nbytes: int | None = None, recv=None, mem: int = CZK_MEM_HOST):
+        if mem == CZK_MEM_HOST:
+            send = np.ascontiguousarray(send).view(np.uint8).reshape(-1)
+            nbytes = send.size
+            recv = np.zeros((self.world, nbytes), dtype=np.uint8) if self.rank == 0 else None
+        self._ck(self._L.czk_net_send_to_king(self._h, _ptr(send if nbytes else None), C.c_size_t(nbytes), _ptr(recv if nbytes else None), C.c_int(mem)))
+        return recv
+
+    def recv_from_king(self, send, nbytes: int | None = None, recv=None, mem: int = CZK_MEM_HOST):
+        """send: (world, nbytes) on the king, None elsewhere (host mode: nbytes must then be given)"""
+        if mem == CZK_MEM_HOST:
+            if send is not None:
+                send = np.ascontiguousarray(send).view(np.uint8).reshape(self.world, -1)
+                nbytes = send.shape[1]
+            recv = np.zeros(nbytes, dtype=np.uint8)
+        self._ck(self._L.czk_net_recv_from_king(self._h, _ptr(send if nbytes else None), C.c_size_t(nbytes), _ptr(recv if nbytes else None), C.c_int(mem)))
+        return recv
+
+    def atomic_broadcast(self, x_ptr, n: int, recv_ptr, rand32: bytes | None = None, mem: int = CZK_MEM_DEVICE):
+        r = (C.c_uint8 * 32).from_buffer_copy(rand32) if rand32 is not None else None
+        self._ck(self._L.czk_net_atomic_broadcast(self._h, _ptr(x_ptr), C.c_size_t(n), _ptr(recv_ptr), r, C.c_int(mem)))
+
+    # ---- the reference's batch opens on device lanes ---------------------------------------------------------------------------
+    def spdz_batch_open(self, sh_ptr, mac_ptr, mac_share, n: int, out_ptr, commit: bool = False) -> int:
+        """SpdzFieldShare::batch_open; returns the number of failed MAC checks (the reference asserts 0)"""
+        ms = np.ascontiguousarray(mac_share, np.uint64).reshape(4)
+        bad = C.c_uint64(0)
+        self._ck(self._L.czk_spdz_batch_open(self._h, _ptr(sh_ptr), _ptr(mac_ptr), _ptr(ms), C.c_size_t(n), _ptr(out_ptr),
+                                             C.c_int(CZK_OPEN_COMMIT if commit else 0), C.byref(bad)))
+        return bad.value
+
+    def add_batch_open(self, val_ptr, n: int, out_ptr):
+        self._ck(self._L.czk_add_batch_open(self._h, _ptr(val_ptr), C.c_size_t(n), _ptr(out_ptr)))
+
+    def gsz_batch_open(self, val_ptr, n: int, out_ptr, degree: int = 0, degrees_ptr=None) -> int:
+        bad = C.c_uint64(0)
+        self._ck(self._L.czk_gsz_batch_open(self._h, _ptr(val_ptr), C.c_size_t(n), _ptr(degrees_ptr), C.c_uint(degree), _ptr(out_ptr), C.byref(bad)))
+        return bad.value
+
+    def gsz_batch_king_compute(self, val_ptr, n: int, out_ptr, degree: int = 0, degrees_ptr=None) -> int:
+        bad = C.c_uint64(0)
+        self._ck(self._L.czk_gsz_batch_king_compute(self._h, _ptr(val_ptr), C.c_size_t(n), _ptr(degrees_ptr), C.c_uint(degree), _ptr(out_ptr), C.byref(bad)))
+        return bad.value
+
+    def fr_send_to_king(self, x_ptr, n: int, gathered_ptr):
+        self._ck(self._L.czk_fr_send_to_king(self._h, _ptr(x_ptr), C.c_size_t(n), _ptr(gathered_ptr)))
+
+    def fr_recv_from_king(self, parts_ptr, n: int, out_ptr):
+        self._ck(self._L.czk_fr_recv_from_king(self._h, _ptr(parts_ptr), C.c_size_t(n), _ptr(out_ptr)))
+
+    def close(self):
+        if self._h:
+            self._L.czk_net_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sha256(data: bytes, lab: bool = False) -> bytes:
+    """czk_sha256 (the library's CommitHash): for tests against hashlib"""
+    out = (C.c_uint8 * 32)()
+    buf = (C.c_uint8 * max(1, len(data))).from_buffer_copy(data or b"\0")
+    (lab_lib() if lab else lib()).czk_sha256(buf, C.c_size_t(len(data)), out)
+    return bytes(out)
 
 
 class Lanes:

@@ -25,7 +25,7 @@ LIB_LAB = os.path.join(HERE, "libczk_hip_lab.so")
 # multiply out of line (see field.h CZK_NOINLINE_MUL); the hot kernels keep it inlined.  core.hip is host code only (the host-side
 # group operations): out of line too, 14 s instead of 4.5 min of host compilation.
 SOURCES = [("core.hip", ["-DCZK_NOINLINE_MUL"]), ("lanes.hip", ["-DCZK_NOINLINE_MUL"]), ("ntt.hip", []), ("ntt_pass.hip", []), ("ntt_mixed.hip", []), ("msm.hip", ["-DCZK_NOINLINE_MUL"]), ("msm_acc_g1.hip", []),
-           ("msm_acc_g2.hip", []), ("msm_red_g2.hip", []), ("msm_heavy_g2.hip", []), ("poly.hip", []), ("share.hip", [])]
+           ("msm_acc_g2.hip", []), ("msm_red_g2.hip", []), ("msm_heavy_g2.hip", []), ("poly.hip", []), ("share.hip", []), ("net.hip", ["-DCZK_NOINLINE_MUL"])]
 HEADERS = ["field.h", "curve.h", "czk_internal.h", "msm_acc.h", "fq2p.h", "fq2pu.h", "fqu.h", "fru.h", "fru_constants.inc", "ntt_pass.h", "te.h", "te_constants.inc",
            os.path.join("..", "..", "include", "czk.h")]
 LAB_HEADERS = [os.path.join("lab", h) for h in ("msm_aff.h", "fq_safegcd.h", "fqu_il.h", "fqu_mad_il.inc", "fq2u_karatsuba.h")]

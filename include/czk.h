@@ -41,7 +41,9 @@ typedef enum {
     CZK_ERR_SIZE = 1,  /* domain too large (log2 D > TWO_ADICITY = 47: radix2/mod.rs:61-63) or len > D (:100) */
     CZK_ERR_HIP = 2,   /* HIP runtime failure (message via czk_last_error) */
     CZK_ERR_ARG = 3,   /* null / inconsistent argument */
-    CZK_ERR_NOMEM = 4
+    CZK_ERR_NOMEM = 4,
+    CZK_ERR_NET = 5,   /* czk_net_*: transport failure or a peer that did not arrive within the communicator's timeout (message via czk_net_last_error) */
+    CZK_ERR_CHECK = 6  /* czk_net_atomic_broadcast: a party's data does not match its commitment (the reference's assert_eq!, channel.rs:63-66) */
 } czk_status;
 
 typedef enum {
@@ -216,6 +218,95 @@ int czk_fr_spdz_dx(czk_ctx* ctx, const uint64_t* value, const uint64_t* mac, con
 int czk_share_domain_constants(czk_ctx* ctx, size_t parties, uint64_t* out12);
 int czk_fr_gsz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t n, const uint32_t* degrees, unsigned degree,
                     uint64_t* out_value, uint64_t* out_bad);
+
+/* ---- mpc-net between GPUs: the opens' transport, behind the C ABI -------------------------------- */
+/* The reference's parties talk through the process-global MpcMultiNet (mpc-net/src/multi.rs:15-23: one TCP connection per pair of
+ * parties) with four primitives -- broadcast (:145-173), send_to_king (:175-210), recv_from_king (:211-242) and, on top of them,
+ * MpcSerNet::atomic_broadcast (mpc-algebra/src/channel.rs:50-75).  A czk_net is the same thing for parties that are czk contexts:
+ * one communicator per (context, party), its exchanges enqueued on the context's stream (czk_ctx_stream), so a share vector that
+ * the context's kernels produce is exchanged, summed and checked WITHOUT leaving HBM and without a host synchronisation between
+ * the kernels and the exchange.  Two transports:
+ *   CZK_NET_RCCL  one party per GPU of one node: RCCL over xGMI (ncclCommInitRank).  id = the 128 bytes czk_net_unique_id returned on
+ *                 rank 0, carried to the other parties by whatever channel started them (the reference's host has mpc-net's TCP for it).
+ *                 librccl.so.1 is dlopen-ed on first use: the library has no link-time dependency on RCCL.
+ *   CZK_NET_SHM   parties are processes of one node in ANY assignment to GPUs -- several parties on ONE GPU included -- staged through a
+ *                 POSIX shared-memory segment named by the id bytes (pinned by every party: two DMA copies per buffer).  For rigs with
+ *                 fewer GPUs than parties and for tests; blocks the host for the duration of each exchange.  id: 1..32 arbitrary bytes
+ *                 the launcher chooses, the same on every rank.  ctx may be NULL: host-memory primitives only (no composite opens).
+ * czk_net_create is collective (returns once every rank has joined; CZK_ERR_NET after the timeout).  All ranks call the same
+ * sequence of exchanges, like the reference's lock-step rounds.  Buffers: `mem` = CZK_MEM_DEVICE (on the context's GPU, used in
+ * stream order) or CZK_MEM_HOST (read / written before the call returns).  Byte counts must be equal on all ranks (mpc-net asserts it).
+ * Options (czk_net_set_option): "exchange" 0 = ring (one ncclAllGather), 1 = p2p (world - 1 grouped ncclSend / ncclRecv pairs: every
+ * pair of GPUs of an MI355X node has its own xGMI link -- mpc-net's own star shape); "timeout_ms" (default 120000);
+ * "slot_bytes" (SHM: staging slot per rank, default 16 MiB; before the first exchange). */
+typedef struct czk_net czk_net;
+typedef enum { CZK_NET_RCCL = 1, CZK_NET_SHM = 2 } czk_net_transport;
+#define CZK_NET_UNIQUE_ID_BYTES 128
+int czk_net_unique_id(int transport, uint8_t* out, size_t cap, size_t* len);
+int czk_net_create(czk_ctx* ctx, int transport, int rank, int world, const uint8_t* id, size_t id_len, czk_net** out);
+void czk_net_destroy(czk_net* net);
+int czk_net_rank(const czk_net* net);    /* MpcNet::party_id */
+int czk_net_world(const czk_net* net);   /* MpcNet::n_parties */
+int czk_net_set_option(czk_net* net, const char* name, long value);
+const char* czk_net_last_error(const czk_net* net);
+/* mpc-net's Stats (mpc-net/src/lib.rs: bytes_sent, bytes_recv, broadcasts, to_king, from_king), counted by the reference's rules:
+ * out[0..5) in that order.  czk_net_stats_reset = MpcNet::reset_stats. */
+int czk_net_stats(const czk_net* net, uint64_t* out5);
+void czk_net_stats_reset(czk_net* net);
+/* broadcast (multi.rs:145-173): every party contributes `bytes` bytes; recv (world x bytes, party order) receives all of them. */
+int czk_net_broadcast(czk_net* net, const void* send, size_t bytes, void* recv, int mem);
+/* send_to_king (multi.rs:175-210): recv (world x bytes, party order) is written on the king (rank 0) only and may be NULL elsewhere. */
+int czk_net_send_to_king(czk_net* net, const void* send, size_t bytes, void* recv, int mem);
+/* recv_from_king (multi.rs:211-242): the king hands party p the p-th of `world` equally long buffers (send: world x bytes on the
+ * king, ignored elsewhere); recv (bytes) receives this party's.  The reference prefixes each message with its u64 length
+ * (multi.rs:219-228); here lengths are arguments and only the stats count the 8 bytes. */
+int czk_net_recv_from_king(czk_net* net, const void* send, size_t bytes, void* recv, int mem);
+int czk_net_barrier(czk_net* net);
+/* MpcSerNet::atomic_broadcast of one Vec<Fr> (channel.rs:50-75): round 1 broadcasts SHA-256(serialize(x) || 32 random bytes), round 2
+ * the vector and the randomness; every receiver re-hashes what the others sent (CZK_ERR_CHECK on a mismatch).  x: n Montgomery Fr
+ * (`mem`), recv: world x n Fr.  The commitment runs over the reference's wire bytes (czk_fr_vec_serialize), so equal data and
+ * randomness give the reference's hashes.  rand32: the 32 commitment bytes (tests), NULL = drawn from the OS.  Hashing is host
+ * work over a download of the vectors: the protocol's check, not hot-path arithmetic -- the opens below take it as an option. */
+int czk_net_atomic_broadcast(czk_net* net, const uint64_t* x, size_t n, uint64_t* recv, const uint8_t* rand32, int mem);
+
+/* The reference's batch opens as ONE call each on device lanes (all buffers CZK_MEM_DEVICE on the communicator's context; gathered
+ * shares live in the communicator's own scratch).  flags: CZK_OPEN_COMMIT = the second round goes through czk_net_atomic_broadcast.
+ *   czk_spdz_batch_open  SpdzFieldShare::batch_open (mpc-algebra/src/share/spdz.rs:166-185): broadcast of the sh lane, value = sum;
+ *                        dx_t = mac_share * value - mac; (atomic_)broadcast of dx_t; *out_bad = number of i whose dx_t do not sum to
+ *                        zero (the reference asserts 0).  sh, mac: n Fr each; mac_share: one Montgomery Fr, HOST (1 on the king, 0
+ *                        elsewhere with the reference's stand-in key, spdz.rs:30-37); MAC shares never leave the party.
+ *   czk_add_batch_open   AdditiveFieldShare::batch_open (share/add.rs:256-259): broadcast, sum.
+ *   czk_gsz_batch_open   GszFieldShare::batch_open (share/gsz20/mod.rs:286-300) -> open_degree_vec (:440-466): broadcast, per element
+ *                        the size-world inverse DFT, degree check, p(0); degrees / degree / out_bad as in czk_fr_gsz_open.
+ * out_value may alias the input share lane.  Each call ends with the read-back of its check count (the reference asserts right there). */
+#define CZK_OPEN_COMMIT 1
+int czk_spdz_batch_open(czk_net* net, const uint64_t* sh, const uint64_t* mac, const uint64_t* mac_share, size_t n, uint64_t* out_value,
+                        int flags, uint64_t* out_bad);
+int czk_add_batch_open(czk_net* net, const uint64_t* val, size_t n, uint64_t* out_value);
+int czk_gsz_batch_open(czk_net* net, const uint64_t* val, size_t n, const uint32_t* degrees, unsigned degree, uint64_t* out_value,
+                       uint64_t* out_bad);
+/* The king's side of king_compute (mpc-algebra/src/channel.rs:77-80; gsz20's degree reduction, share/gsz20/mod.rs:470-500): every
+ * party's n Fr to the king, who receives world x n (device, party order) -- czk_net_send_to_king on Fr lanes -- and the way back. */
+int czk_fr_send_to_king(czk_net* net, const uint64_t* x, size_t n, uint64_t* gathered);
+int czk_fr_recv_from_king(czk_net* net, const uint64_t* parts, size_t n, uint64_t* out);
+/* gsz20::batch_king_compute with f = the identity -- the only f the reference passes (share/gsz20/mod.rs:494-527, called at :547,
+ * :578, :805: "king just reduces the sharing degree" of a product share x * y + r2): every party's lane to the king, the king opens
+ * each element with the degree bound (czk_fr_gsz_open) and sends the opened VALUE back to every party as its new share (:478
+ * `vec![output; n]`, "TODO: randomize").  val: n Fr (device); out (n Fr, device; may alias val) = from_king; *out_bad is meaningful
+ * on the king (0 elsewhere). */
+int czk_gsz_batch_king_compute(czk_net* net, const uint64_t* val, size_t n, const uint32_t* degrees, unsigned degree, uint64_t* out,
+                               uint64_t* out_bad);
+
+/* `Vec<Fr>::serialize` / `deserialize` (algebra/serialize/src/lib.rs:220-229 with impl_prime_field_serializer, fields/macros.rs:
+ * 532-537): u64 little-endian length, then into_repr() of every element as 32 little-endian bytes.  For a host that still carries
+ * some vectors over the reference's own sockets.  serialize: a = n Montgomery Fr (`mem`), out = 8 + 32 n bytes, HOST.  deserialize:
+ * bytes / len as received; writes at most cap Fr (Montgomery) to out (`mem`), *n = the length prefix; CZK_ERR_ARG when the prefix
+ * does not match len (the reference's deserialize fails) or exceeds cap. */
+int czk_fr_vec_serialize(czk_ctx* ctx, const uint64_t* a, size_t n, int mem, uint8_t* out);
+int czk_fr_vec_deserialize(czk_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t* out, size_t cap, int mem, size_t* n);
+/* SHA-256 (FIPS 180-4) of `len` host bytes: the reference's CommitHash (channel.rs:92).  Exported so a host can reproduce / verify
+ * commitments; no context needed. */
+void czk_sha256(const void* data, size_t len, uint8_t* out32);
 
 /* ---- callers either side of the NTT: constraint evaluation and division by (X - z) ------------------ */
 /* R1CS matrix (one of ConstraintMatrices::{a, b, c}, Vec<Vec<(F, usize)>>) in CSR form, pinned on the GPU once per

@@ -17,6 +17,10 @@
 //   GroupShare::multi_scale_pub_group(bases, &[share]) (SPDZ)                SpdzGroupShare::multi_scale_pub_group
 //     (mpc-algebra/src/share/spdz.rs:440-446)
 //   R1CStoQAP::witness_map (mpc-snarks/src/groth/r1cs_to_qap.rs:47-113)      R1CStoQAP::witness_map(domain, a, b, c [, batch_product])
+//   MpcMultiNet::{party_id, n_parties, am_king, broadcast, send_to_king,      Net (czk_net: RCCL between GPUs, or shared memory between
+//     recv_from_king, stats} (mpc-net/src/multi.rs:145-242, lib.rs:30-76)      processes of one node), on DeviceLanes and on host bytes
+//   SpdzFieldShare / AdditiveFieldShare / GszFieldShare::batch_open           Net::spdz_batch_open / add_batch_open / gsz_batch_open
+//     (share/spdz.rs:166-185, add.rs:256-259, gsz20/mod.rs:286-300)
 //   Vec<T> that stays alive across the witness map and feeds the h MSM        DeviceLanes (czk_lanes: the vector lives in HBM; every
 //     (r1cs_to_qap.rs:66-110, groth/prover.rs:104)                            domain / MSM / pointwise call below has a DeviceLanes form)
 //
@@ -115,6 +119,103 @@ class DeviceLanes {
 
   public:
     size_t len;   // logical Vec length of every lane (<= capacity)
+};
+
+// mpc-net's MpcMultiNet for parties that are czk contexts (include/czk.h "mpc-net between GPUs"): the exchanges of an open run on the
+// context's stream, on lanes that stay in HBM.  One Net per (Context, party); destroy it before its Context.
+//   transport CZK_NET_RCCL: one party per GPU, id = Net::unique_id(CZK_NET_RCCL) of rank 0, handed to the other parties by the launcher
+//   transport CZK_NET_SHM : parties are processes of one node (several may share a GPU), id = any 1..32 bytes the launcher chose
+class Net {
+  public:
+    struct Stats { uint64_t bytes_sent, bytes_recv, broadcasts, to_king, from_king; };   // mpc-net/src/lib.rs Stats
+    Net(const Context& ctx, int transport, int rank, int world, const std::vector<uint8_t>& id) : ctx_(&ctx) {
+        ctx.check(czk_net_create(ctx.raw(), transport, rank, world, id.data(), id.size(), &n_));
+    }
+    ~Net() { czk_net_destroy(n_); }
+    Net(const Net&) = delete;
+    Net& operator=(const Net&) = delete;
+    static std::vector<uint8_t> unique_id(int transport) {
+        std::vector<uint8_t> id(CZK_NET_UNIQUE_ID_BYTES);
+        size_t len = 0;
+        int rc = czk_net_unique_id(transport, id.data(), id.size(), &len);
+        if (rc != CZK_OK) throw Panic(rc, "czk_net_unique_id failed (RCCL transport: librccl.so.1 could not be loaded)");
+        id.resize(len);
+        return id;
+    }
+    czk_net* raw() const { return n_; }
+    const Context& ctx() const { return *ctx_; }
+    void check(int rc) const {
+        if (rc != CZK_OK) throw Panic(rc, czk_net_last_error(n_));
+    }
+    size_t party_id() const { return (size_t)czk_net_rank(n_); }     // MpcNet::party_id
+    size_t n_parties() const { return (size_t)czk_net_world(n_); }   // MpcNet::n_parties
+    bool am_king() const { return party_id() == 0; }                  // MpcNet::am_king
+    void set_option(const char* name, long value) const { check(czk_net_set_option(n_, name, value)); }
+    Stats stats() const {
+        uint64_t s[5];
+        check(czk_net_stats(n_, s));
+        return Stats{s[0], s[1], s[2], s[3], s[4]};
+    }
+    void reset_stats() const { czk_net_stats_reset(n_); }
+    void barrier() const { check(czk_net_barrier(n_)); }
+    // MpcNet::broadcast_bytes / send_bytes_to_king / recv_bytes_from_king on host bytes (mpc-net/src/lib.rs:44-61)
+    std::vector<std::vector<uint8_t>> broadcast_bytes(const std::vector<uint8_t>& out) const {
+        std::vector<uint8_t> flat(out.size() * n_parties());
+        check(czk_net_broadcast(n_, out.data(), out.size(), flat.data(), CZK_MEM_HOST));
+        return split(flat, out.size());
+    }
+    std::optional<std::vector<std::vector<uint8_t>>> send_bytes_to_king(const std::vector<uint8_t>& out) const {
+        std::vector<uint8_t> flat(am_king() ? out.size() * n_parties() : 0);
+        check(czk_net_send_to_king(n_, out.data(), out.size(), am_king() ? flat.data() : nullptr, CZK_MEM_HOST));
+        if (!am_king()) return std::nullopt;
+        return split(flat, out.size());
+    }
+    std::vector<uint8_t> recv_bytes_from_king(const std::optional<std::vector<std::vector<uint8_t>>>& out, size_t m) const {
+        std::vector<uint8_t> flat, mine(m);
+        if (am_king()) {
+            if (!out || out->size() != n_parties()) throw Panic(CZK_ERR_ARG, "recv_bytes_from_king: the king passes one buffer per party");
+            for (const auto& b : *out) {
+                if (b.size() != m) throw Panic(CZK_ERR_ARG, "assertion failed: bytes_out[id].len() == m");   // multi.rs:224
+                flat.insert(flat.end(), b.begin(), b.end());
+            }
+        }
+        check(czk_net_recv_from_king(n_, am_king() ? flat.data() : nullptr, m, mine.data(), CZK_MEM_HOST));
+        return mine;
+    }
+    // The batch opens on lanes that live on the GPU.  Each opens `n` elements starting at element 0 of the given lanes and writes the
+    // opened (public) vector to `out`; a failed check panics like the reference's assert.
+    //   SpdzFieldShare::batch_open (share/spdz.rs:166-185): `shares` lane `sh_lane` = sh, lane `sh_lane + 1` = mac
+    void spdz_batch_open(const DeviceLanes& shares, size_t sh_lane, const Fr& mac_share, size_t n, uint64_t* out, bool commit = false) const {
+        uint64_t bad = 0;
+        check(czk_spdz_batch_open(n_, shares.data(sh_lane), shares.data(sh_lane + 1), mac_share.l, n, out, commit ? CZK_OPEN_COMMIT : 0, &bad));
+        if (bad) throw Panic(CZK_ERR_CHECK, "assertion failed: sum.is_zero() (SPDZ MAC check, share/spdz.rs:183) on " + std::to_string(bad) + " values");
+    }
+    //   AdditiveFieldShare::batch_open (share/add.rs:256-259)
+    void add_batch_open(const uint64_t* val, size_t n, uint64_t* out) const { check(czk_add_batch_open(n_, val, n, out)); }
+    //   GszFieldShare::batch_open (share/gsz20/mod.rs:286-300) with one degree bound for the whole vector
+    void gsz_batch_open(const uint64_t* val, size_t n, unsigned degree, uint64_t* out) const {
+        uint64_t bad = 0;
+        check(czk_gsz_batch_open(n_, val, n, nullptr, degree, out, &bad));
+        if (bad) throw Panic(CZK_ERR_CHECK, "assertion failed: p.degree() <= d (share/gsz20/mod.rs:452) on " + std::to_string(bad) + " values");
+    }
+    //   gsz20::batch_king_compute(shares, new_degree, |r| r) (share/gsz20/mod.rs:494-527): the degree reduction inside batch_mult
+    void gsz_batch_king_compute(const uint64_t* val, size_t n, unsigned degree, uint64_t* out) const {
+        uint64_t bad = 0;
+        check(czk_gsz_batch_king_compute(n_, val, n, nullptr, degree, out, &bad));
+        if (bad) throw Panic(CZK_ERR_CHECK, "assertion failed: p.degree() <= d (king, share/gsz20/mod.rs:452) on " + std::to_string(bad) + " values");
+    }
+
+  private:
+    static std::vector<std::vector<uint8_t>> split(const std::vector<uint8_t>& flat, size_t m) {
+        std::vector<std::vector<uint8_t>> r;
+        for (size_t p = 0; p * m < flat.size() || (m == 0 && p == 0); p++) {
+            r.emplace_back(flat.begin() + p * m, flat.begin() + (p + 1) * m);
+            if (m == 0) break;
+        }
+        return r;
+    }
+    const Context* ctx_;
+    czk_net* n_ = nullptr;
 };
 
 // mpc-algebra/src/wire/field.rs:27-30 -- MpcField<Fr, SpdzFieldShare<Fr>>: Public(x) or Shared{sh, mac}

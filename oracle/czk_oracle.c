@@ -674,6 +674,16 @@ int orc_max_threads(void) { return omp_get_max_threads(); }
 /* input generation for the CPU baseline: n distinct subgroup points (see ec_tmpl.h chain_points) */
 void orc_g1_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g1_chain_points((g1_aff_t *)out, n, (const g1_aff_t *)gen_aff); }
 void orc_g2_chain_points(const uint64_t *gen_aff, uint64_t *out, size_t n) { g2_chain_points((g2_aff_t *)out, n, (const g2_aff_t *)gen_aff); }
+/* FixedBaseMSM (algebra/ec/src/msm/fixed_base.rs): [k_i] * generator as affine points -- how the reference's generator derives a key's queries
+ * (groth16/src/generator.rs:118-163); the checker for czk_fixed_base_points at full size and the base arrays of tests/golden/make_fullsize.py */
+void orc_g1_fixed_base_msm(const uint64_t *gen_aff, const uint64_t *k, size_t n, uint64_t *out, uint8_t *out_inf, int threads) {
+    if (threads > 0) omp_set_num_threads(threads);
+    g1_fixed_base_msm((g1_aff_t *)out, out_inf, k, n, (const g1_aff_t *)gen_aff);
+}
+void orc_g2_fixed_base_msm(const uint64_t *gen_aff, const uint64_t *k, size_t n, uint64_t *out, uint8_t *out_inf, int threads) {
+    if (threads > 0) omp_set_num_threads(threads);
+    g2_fixed_base_msm((g2_aff_t *)out, out_inf, k, n, (const g2_aff_t *)gen_aff);
+}
 
 /* ------------------------------------------------------------------ MixedRadixEvaluationDomain<Fr> (size 2^a * 3^b, b <= 1)
  * algebra/poly/src/domain/mixed_radix.rs:232-262 -- mixed_radix_fft_permute */

@@ -270,3 +270,87 @@ static void EC(chain_points)(EC(aff_t) *out, size_t n, const EC(aff_t) *gen) {
     free(jac);
     free(pre);
 }
+
+/* algebra/ec/src/msm/fixed_base.rs:11-96 -- FixedBaseMSM::{get_window_table, windowed_mul, multi_scalar_mul}, the way the
+ * reference's generator builds a proving key's queries (groth16/src/generator.rs:118-163: scalar_size = Fr::size_in_bits() = 253,
+ * window = get_mul_window_size(n) = ln_without_floats(n), 3 below 32 scalars).  out[i] = [k_i] g as AFFINE points + infinity bytes
+ * (the generator's batch_normalization_into_affine, short_weierstrass_jacobian.rs:480-500).  k: n x 4 canonical limbs.  The scalars
+ * are processed by all OpenMP threads (the reference's `cfg_iter!(v)`); each point's additions run in the reference's order. */
+static void EC(fixed_base_msm)(EC(aff_t) *out, uint8_t *out_inf, const uint64_t *k, size_t n, const EC(aff_t) *g) {
+    const size_t scalar_size = 253;
+    size_t window = n < 32 ? 3 : (size_t)(orc_log2(n) * 69 / 100);      /* msm/mod.rs:10-13 ln_without_floats */
+    if (window == 0) window = 1;
+    const size_t in_window = (size_t)1 << window, outerc = (scalar_size + window - 1) / window;
+    const size_t last_in_window = (size_t)1 << (scalar_size - (outerc - 1) * window);
+    /* get_window_table (:20-58): multiples_of_g[outer][inner] = inner * 2^(window * outer) * g; entries beyond the last window's range stay zero */
+    EC(aff_t) *table = (EC(aff_t) *)malloc(outerc * in_window * sizeof(EC(aff_t)));
+    uint8_t *tinf = (uint8_t *)malloc(outerc * in_window);
+    EC(jac_t) g_outer;
+    g_outer.x = g->x; g_outer.y = g->y; BF(one)(&g_outer.z);
+    for (size_t outer = 0; outer < outerc; outer++) {
+        const size_t cur = outer == outerc - 1 ? last_in_window : in_window;
+        EC(jac_t) g_inner;
+        EC(jac_zero)(&g_inner);
+        for (size_t inner = 0; inner < in_window; inner++) {
+            EC(aff_t) *t = &table[outer * in_window + inner];
+            if (inner < cur) {
+                tinf[outer * in_window + inner] = (uint8_t)EC(jac_to_affine)(t, &g_inner);   /* batch_normalization_into_affine, element-wise here */
+                EC(jac_add)(&g_inner, &g_outer);
+            } else {
+                tinf[outer * in_window + inner] = 1;
+                BF(zero)(&t->x); BF(one)(&t->y);
+            }
+        }
+        for (size_t i = 0; i < window; i++) EC(jac_double)(&g_outer);
+    }
+    /* multi_scalar_mul (:82-95) -> windowed_mul (:60-80) per scalar, then normalisation in chunks with one inversion each */
+    enum { FB_CH = 1024 };
+#pragma omp parallel
+    {
+        EC(jac_t) *jac = (EC(jac_t) *)malloc(FB_CH * sizeof(EC(jac_t)));
+        BF_T *pre = (BF_T *)malloc(FB_CH * sizeof(BF_T));
+#pragma omp for schedule(dynamic, 1)
+        for (size_t start = 0; start < n; start += FB_CH) {
+            const size_t m = n - start < FB_CH ? n - start : FB_CH;
+            BF_T acc;
+            BF(one)(&acc);
+            for (size_t i = 0; i < m; i++) {
+                const uint64_t *s = k + 4 * (start + i);
+                EC(jac_t) res;
+                EC(jac_zero)(&res);                                     /* multiples_of_g[0][0].into_projective() = zero */
+                for (size_t outer = 0; outer < outerc; outer++) {
+                    size_t inner = 0;
+                    for (size_t b = 0; b < window; b++) {
+                        const size_t bit = outer * window + b;
+                        if (bit < 253 && ((s[bit / 64] >> (bit % 64)) & 1)) inner |= (size_t)1 << b;   /* bit < modulus_size (:72) */
+                    }
+                    EC(jac_add_mixed)(&res, &table[outer * in_window + inner], tinf[outer * in_window + inner]);
+                }
+                jac[i] = res;
+                pre[i] = acc;
+                if (!EC(jac_is_zero)(&res)) BF(mul)(&acc, &acc, &res.z);
+            }
+            BF_T inv;
+            BF(inv)(&inv, &acc);
+            for (size_t i = m; i-- > 0;) {
+                if (EC(jac_is_zero)(&jac[i])) {
+                    out_inf[start + i] = 1;
+                    BF(zero)(&out[start + i].x); BF(one)(&out[start + i].y);
+                    continue;
+                }
+                BF_T zi, zi2, zi3;
+                BF(mul)(&zi, &inv, &pre[i]);
+                BF(mul)(&inv, &inv, &jac[i].z);
+                BF(sqr)(&zi2, &zi);
+                BF(mul)(&zi3, &zi2, &zi);
+                BF(mul)(&out[start + i].x, &jac[i].x, &zi2);
+                BF(mul)(&out[start + i].y, &jac[i].y, &zi3);
+                out_inf[start + i] = 0;
+            }
+        }
+        free(jac);
+        free(pre);
+    }
+    free(table);
+    free(tinf);
+}

@@ -313,6 +313,19 @@ def chain_points(g, n):
     return out
 
 
+def fixed_base_points(g, k_canonical, threads=0):
+    """FixedBaseMSM::multi_scalar_mul over the group's generator (algebra/ec/src/msm/fixed_base.rs:11-96): (n, 12|24) affine Montgomery
+    limbs and (n,) infinity bytes of [k_i] G -- the reference generator's way of building a key's queries; all host threads."""
+    aff_w, _ = _grp(g)
+    k = _u64(k_canonical).reshape(-1, 4)
+    n = k.shape[0]
+    gen = _u64(generator_affine(g))
+    out = np.zeros((n, aff_w), dtype=np.uint64)
+    inf = np.zeros(n, dtype=np.uint8)
+    getattr(lib(), f"orc_g{g}_fixed_base_msm")(_p(gen), _p(k), C.c_size_t(n), _p(out), _p(inf), C.c_int(threads))
+    return out, inf
+
+
 def groth16_local_par(log_d, N, a, b, c, wit, asg, h_q, l_q, a_q, b1_q, b2_q, inf_b, threads=0):
     """One proof's local compute (witness map + 5 MSMs per share lane) with OpenMP tasks on `threads` host threads
     (0 = all).  a, b, c: (lanes, D, 4) and are overwritten; returns (lanes, 108) u64: h, l, a, b_g1 Jacobian (18 each), b_g2 (36)."""

@@ -4,7 +4,8 @@
 //   reference                                                                      here
 //   R1CStoQAP::witness_map            mpc-snarks/src/groth/r1cs_to_qap.rs:47-113   Groth16Host::step (czk::R1CStoQAP::witness_map on DeviceLanes)
 //   F::batch_product_in_place -> S::batch_mul (Beaver)   share/field.rs:97-127     Groth16Host::batch_product
-//   SpdzFieldShare::batch_open (all parties local)       share/spdz.rs:166-185     Groth16Host::open
+//   SpdzFieldShare::batch_open                           share/spdz.rs:166-185     Groth16Host::open: all parties' lanes on this GPU -> lane sums;
+//                                                                                  one party per process -> czk::Net::spdz_batch_open (czk_net)
 //   create_proof's five MSMs          mpc-snarks/src/groth/prover.rs:104-156       czk::multi_scalar_mul_async
 //
 // Inputs are host `std::vector`s, as the reference holds `Vec`s: the share lanes of the assignment go up ONCE
@@ -154,9 +155,20 @@ class Groth16Host {
     unsigned log_d = 0;
     double register_s = 0, setup_s = 0;
 
-    Groth16Host(const czk::Context& c, size_t n_constraints, size_t parties, uint64_t seed = 0xC0FFEE, bool no_tables = false)
-        : ctx(c), N(n_constraints), P(parties), L(2 * parties) {
+    // local_parties: the MPC parties whose share lanes live on this GPU (empty = all of them, BASELINE configs[1]).  With ONE local
+    // party and a czk::Net this is the reference's own layout -- one process per party (mpc-net/src/multi.rs:15-23) -- and the two opens
+    // of the witness map run SpdzFieldShare::batch_open's two broadcast rounds through the communicator, on lanes that stay in HBM.
+    Groth16Host(const czk::Context& c, size_t n_constraints, size_t parties, uint64_t seed = 0xC0FFEE, bool no_tables = false,
+                std::vector<size_t> local_parties = {}, const czk::Net* net = nullptr, bool commit_opens = false)
+        : ctx(c), N(n_constraints), P(parties), net_(net), commit_opens_(commit_opens) {
         auto t0 = std::chrono::steady_clock::now();
+        if (local_parties.empty())
+            for (size_t p = 0; p < P; p++) local_parties.push_back(p);
+        local_ = local_parties;
+        L = 2 * local_.size();
+        if (local_.size() < P && (local_.size() != 1 || !net_ || net_->n_parties() != P || net_->party_id() != local_[0]))
+            throw czk::Panic(CZK_ERR_ARG, "party layout: one local party per process, and a Net whose rank is that party");
+        mac_share_ = local_[0] == 0 ? hostfr::one() : Fr{{0, 0, 0, 0}};   // mac_share() = 1 on the king, 0 elsewhere (share/spdz.rs:30-37)
         while (((size_t)1 << log_d) < N + 2) log_d++;   // D = next_pow2(N + num_instance)  (r1cs_to_qap.rs:63-65)
         D = (size_t)1 << log_d;
         domain_.emplace(*czk::Radix2EvaluationDomain::create(ctx, N + 2));
@@ -191,16 +203,17 @@ class Groth16Host {
         asg_ = lanes(N + 1);    // a / b MSM scalars: [out, witness]
         {
             std::vector<Fr> f(N + 2), g(N + 1);
-            for (size_t j = 0; j < P; j++) {
+            for (size_t k = 0; k < local_.size(); k++) {
+                const size_t j = local_[k];
                 f[0] = j == 0 ? one : Fr{{0, 0, 0, 0}};
                 f[1] = sh[j][N];
                 std::copy(sh[j].begin(), sh[j].begin() + N, f.begin() + 2);
                 g[0] = sh[j][N];
                 std::copy(sh[j].begin(), sh[j].begin() + N, g.begin() + 1);
                 for (size_t m = 0; m < 2; m++) {     // the witness lanes go up once
-                    full_->upload(2 * j + m, f);
-                    wit_->upload(2 * j + m, 0, sh[j].data(), N);
-                    asg_->upload(2 * j + m, g);
+                    full_->upload(2 * k + m, f);
+                    wit_->upload(2 * k + m, 0, sh[j].data(), N);
+                    asg_->upload(2 * k + m, g);
                 }
             }
         }
@@ -222,7 +235,8 @@ class Groth16Host {
         // ---- dummy Beaver triples (wire/field.rs:41-60): king holds (1, 1, 1), everyone else (0, 0, 0) ----
         tx_ = lanes(D), ty_ = lanes(D), tz_ = lanes(D);
         for (auto* t : {tx_.get(), ty_.get(), tz_.get()})
-            for (size_t ln = 0; ln < 2; ln++) ctx.check(czk_fr_powers(ctx.raw(), one.l, nullptr, D, t->data(ln), CZK_MEM_DEVICE));
+            for (size_t ln = 0; ln < L; ln++)
+                if (king_lane(ln)) ctx.check(czk_fr_powers(ctx.raw(), one.l, nullptr, D, t->data(ln), CZK_MEM_DEVICE));
         a_ = lanes(D), b_ = lanes(D), c_ = lanes(D), ab_ = lanes(D);
         sx_.reset(new czk::DeviceLanes(ctx, 1, D));
         oy_.reset(new czk::DeviceLanes(ctx, 1, D));
@@ -253,7 +267,8 @@ class Groth16Host {
         return r;
     }
 
-    // number of non-zero entries of the two MAC-check vectors (share/spdz.rs:176-183: the reference asserts zero)
+    // number of non-zero entries of the two MAC-check vectors (share/spdz.rs:176-183: the reference asserts zero).  Party layout: the
+    // check is part of czk::Net::spdz_batch_open, which panics on a failure; the vectors stay zero.
     uint64_t mac_check_failures() const {
         uint64_t bad = 0;
         ctx.check(czk_fr_lanes_sum(ctx.raw(), chk_->data(), 1, 2 * D, nullptr, &bad));
@@ -262,7 +277,10 @@ class Groth16Host {
     const czk::DeviceLanes& h_lanes() const { return *ab_; }
     std::deque<ProofElements> results;   // deque: element addresses stay valid while the MSMs that write them are in flight
 
+    const std::vector<size_t>& local_parties() const { return local_; }
+
   private:
+    bool king_lane(size_t ln) const { return local_[ln / 2] == 0; }
     std::unique_ptr<czk::DeviceLanes> lanes(size_t len) { return std::unique_ptr<czk::DeviceLanes>(new czk::DeviceLanes(ctx, L, len)); }
 
     template <int GROUP>
@@ -282,6 +300,10 @@ class Groth16Host {
     // the mac lanes with mac_share = 1 on the king, 0 elsewhere (share/spdz.rs:31-37, 166-185)
     void open(const czk::DeviceLanes& shares, czk::DeviceLanes& out, uint64_t* chk) {
         const int M = CZK_MEM_DEVICE;
+        if (local_.size() < P) {   // one party per process: Net::broadcast(&s_vals), dx_t, Net::atomic_broadcast(&dx_ts), assert (spdz.rs:166-185)
+            net_->spdz_batch_open(shares, 0, mac_share_, D, out.data(), commit_opens_);
+            return;
+        }
         ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_ADD, shares.data(0), shares.data(2), out.data(), D, M));
         for (size_t p = 2; p < P; p++) ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_ADD, out.data(), shares.data(2 * p), out.data(), D, M));
         ctx.check(czk_fr_vec_op(ctx.raw(), CZK_OP_SUB, out.data(), shares.data(1), chk, D, M));
@@ -296,9 +318,13 @@ class Groth16Host {
         open(a, *sx_, chk_->data(0));
         open(b, *oy_, chk_->data(1));
         for (size_t ln = 0; ln < L; ln++)
-            ctx.check(czk_fr_beaver_combine(ctx.raw(), tx_->data(ln), ty_->data(ln), tz_->data(ln), sx_->data(), oy_->data(), ln < 2 ? 1 : 0, ab.data(ln), D, M));
+            ctx.check(czk_fr_beaver_combine(ctx.raw(), tx_->data(ln), ty_->data(ln), tz_->data(ln), sx_->data(), oy_->data(), king_lane(ln) ? 1 : 0, ab.data(ln), D, M));
     }
 
+    const czk::Net* net_ = nullptr;
+    bool commit_opens_ = false;
+    std::vector<size_t> local_;
+    Fr mac_share_{};
     std::optional<czk::Radix2EvaluationDomain> domain_;
     std::unique_ptr<czk::G1Bases> h_query_, l_query_, a_query_, b_g1_query_;
     std::unique_ptr<czk::G2Bases> b_g2_query_;

@@ -1,5 +1,8 @@
 // host_demo.cpp -- exercises include/czk.hpp (the C++ mirror of the reference's trait surface) end to end.
 // Build: g++ -std=c++17 -Iinclude tools/host_demo.cpp -Lcollaborative-zksnark_amd -lczk_hip -Wl,-rpath,$PWD/collaborative-zksnark_amd -o tools/host_demo.bin
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include <cstdio>
 #include <cstring>
 
@@ -44,6 +47,38 @@ static int dump_lift(const Context& ctx) {
         }
     }
     return 0;
+}
+
+static std::string hex(const uint8_t* p, size_t n) {
+    static const char* d = "0123456789abcdef";
+    std::string s;
+    for (size_t i = 0; i < n; i++) s += d[p[i] >> 4], s += d[p[i] & 15];
+    return s;
+}
+static std::vector<uint8_t> unhex(const char* h) {
+    std::vector<uint8_t> v;
+    auto nib = [](char c) { return (uint8_t)(c <= '9' ? c - '0' : (c | 32) - 'a' + 10); };
+    for (size_t i = 0; h[i] && h[i + 1]; i += 2) v.push_back((uint8_t)(nib(h[i]) << 4 | nib(h[i + 1])));
+    return v;
+}
+// The affine group elements of one proof on this process's lanes as bench.py's `results_sha256` orders them: per query (h, l, a, b_g1,
+// b_g2) the lanes in order, each as its affine limbs followed by the infinity byte.  Returns the five per-query byte strings.
+static std::vector<std::vector<uint8_t>> proof_bytes(const Context& ctx, const g16::ProofElements& r, size_t L) {
+    std::vector<std::vector<uint8_t>> out(5);
+    const G1Projective* g1[4] = {r.h.data(), r.l.data(), r.a.data(), r.b_g1.data()};
+    for (int q = 0; q < 5; q++) {
+        const size_t aw = q < 4 ? 12 : 24;
+        std::vector<uint64_t> aff(L * aw);
+        std::vector<uint8_t> inf(L);
+        if (q < 4) ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, g1[q]->x.l, L, aff.data(), inf.data()));
+        else ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G2, r.b_g2.data()->x.c0.l, L, aff.data(), inf.data()));
+        for (size_t ln = 0; ln < L; ln++) {
+            const uint8_t* b = (const uint8_t*)&aff[ln * aw];
+            out[q].insert(out[q].end(), b, b + 8 * aw);
+            out[q].push_back(inf[ln]);
+        }
+    }
+    return out;
 }
 
 // `host_demo.bin bench [--log-n K | --constraints N] [--parties P] [--steps K] [--warmup W] [--no-tables] [--dump FILE]`:
@@ -103,6 +138,12 @@ static int bench(const Context& ctx, int argc, char** argv) {
     }
     const uint64_t bad = prover.mac_check_failures();
     REQUIRE(bad == 0);
+    uint8_t digest[32];
+    {
+        std::vector<uint8_t> all;
+        for (const auto& q : proof_bytes(ctx, prover.results[0], L)) all.insert(all.end(), q.begin(), q.end());
+        czk_sha256(all.data(), all.size(), digest);
+    }
     if (dump) {
         FILE* f = fopen(dump, "wb");
         REQUIRE(f != nullptr);
@@ -123,10 +164,117 @@ static int bench(const Context& ctx, int argc, char** argv) {
     printf("{\"harness\": \"tools/host_demo.cpp bench (C++ over include/czk.hpp; no torch, no Python)\", \"constraints\": %zu, \"parties\": %zu, "
            "\"share_lanes\": %zu, \"steps\": %zu, \"warmup\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, \"latency_ms_single_proof\": %.3f, "
            "\"first_proof_ms\": %.3f, \"register_key_s\": %.4f, \"setup_s\": %.3f, \"window_tables\": %s, \"pipelined_proofs_equal\": true, "
-           "\"mac_check_failures\": %llu}\n",
+           "\"mac_check_failures\": %llu, \"results_sha256\": \"%s\"}\n",
            prover.N, prover.P, L, steps, warmup, dt / steps * 1e3, steps / dt, latency_ms, first_ms, prover.register_s, prover.setup_s,
-           no_tables ? "false" : "true", (unsigned long long)bad);
+           no_tables ? "false" : "true", (unsigned long long)bad, hex(digest, 32).c_str());
     return 0;
+}
+
+// `host_demo.bin party --rank R --world W --id HEX [--transport shm|rccl] [--device D] [--log-n K | --constraints N] [--steps K]
+// [--warmup W] [--no-tables] [--commit-opens] [--exchange ring|p2p]`: ONE MPC party of the reference's own layout -- one process per
+// party (mpc-net/src/multi.rs:15-23) -- as a compiled host: party R's two share lanes on this process's GPU, the two opens of every
+// witness map as SpdzFieldShare::batch_open through czk::Net (RCCL between GPUs; shared memory when the parties share a GPU), nothing
+// leaves HBM except the proof's group elements.  Rank 0 prints one JSON line whose results_sha256 covers ALL parties' elements in
+// bench.py's order (the other ranks' bytes reach it with send_bytes_to_king), so it equals the one-GPU layout's digest.
+// `host_demo.bin party-launch --world W [...]` forks + execs the W ranks with a fresh id.
+static int party(int argc, char** argv) {
+    size_t n = (size_t)1 << 20, steps = 4, warmup = 1;
+    int rank = -1, world = 0, device = -1, transport = CZK_NET_SHM, exchange = 0;
+    bool no_tables = false, commit = false;
+    std::vector<uint8_t> id;
+    for (int i = 2; i < argc; i++) {
+        auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
+        if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
+        else if (!strcmp(argv[i], "--constraints")) n = (size_t)atoll(val());
+        else if (!strcmp(argv[i], "--steps")) steps = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--warmup")) warmup = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--rank")) rank = atoi(val());
+        else if (!strcmp(argv[i], "--world")) world = atoi(val());
+        else if (!strcmp(argv[i], "--device")) device = atoi(val());
+        else if (!strcmp(argv[i], "--id")) id = unhex(val());
+        else if (!strcmp(argv[i], "--transport")) transport = !strcmp(val(), "rccl") ? CZK_NET_RCCL : CZK_NET_SHM;
+        else if (!strcmp(argv[i], "--exchange")) exchange = !strcmp(val(), "p2p") ? 1 : 0;
+        else if (!strcmp(argv[i], "--no-tables")) no_tables = true;
+        else if (!strcmp(argv[i], "--commit-opens")) commit = true;
+        else { printf("unknown argument %s\n", argv[i]); return 2; }
+    }
+    if (rank < 0 || world < 2 || rank >= world || id.empty() || n < 2 || steps < 1) { printf("party: need --rank, --world >= 2, --id\n"); return 2; }
+    if (device < 0) device = transport == CZK_NET_RCCL ? rank : 0;
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    Context ctx(device);
+    Net net(ctx, transport, rank, world, id);
+    net.set_option("exchange", exchange);
+    g16::Groth16Host prover(ctx, n, (size_t)world, 0xC0FFEE, no_tables, {(size_t)rank}, &net, commit);
+    for (size_t i = 0; i < warmup; i++) prover.step();
+    prover.results.clear();
+    net.reset_stats();
+    net.barrier();
+    auto t0 = clk::now();
+    for (size_t i = 0; i < steps; i++) prover.step(false);
+    ctx.sync();
+    net.barrier();
+    const double dt = secs(t0, clk::now());
+    const Net::Stats st = net.stats();
+    const size_t L = prover.L;
+    auto mine = proof_bytes(ctx, prover.results[0], L);
+    for (size_t k = 1; k < steps; k++) REQUIRE(proof_bytes(ctx, prover.results[k], L) == mine);   // equal inputs, equal proofs
+    std::vector<uint8_t> flat;
+    for (const auto& q : mine) flat.insert(flat.end(), q.begin(), q.end());
+    auto all = net.send_bytes_to_king(flat);
+    if (rank != 0) return 0;
+    std::vector<uint8_t> ordered;            // per query, the parties in order (bench.py's order)
+    size_t off = 0;
+    for (int q = 0; q < 5; q++) {
+        const size_t len = mine[q].size();
+        for (int p = 0; p < world; p++) ordered.insert(ordered.end(), (*all)[p].begin() + off, (*all)[p].begin() + off + len);
+        off += len;
+    }
+    uint8_t digest[32];
+    czk_sha256(ordered.data(), ordered.size(), digest);
+    printf("{\"harness\": \"tools/host_demo.cpp party (C++ over include/czk.hpp: one process per MPC party, opens through czk_net)\", \"layout\": \"party\", "
+           "\"transport\": \"%s\", \"exchange\": \"%s\", \"constraints\": %zu, \"parties\": %d, \"share_lanes_per_process\": %zu, \"steps\": %zu, "
+           "\"warmup\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, \"window_tables\": %s, \"commit_opens\": %s, \"pipelined_proofs_equal\": true, "
+           "\"king_net_stats\": {\"bytes_sent\": %llu, \"bytes_recv\": %llu, \"broadcasts\": %llu, \"to_king\": %llu, \"from_king\": %llu}, "
+           "\"results_sha256\": \"%s\"}\n",
+           transport == CZK_NET_RCCL ? "rccl" : "shm", exchange ? "p2p" : "ring", prover.N, world, L, steps, warmup, dt / steps * 1e3, steps / dt,
+           no_tables ? "false" : "true", commit ? "true" : "false", (unsigned long long)st.bytes_sent, (unsigned long long)st.bytes_recv,
+           (unsigned long long)st.broadcasts, (unsigned long long)st.to_king, (unsigned long long)st.from_king, hex(digest, 32).c_str());
+    return 0;
+}
+
+static int party_launch(int argc, char** argv) {
+    int world = 0, transport = CZK_NET_SHM;
+    for (int i = 2; i + 1 < argc; i++) {
+        if (!strcmp(argv[i], "--world")) world = atoi(argv[i + 1]);
+        if (!strcmp(argv[i], "--transport") && !strcmp(argv[i + 1], "rccl")) transport = CZK_NET_RCCL;
+    }
+    if (world < 2) { printf("party-launch: need --world >= 2\n"); return 2; }
+    const std::string id = [&] {
+        std::vector<uint8_t> b = Net::unique_id(transport);   // RCCL: ncclGetUniqueId here, before any child exists; no GPU work in this process
+        return hex(b.data(), b.size());
+    }();
+    std::vector<pid_t> kids;
+    for (int r = 0; r < world; r++) {
+        const pid_t pid = fork();
+        if (pid == 0) {
+            std::vector<std::string> a = {argv[0], "party", "--rank", std::to_string(r), "--id", id};
+            for (int i = 2; i < argc; i++) a.push_back(argv[i]);
+            std::vector<char*> av;
+            for (auto& x : a) av.push_back(&x[0]);
+            av.push_back(nullptr);
+            execv(argv[0], av.data());
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t k : kids) {
+        int st = 0;
+        waitpid(k, &st, 0);
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+    }
+    return rc;
 }
 
 // `host_demo.bin inputs SEED N` (no GPU needed): the harness's own input generation -- SplitMix64 stream -> canonical values,
@@ -149,6 +297,15 @@ static int dump_inputs(int argc, char** argv) {
 
 int main(int argc, char** argv) {
     if (argc > 1 && strcmp(argv[1], "inputs") == 0) return dump_inputs(argc, argv);
+    if (argc > 1 && strcmp(argv[1], "party-launch") == 0) return party_launch(argc, argv);
+    if (argc > 1 && strcmp(argv[1], "party") == 0) {
+        try {
+            return party(argc, argv);
+        } catch (const Panic& p) {
+            printf("FAILED: czk::Panic %d: %s\n", p.code, p.what());
+            return 1;
+        }
+    }
     Context ctx(0);
     if (argc > 1 && strcmp(argv[1], "dump-lift") == 0) return dump_lift(ctx);
     if (argc > 1 && strcmp(argv[1], "bench") == 0) {
