@@ -154,6 +154,109 @@ def relaunch_under_torchrun(n: int, argv: list[str]) -> int:
     return subprocess.call(cmd, env=dict(os.environ, CZK_BENCH_CHILD="1"))
 
 
+def per_rank_report(parallel, dt_local: float, steps: int, device) -> list:
+    """[{rank, ms_per_step, sclk_mhz_by_card}] of every rank (before the max over ranks): shows a straggler GPU or a clock that power management
+    holds lower on one device.  The clocks are a single sample right after the timed region (None when sysfs does not expose them)."""
+    import torch
+    rank, world, _ = parallel.env_rank_world()
+    clk = None
+    try:
+        # current shader clock of every card, from sysfs (the line marked `*` of pp_dpm_sclk): a file read -- the SMI libraries behind
+        # torch.cuda.clock_rate take tens of seconds to initialise in a fresh process
+        import glob
+        clk = []
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            cur = [ln for ln in open(f).read().splitlines() if ln.rstrip().endswith("*")]
+            clk.append(int(cur[0].split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", "")) if cur else None)
+    except Exception:      # noqa: BLE001 -- reporting only
+        clk = None
+    mine = {"rank": rank, "ms_per_step": dt_local / max(1, steps) * 1e3, "sclk_mhz_by_card": clk}
+    if world == 1 or not torch.distributed.is_initialized():
+        return [mine]
+    got = [None] * world
+    torch.distributed.all_gather_object(got, mine)
+    return got
+
+
+# What `bench.py --gpus N` adds to its JSON line when it runs on N > 1 GPUs (the driver's SCALE run): after the replica line, rank 0 runs
+# these as short children over the same N GPUs.  Every entry is one open question of DESIGN.md section 6; see multi_gpu_report.
+_EXCH = (("ring", "torch"), ("p2p", "torch"), ("ring", "czk"), ("p2p", "czk"))
+
+
+def multi_gpu_plan(n: int) -> list:
+    """[(key, argv of a bench.py child, reference key or None)]: the party layout of the BASELINE config whose party count is n under both
+    exchange patterns and both transports, its one-GPU layout as the digest reference, and the split layout of the headline."""
+    g16_20 = ["--workload", "groth16", "--log-n", "20", "--steps", "4", "--warmup", "1", "--no-seam-report"]
+    cfgs = {
+        2: [("marlin_spdz2_2e20", ["--workload", "marlin", "--parties", "2", "--log-n", "20", "--steps", "4", "--warmup", "2"]),       # configs[3]
+            ("groth16_spdz2_2e20", g16_20 + ["--parties", "2"])],
+        3: [("plonk_gsz3_2e18", ["--workload", "plonk", "--parties", "3", "--log-n", "18", "--steps", "4", "--warmup", "2"]),            # configs[2]
+            ("groth16_spdz3_2e20", g16_20 + ["--parties", "3"])],
+        4: [("groth16_spdz4_2e20", g16_20 + ["--parties", "4"])],
+        8: [("groth16_spdz8_2e22", ["--workload", "groth16", "--parties", "8", "--log-n", "22", "--steps", "3", "--warmup", "1", "--no-seam-report"]),   # configs[4]
+            ("groth16_spdz8_2e22_no_tables", ["--workload", "groth16", "--parties", "8", "--log-n", "22", "--steps", "3", "--warmup", "1", "--no-seam-report",
+                                              "--no-tables"])],
+    }.get(n, [(f"groth16_spdz{n}_2e20", g16_20 + ["--parties", str(n)])])
+    plan = []
+    for key, argv in cfgs:
+        one_gpu = argv + (["--no-tables"] if "--log-n" in argv and argv[argv.index("--log-n") + 1] == "22" and "--no-tables" not in argv else [])
+        ref = key + "/one_gpu"
+        plan.append((ref, ["--gpus", "1", "--inflight", "1"] + one_gpu, None))           # all parties' lanes on ONE GPU: the digest every party layout must reproduce
+        for exch, net in (_EXCH if not key.endswith("_no_tables") else _EXCH[:1] + _EXCH[2:3]):
+            plan.append((f"{key}/party/{net}/{exch}", ["--gpus", str(n), "--layout", "party", "--exchange", exch, "--net", net] + argv, ref))
+    plan.append(("groth16_spdz2_2e20/split", ["--gpus", str(n), "--layout", "split", "--parties", "2"] + g16_20, "headline"))
+    return plan
+
+
+def multi_gpu_report(n: int, headline: dict, dry_run: bool, budget_s: float) -> dict:
+    """Runs multi_gpu_plan(n) as children (rank 0 only; the other ranks of the replica run have exited and freed their GPUs) and reduces
+    each child's JSON line to the fields that answer DESIGN.md section 6's open questions:
+      value / ms_per_step / latency_ms_single_proof   ring vs p2p, torch.distributed vs czk_net, with vs without tables, split latency vs one GPU
+      backend / net / ranks_seen_by_backend              that the RCCL branch really ran with n ranks
+      per_rank                                           a straggler GPU, per-device clocks
+      digest_equals_reference                            the layout reproduces the one-GPU layout's proof elements"""
+    scrub = ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+             "MASTER_ADDR", "MASTER_PORT", "GPU_MAX_HW_QUEUES", "OMP_NUM_THREADS", "CZK_BENCH_CHILD")
+    env = {k: v for k, v in os.environ.items() if k not in scrub and not k.startswith(("TORCHELASTIC_", "TORCH_NCCL_ASYNC"))}
+    env["CZK_BENCH_REPORT_CHILD"] = "1"
+    out, digests, t_start = {}, {"headline": (headline or {}).get("config", {}).get("results_sha256")}, time.time()
+    exercised = set()
+    for key, argv, ref in multi_gpu_plan(n):
+        kind = key.split("/")[1]                     # one_gpu / party / split
+        if dry_run and kind in exercised:            # CPU test of the report's shape: one launch per kind of child, the rest as planned commands
+            out[key] = {"dry_run": "planned", "reference": ref, "command": "python bench.py " + " ".join(argv)}
+            continue
+        exercised.add(kind)
+        left = budget_s - (time.time() - t_start)
+        if left < 30:
+            out[key] = {"skipped": f"report budget of {budget_s:.0f} s used up"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-workloads", "--no-multi-gpu-report"] + argv + (["--dry-run"] if dry_run else [])
+        t0 = time.time()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(600.0, left), env=env)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[key] = {"error": (r.stdout + r.stderr)[-400:], "command": "python bench.py " + " ".join(argv)}
+                continue
+            j = json.loads(line[-1])
+            if dry_run:
+                out[key] = {"dry_run": True, "n_gpus": j.get("n_gpus"), "ranks_seen_by_backend": j.get("ranks_seen_by_backend"), "layout": j.get("layout"),
+                            "reference": ref, "command": "python bench.py " + " ".join(argv)}
+                continue
+            dg = j.get("config", {}).get("results_sha256")
+            digests[key] = dg
+            out[key] = {"proofs_per_s": j["value"], "ms_per_proof": j["ms_per_step"], "latency_ms_single_proof": j.get("latency_ms_single_proof"),
+                        "n_gpus": j["n_gpus"], "ranks_seen_by_backend": j.get("ranks_seen_by_backend"), "backend": j.get("backend"), "net": j.get("net"),
+                        "layout": j["config"].get("layout"), "exchange": argv[argv.index("--exchange") + 1] if "--exchange" in argv else None,
+                        "per_rank": j.get("per_rank"), "results_checked": bool(j.get("results_checked")), "results_sha256": dg,
+                        "reference": ref, "digest_equals_reference": (dg == digests.get(ref)) if ref and digests.get(ref) else None,
+                        "wall_s": time.time() - t0, "command": "python bench.py " + " ".join(argv)}
+        except Exception as e:      # noqa: BLE001 -- the report must not take the replica line down with it
+            out[key] = {"error": repr(e)[-400:], "command": "python bench.py " + " ".join(argv)}
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # host-side result check: pure-Python big-integer group arithmetic (no library, no checker code involved)
 # ---------------------------------------------------------------------------------------------------------------
@@ -539,6 +642,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     out = outs[0]
     for c, _, _, _ in provers:
         c.profile_enable(False)
+    per_rank = per_rank_report(parallel, dt, args.steps, dev_index)
     dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
     checked = {"results_checked": False} if args.no_result_check else verify_openings(czk, ctx, B, out)
     for o in outs[1:]:                                  # the other in-flight provers run the same deterministic inputs
@@ -570,7 +674,8 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     res = {
         "metric": f"collaborative {'Plonk' if plonk else 'Marlin'} proofs/sec (BLS12-377, {size_txt} constraints, {scheme} N={args.parties})",
         "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "ranks_seen_by_backend": world, "backend": args.backend if world > 1 else None,
-        "steps": args.steps, "warmup": args.warmup,
+        "net": (("czk_net " + ("rccl" if args.backend == "nccl" else "shm")) if parallel.get_net() is not None else "torch.distributed") if party else None,
+        "steps": args.steps, "warmup": args.warmup, "per_rank": per_rank,
         "ms_per_step": dt / args.steps * 1e3, "first_proof_ms": first_ms, "higher_is_better": True, "scaling": "strong" if party else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic", **checked,
         "config": {"workload": f"{what}; {where}; synthetic circuit / index and SRS, fixed Fiat-Shamir challenges, commitments / evaluations settled at "
@@ -589,8 +694,12 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     }
     if rank == 0:
         print(json.dumps(res))
+    if parallel.get_net() is not None:
+        parallel.get_net().close()      # before its context goes away
+        parallel.use_net(None)
     if world > 1:
         torch.distributed.destroy_process_group()
+
 
 def mac_shortcut_report(czk, device, tstream, n_constraints, args, value, check_results) -> dict:
     """The reference's SPDZ multi_scale_pub_group reads `s.sh.val` for BOTH of its MSMs (mpc-algebra/src/share/spdz.rs:441-442), so
@@ -681,13 +790,21 @@ def main():
     ap.add_argument("--inflight", type=int, default=None, help="plonk / marlin, replica layout: independent proofs in flight per GPU, each on its own context "
                                                                  "(default 4 with 24 hardware queues: the transcript points of one proof drain the MSM pipeline, the other proofs fill "
                                                                  "the bubbles -- round 4: plonk 172 / 151 / 137 ms per proof with 1 / 2 / 4 in flight, marlin 226 / 198 / 184)")
-    ap.add_argument("--scheme", choices=("spdz", "hbc"), default="spdz", help="groth16: spdz (default; sh + mac lane per party) or hbc (the reference's honest-but-curious "
-                                                                               "additive sharing: one lane per party, mpc-snarks/src/proof.rs:379-387)")
+    ap.add_argument("--scheme", choices=("spdz", "hbc", "gsz"), default="spdz", help="groth16: spdz (default; sh + mac lane per party), hbc (the reference's honest-but-curious "
+                                                                                      "additive sharing: one lane per party) or gsz (honest-majority Shamir sharing: one lane per party, "
+                                                                                      "products through the king's degree-reduction open) -- mpc-snarks/src/proof.rs:379-387")
     ap.add_argument("--exchange", choices=("ring", "p2p"), default="ring", help="party layout over RCCL: the opens' share exchange as one ring all-gather or as "
                                                                                  "world - 1 grouped point-to-point copies (parallel.set_exchange)")
+    ap.add_argument("--net", choices=("torch", "czk"), default="torch", help="party layout: the opens' transport.  torch: torch.distributed collectives issued from "
+                                                                               "Python (RCCL through torch, or gloo through the host); czk: the library's own communicator "
+                                                                               "(czk_net_*, include/czk.h -- what a compiled host calls): RCCL inside the library when --backend nccl, "
+                                                                               "shared memory between the ranks' processes otherwise; torch.distributed then only carries the "
+                                                                               "communicator id and the timing reduction")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE", help="czk_ctx_set_option on every context before any key is registered "
                                                                                              "(e.g. msm_window_g1=18); repeatable")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
+    ap.add_argument("--no-multi-gpu-report", action="store_true", help="--gpus N > 1, replica layout: skip the party / split layout children rank 0 runs after the replica line")
+    ap.add_argument("--report-budget-s", type=float, default=540.0, help="wall-clock budget of the multi-GPU report; children that would start beyond it are skipped")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
 
@@ -706,15 +823,20 @@ def main():
     from czk_amd import parallel
     from czk_amd.provers import Groth16Local
     rank, world, local_rank = parallel.env_rank_world()
+    # the driver's SCALE run (`--gpus N`, replica layout, default workload): rank 0 follows the replica line with the party / split layout children
+    want_report = (world > 1 and args.layout == "replica" and args.workload == "groth16" and not args.no_multi_gpu_report
+                   and not os.environ.get("CZK_BENCH_REPORT_CHILD"))
     if args.dry_run:
         parallel.init("gloo")
         seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         dt = parallel.max_over_ranks(0.001 * (rank + 1))
-        if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen_by_backend": seen, "backend": "gloo", "max_over_ranks_s": dt,
-                              "layout": args.layout}))
         if world > 1:
             torch.distributed.destroy_process_group()
+        if rank == 0:
+            line = {"dry_run": True, "n_gpus": world, "ranks_seen_by_backend": seen, "backend": "gloo", "max_over_ranks_s": dt, "layout": args.layout}
+            if want_report:          # the shape of the report the first multi-GPU lease will fill in (tests/test_distributed_cpu.py)
+                line["multi_gpu_report"] = multi_gpu_report(world, None, True, args.report_budget_s)
+            print(json.dumps(line))
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -735,9 +857,11 @@ def main():
     args.ctx_options = ctx_options
     ctx = czk.Context(device, tstream.cuda_stream, options=ctx_options)
     assert tstream.cuda_stream != 0
+    parallel.set_exchange(args.exchange)
+    if args.net == "czk" and args.layout == "party" and world > 1:
+        parallel.use_net(parallel.make_net(ctx, "rccl" if args.backend == "nccl" else "shm", device=torch.device("cuda", device) if args.backend == "nccl" else None))
     if args.workload != "groth16":
         return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)
-    parallel.set_exchange(args.exchange)
     if party_layout:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables, scheme=args.scheme)
         prover.commit_opens = args.commit_opens
@@ -773,6 +897,7 @@ def main():
     dt = time.perf_counter() - t0
     ctx.profile_enable(False)
     assert len(prover.all_results) == args.steps and all(r["h"].any() and r["b_g2"].any() for r in prover.all_results)
+    per_rank = per_rank_report(parallel, dt, args.steps, device)
     dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
     proofs = args.steps if (party_layout or split_layout) else world * args.steps      # party / split layout: all ranks work on the same proof
     if split_layout:
@@ -868,9 +993,11 @@ def main():
         "n_gpus": world,
         "ranks_seen_by_backend": ranks_seen,
         "backend": args.backend if world > 1 else None,
+        "net": (("czk_net " + ("rccl" if args.backend == "nccl" else "shm")) if parallel.get_net() is not None else "torch.distributed") if party_layout else None,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
+        "per_rank": per_rank,
         "latency_ms_single_proof": latency_ms,
         # the reference's own metric is one proof's wall time (mpc-snarks/src/proof.rs:130-135): the un-pipelined rate
         "proofs_per_s_unpipelined": 1000.0 / latency_ms,
@@ -890,7 +1017,10 @@ def main():
         **checked,
         "config": {"workload": f"Groth16 {args.scheme.upper()} {args.parties} parties, BLS12-377, {size_txt} constraints (squaring circuit), "
                                + ("both parties' share-local NTT+MSM on one GPU" if not party_layout else "one party per GPU") +
-                               ": " + prover.describe(),
+                               ": " + prover.describe()
+                               + ("; `value` counts ONE MSM PER SHARE LANE -- twice the MSM work of the reference's SPDZ path, whose mac-lane MSM repeats its "
+                                  "sh-lane MSM on the same scalars (mpc-algebra/src/share/spdz.rs:441-442); the reference-shaped figure (one MSM per party, "
+                                  "result used twice) is reported separately as `spdz_mac_msm_from_sh`" if args.scheme == "spdz" else ""),
                    "constraints": n_constraints, "domain": prover.D, "parties": args.parties, "share_lanes": prover.lanes,
                    "parallelism": (f"ONE proof over {world} GPUs, all share lanes on every rank: the witness map runs in full on each (9 % of a proof, no "
                                    "exchange), every MSM is split by base range (1 / N of the window tables and of the accumulation per GPU), the partial "
@@ -963,10 +1093,25 @@ def main():
         out["other_workloads"] = other_workloads_report(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_log_n, (n_constraints - 1).bit_length(), args.parties)
-    if rank == 0:
-        print(json.dumps(out))
+    if parallel.get_net() is not None:
+        parallel.get_net().close()      # before its context goes away
+        parallel.use_net(None)
+    if want_report:
+        # every rank gives its GPU back (key, tables, workspaces) and leaves the process group; rank 0 alone goes on to run the other
+        # layouts as children over the same N GPUs and folds their lines into the one JSON line it prints
+        try:
+            del prover
+        except NameError:
+            pass
+        ctx.close()
+        torch.cuda.empty_cache()
+        barrier()
     if world > 1:
         torch.distributed.destroy_process_group()
+    if want_report and rank == 0:
+        out["multi_gpu_report"] = multi_gpu_report(world, out, False, args.report_budget_s)
+    if rank == 0:
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -16,6 +16,7 @@ CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT = 0, 1, 2, 3
 CZK_MEM_HOST, CZK_MEM_DEVICE = 0, 1
 CZK_MEM_NO_TABLES = 32   # czk_bases_register: OR-ed with the above, see include/czk.h
 CZK_MEM_ANY_POINTS = 64  # czk_bases_register: bases need not lie in the prime-order subgroup (keeps the XYZZ kernels for G1)
+CZK_MEM_SCALAR_HOST = 256    # czk_fr_vec_scale: device vectors, host scalar
 CZK_MEM_CHECK_SUBGROUP = 128  # czk_bases_register: verify [r] P == infinity; a failing base keeps the handle on the XYZZ kernels
 CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY = 0, 1
 CZK_G1, CZK_G2 = 1, 2
@@ -213,6 +214,8 @@ class Context:
         return out
 
     def fr_vec_scale(self, a, k, out=None, n=None, mem=CZK_MEM_HOST):
+        if mem == (CZK_MEM_DEVICE | CZK_MEM_SCALAR_HOST):
+            k = np.ascontiguousarray(k, np.uint64).reshape(4)
         if mem == CZK_MEM_HOST:
             a, k = np.ascontiguousarray(a, np.uint64), np.ascontiguousarray(k, np.uint64)
             n = a.size // 4
@@ -338,6 +341,28 @@ class Context:
         out = np.zeros(jw, dtype=np.uint64)
         self._ck(self._L.czk_jac_add_mixed(self._h, C.c_int(group), _ptr(a), _ptr(b_aff), C.c_int(int(b_inf)), _ptr(out)))
         return out
+
+    def jac_scalar_mul(self, group, a, k, scalar_form=CZK_SCALAR_CANONICAL):
+        """ProjectiveCurve::mul on a host Jacobian value; k: (4,) uint64 (canonical, or Montgomery with CZK_SCALAR_MONTGOMERY)"""
+        jw = 18 if group == CZK_G1 else 36
+        a, k = np.ascontiguousarray(a, np.uint64).reshape(jw), np.ascontiguousarray(k, np.uint64).reshape(4)
+        out = np.zeros(jw, dtype=np.uint64)
+        self._ck(self._L.czk_jac_scalar_mul(self._h, C.c_int(group), _ptr(a), _ptr(k), C.c_int(scalar_form), _ptr(out)))
+        return out
+
+    def jac_neg(self, group, a):
+        jw = 18 if group == CZK_G1 else 36
+        a = np.ascontiguousarray(a, np.uint64).reshape(jw)
+        out = np.zeros(jw, dtype=np.uint64)
+        self._ck(self._L.czk_jac_neg(self._h, C.c_int(group), _ptr(a), _ptr(out)))
+        return out
+
+    def fr_copy_3d(self, dst_ptr, dst_stride, src_ptr, src_stride, n):
+        """czk_fr_copy_3d: strided copy (src_ptr None: zero fill) of Fr elements in device memory, in stream order; strides / extents: 3 ints each"""
+        ds = (C.c_size_t * 3)(*[int(v) for v in dst_stride])
+        ss = (C.c_size_t * 3)(*[int(v) for v in (src_stride or (0, 0, 0))])
+        nn = (C.c_size_t * 3)(*[int(v) for v in n])
+        self._ck(self._L.czk_fr_copy_3d(self._h, _ptr(dst_ptr), ds, _ptr(src_ptr), ss if src_ptr is not None else None, nn))
 
     def fr_spdz_open(self, shares_ptr, parties: int, n: int, out_value_ptr) -> int:
         """Local part of SpdzFieldShare::batch_open on device buffers; returns the number of failed MAC checks."""

@@ -249,6 +249,46 @@ extern "C" int czk_jac_add_mixed(czk_ctx* ctx, int group, const uint64_t* a, con
     return CZK_OK;
 }
 
+namespace czk {
+template <class F>
+static void host_jac_scalar_mul(const u64* a, const Fr& k_canonical, u64* out) {
+    Jac<F> base, res = Jac<F>::zero();
+    load_jac<F>(a, base);
+    int top = 255;
+    while (top >= 0 && !((k_canonical.l[top / 32] >> (top % 32)) & 1)) top--;      // BitIteratorBE::without_leading_zeros
+    for (int i = top; i >= 0; i--) {
+        res = jac_double(res);
+        if ((k_canonical.l[i / 32] >> (i % 32)) & 1) res = jac_add(res, base);
+    }
+    store_jac<F>(res, out);
+}
+template <class F>
+static void host_jac_neg(const u64* a, u64* out) {
+    Jac<F> p;
+    load_jac<F>(a, p);
+    p.y = f_neg(p.y);
+    store_jac<F>(p, out);
+}
+}  // namespace czk
+
+extern "C" int czk_jac_scalar_mul(czk_ctx* ctx, int group, const uint64_t* a, const uint64_t* k, int scalar_form, uint64_t* out) {
+    if (!a || !k || !out) return set_err(ctx, CZK_ERR_ARG, "null jac_scalar_mul argument");
+    if (scalar_form != CZK_SCALAR_CANONICAL && scalar_form != CZK_SCALAR_MONTGOMERY) return set_err(ctx, CZK_ERR_ARG, "bad scalar_form");
+    Fr kk = host_fr(k);
+    if (scalar_form == CZK_SCALAR_MONTGOMERY) kk = fp_into_repr(kk);
+    if (group == CZK_G1) host_jac_scalar_mul<Fq>(a, kk, out);
+    else if (group == CZK_G2) host_jac_scalar_mul<Fq2>(a, kk, out);
+    else return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    return CZK_OK;
+}
+extern "C" int czk_jac_neg(czk_ctx* ctx, int group, const uint64_t* a, uint64_t* out) {
+    if (!a || !out) return set_err(ctx, CZK_ERR_ARG, "null jac_neg argument");
+    if (group == CZK_G1) host_jac_neg<Fq>(a, out);
+    else if (group == CZK_G2) host_jac_neg<Fq2>(a, out);
+    else return set_err(ctx, CZK_ERR_ARG, "group must be CZK_G1 or CZK_G2");
+    return CZK_OK;
+}
+
 extern "C" const char* czk_version(void) { return "czk-mi355x 0.1 (gfx950)"; }
 
 extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {

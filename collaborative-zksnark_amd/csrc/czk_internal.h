@@ -140,6 +140,7 @@ struct czk_bases {
     static constexpr int MAX_EXTRA = 12;
     czk_table_set extra[MAX_EXTRA];
     std::atomic<int> n_extra{0};      // published count: readers scan [0, n_extra) without the lock
+    std::atomic<unsigned> nomem_class{0};   // bit c: building a secondary set of width c failed for lack of memory -- not retried per call (pick_tables)
     std::mutex build_mu;              // serialises builders (contexts of several threads may share one handle)
     bool per_call_width = true;       // CZK_MSM_FIXED_C=1 at registration turns the secondary sets off (A/B runs)
     int device = 0;            // GPU ordinal the tables live on (the handle may outlive its context: no ctx pointer is kept)

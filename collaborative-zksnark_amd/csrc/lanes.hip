@@ -172,3 +172,51 @@ extern "C" int czk_lanes_zero(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t 
     CZK_HIP(ctx, hipMemsetAsync(dst->p + 4 * (lane * dst->len + elem), 0, n * 32, ctx->stream));
     return CZK_OK;
 }
+
+// ---- czk_fr_copy_3d: one strided copy / fill kernel for every re-layout between transforms -------------------------------------
+namespace czk {
+struct Copy3 {
+    size_t n0, n1, n2, d0, d1, d2, s0, s1, s2;
+};
+// one thread per Fr element (two 16-byte accesses); i2 is the fastest index, so unit inner strides give coalesced runs
+__global__ void k_copy_3d(u64* dst, const u64* src, Copy3 c) {
+    const size_t total = c.n0 * c.n1 * c.n2;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const size_t i2 = t % c.n2, r = t / c.n2, i1 = r % c.n1, i0 = r / c.n1;
+        ulonglong2* d = reinterpret_cast<ulonglong2*>(dst + 4 * (i0 * c.d0 + i1 * c.d1 + i2 * c.d2));
+        if (src) {
+            const ulonglong2* s = reinterpret_cast<const ulonglong2*>(src + 4 * (i0 * c.s0 + i1 * c.s1 + i2 * c.s2));
+            const ulonglong2 lo = s[0], hi = s[1];
+            d[0] = lo;
+            d[1] = hi;
+        } else {
+            d[0] = d[1] = make_ulonglong2(0, 0);
+        }
+    }
+}
+}  // namespace czk
+
+extern "C" int czk_fr_copy_3d(czk_ctx* ctx, uint64_t* dst, const size_t* dst_stride, const uint64_t* src, const size_t* src_stride, const size_t* n) {
+    if (!ctx) return CZK_ERR_ARG;
+    if (!dst_stride || !n || (src && !src_stride)) return set_err(ctx, CZK_ERR_ARG, "czk_fr_copy_3d: null stride / extent");
+    const size_t total = n[0] * n[1] * n[2];
+    if (!total) return CZK_OK;
+    if (!dst) return set_err(ctx, CZK_ERR_ARG, "czk_fr_copy_3d: null destination");
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    // contiguous cases go to the copy engine / memset path: no kernel, no CU time
+    const bool dst_dense = dst_stride[2] == 1 && dst_stride[1] == n[2] && dst_stride[0] == n[1] * n[2];
+    if (dst_dense && !src) {
+        CZK_HIP(ctx, hipMemsetAsync(dst, 0, total * 32, ctx->stream));
+        return CZK_OK;
+    }
+    if (dst_dense && src_stride[2] == 1 && src_stride[1] == n[2] && src_stride[0] == n[1] * n[2]) {
+        CZK_HIP(ctx, hipMemcpyAsync(dst, src, total * 32, hipMemcpyDeviceToDevice, ctx->stream));
+        return CZK_OK;
+    }
+    Copy3 c{n[0], n[1], n[2], dst_stride[0], dst_stride[1], dst_stride[2], src ? src_stride[0] : 0, src ? src_stride[1] : 0, src ? src_stride[2] : 0};
+    size_t blocks = (total + 255) / 256, cap = (size_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_copy_3d, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64*)dst, (const u64*)src, c);
+    CZK_HIP(ctx, hipGetLastError());
+    return CZK_OK;
+}

@@ -864,6 +864,7 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
         return best;
     };
     const czk_table_set* t = find();
+    if (!t && build && b->nomem_class.load(std::memory_order_acquire) & (1u << (cc & 31))) return CZK_OK;   // see below: no room last time
     if (!t && build) {
         std::lock_guard<std::mutex> lk(b->build_mu);
         t = find();   // another context may have built it meanwhile
@@ -877,7 +878,12 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
             CZK_TRY(msm_pipeline_sync(ctx));   // (the build synchronises ctx->stream; drain the MSM streams too so that timing stays attributable)
             int rc = build_secondary<F>(ctx, b, cc, cover, &b->extra[n]);
             if (rc == CZK_ERR_NOMEM) {
-                (void)hipGetLastError();        // no room for another table set: this call (and later ones of its size) runs on the key's own tables
+                // no room for another table set: this call and later ones of its width class run on the key's own tables.  The class is
+                // remembered on the handle, so later calls do not drain the pipeline and retry four failing allocations each time
+                // (czk_bases_prepare tries again: a caller that freed memory asks for the set explicitly); the swallowed error is cleared.
+                (void)hipGetLastError();
+                b->nomem_class.fetch_or(1u << (cc & 31), std::memory_order_release);
+                ctx->err.clear();
                 return CZK_OK;
             }
             CZK_TRY(rc);
@@ -1070,9 +1076,16 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                                        part_scatter_lds(256, n_parts), ss, digits, size, W, nb, part_base, part_cursor, n_parts, part_shift, ranks, part_lb);
             }
             {
-                // dynamic LDS: counters + scan scratch + as large a staging area as the device's per-workgroup limit allows (gfx950: 160 KiB -> 36 k entries)
+                // dynamic LDS: counters + scan scratch + a staging area -- as large as the device's per-workgroup limit allows (gfx950: 160 KiB -> 36 k
+                // entries) for long calls, but no larger than a partition can need (twice the mean partition + slack; a partition beyond the area
+                // places directly): a 3-point commitment or a 2^13-point call has a few hundred entries per partition, and a 160 KiB request would
+                // pin one workgroup per CU and block LDS for the kernels of the other contexts on the GPU
                 const size_t fixed = (2 * PART_BUCKETS + PSORT_THREADS) * 4;
-                const size_t lds = ctx->lds_per_block > fixed + 4096 ? ctx->lds_per_block : fixed + 4096;
+                const size_t limit = ctx->lds_per_block > fixed + 4096 ? ctx->lds_per_block : fixed + 4096;
+                size_t want = 2 * (total / n_parts) + 1024;
+                if (want > total) want = total;
+                size_t lds = fixed + (want * 4 > 4096 ? want * 4 : 4096);
+                if (lds > limit) lds = limit;
                 const u32 cap = (u32)((lds - fixed) / 4);
                 hipLaunchKernelGGL(k_part_sort, dim3(n_parts, (unsigned)lanes), dim3(PSORT_THREADS), lds, ss, ranks, part_lb, part_base, n_parts, part_shift, total, B,
                                    sorted, offsets, counts, cap);
@@ -1427,6 +1440,7 @@ extern "C" int czk_bases_prepare(czk_ctx* ctx, const czk_bases* b, size_t n_scal
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t size = b->n < n_scalars ? b->n : n_scalars;
     TableView tv;
+    const_cast<czk_bases*>(b)->nomem_class.store(0, std::memory_order_release);   // an explicit request retries a set that did not fit earlier
     return b->group == CZK_G1 ? pick_tables<Fq>(ctx, b, size, &tv, true) : pick_tables<Fq2>(ctx, b, size, &tv, true);
 }
 

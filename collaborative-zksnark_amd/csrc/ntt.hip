@@ -632,9 +632,16 @@ int czk::ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes) {
 
 extern "C" int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n, int mem) {
     if (!ctx || !k || (n && (!a || !out))) return ctx ? set_err(ctx, CZK_ERR_ARG, "bad vec_scale argument") : CZK_ERR_ARG;
-    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
+    const bool host_scalar = mem == (CZK_MEM_DEVICE | CZK_MEM_SCALAR_HOST);
+    if (host_scalar) mem = CZK_MEM_HOST + 2;   // (neither of the two plain modes below)
+    if (!host_scalar && !valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST, CZK_MEM_DEVICE or CZK_MEM_DEVICE | CZK_MEM_SCALAR_HOST");
     if (!n) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
+    if (host_scalar) {   // device vectors, the scalar by value with the launch
+        hipLaunchKernelGGL(k_vec_scale, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (const u64*)a, host_fr(k), (u64*)out, n);
+        CZK_HIP(ctx, hipGetLastError());
+        return CZK_OK;
+    }
     if (mem == CZK_MEM_DEVICE) {
         // the scalar lives in device memory like the vectors: read it in the kernel (a copy to the host would synchronise the stream -- a
         // full pipeline stall in the middle of a prover's round, which is what this call cost the Plonk / Marlin drivers until round 4)

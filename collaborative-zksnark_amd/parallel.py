@@ -46,10 +46,50 @@ def set_exchange(method: str):
     if method not in ("ring", "p2p"):
         raise ValueError("exchange method must be 'ring' or 'p2p'")
     _EXCHANGE = method
+    if _NET is not None:
+        _NET.set_option("exchange", 1 if method == "p2p" else 0)
 
 
 def get_exchange() -> str:
     return _EXCHANGE
+
+
+# The opens' transport.  None: torch.distributed (RCCL through torch on GPUs, gloo through the host otherwise) -- the exchange is issued from
+# Python on torch's stream.  A binding.Net (czk_net, include/czk.h): the SAME calls a compiled host makes -- RCCL / shared memory inside the
+# library, enqueued on the czk context's stream; every function below then is a thin wrapper over one C-ABI call (use_net).
+_NET = None
+
+
+def use_net(net):
+    """Route the opens through a czk_net communicator (binding.Net) instead of torch.distributed; None switches back."""
+    global _NET
+    _NET = net
+    if net is not None:
+        net.set_option("exchange", 1 if _EXCHANGE == "p2p" else 0)
+
+
+def get_net():
+    return _NET
+
+
+def make_net(ctx, transport: str | None = None, device=None):
+    """A czk_net over the ranks of torch's default process group (which only carries the communicator id here): transport "rccl" (one GPU
+    per rank; default when the group's backend is nccl) or "shm" (ranks of one node in any assignment to GPUs)."""
+    from . import binding
+    world, rank = _world_rank()
+    if transport is None:
+        transport = "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") else "shm"
+    t = binding.CZK_NET_RCCL if transport == "rccl" else binding.CZK_NET_SHM
+    box = [binding.Net.unique_id(t) if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, **({"device": device} if device is not None else {}))
+    return binding.Net(ctx, t, rank, world, box[0])
+
+
+def _net_in(ctx, t: torch.Tensor):
+    """`t` may come from torch kernels on torch's current stream; czk_net enqueues on the context's stream"""
+    if ctx.stream_handle() != torch.cuda.current_stream(t.device).cuda_stream:
+        _ctx_stream(ctx, t.device).wait_stream(torch.cuda.current_stream(t.device))
 
 
 def _ctx_stream(ctx, device):
@@ -142,8 +182,21 @@ def all_gather_shares(share: torch.Tensor, ctx=None, method: str | None = None) 
     (share/spdz.rs:166-185) is then a local, share-linear pointwise step.  `ctx`: the czk context whose kernels produced `share` and
     will consume the result -- given, the hand-over in both directions is an event wait between streams; omitted, the caller has
     synchronised and the host waits for the collective.  `method`: "ring" / "p2p" (default: set_exchange)."""
-    if not dist.is_initialized():
+    if not dist.is_initialized() and _NET is None:
         return share.unsqueeze(0)
+    if _NET is not None and share.is_cuda:
+        c = ctx if ctx is not None else _NET.ctx
+        share = share.contiguous()
+        out = torch.empty((_NET.world,) + tuple(share.shape), dtype=share.dtype, device=share.device)
+        _net_in(c, share)
+        if method is not None:
+            _NET.set_option("exchange", 1 if method == "p2p" else 0)
+        _NET.broadcast(share.data_ptr(), nbytes=share.numel() * share.element_size(), recv=out.data_ptr(), mem=1)
+        if method is not None:
+            _NET.set_option("exchange", 1 if _EXCHANGE == "p2p" else 0)
+        if ctx is None:
+            c.sync()
+        return _after_consume(c, out)
     world, rank = dist.get_world_size(), dist.get_rank()
     method = method or _EXCHANGE
     if ctx is not None:
@@ -170,6 +223,8 @@ def all_gather_shares(share: torch.Tensor, ctx=None, method: str | None = None) 
 # mpc-net's other primitives over torch.distributed (RCCL on GPUs, gloo on CPU) and the reference's wire format
 # ------------------------------------------------------------------------------------------------------------------
 def _world_rank():
+    if _NET is not None:
+        return _NET.world, _NET.rank
     return (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
 
 
@@ -179,6 +234,13 @@ def send_to_king(x: torch.Tensor):
     world, rank = _world_rank()
     if world == 1:
         return x.unsqueeze(0)
+    if _NET is not None and x.is_cuda:
+        x = x.contiguous()
+        out = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device) if rank == 0 else None
+        _net_in(_NET.ctx, x)
+        _NET.send_to_king(x.data_ptr(), nbytes=x.numel() * x.element_size(), recv=out.data_ptr() if out is not None else None, mem=1)
+        _after_consume(_NET.ctx, x)
+        return out
     if dist.get_backend() == "gloo":
         host = x.contiguous().cpu()
         out = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
@@ -196,6 +258,14 @@ def recv_from_king(xs, like: torch.Tensor) -> torch.Tensor:
     world, rank = _world_rank()
     if world == 1:
         return xs[0]
+    if _NET is not None and like.is_cuda:
+        out = torch.empty_like(like, memory_format=torch.contiguous_format)
+        if rank == 0:
+            assert xs.shape[0] == world
+            xs = xs.contiguous()
+            _net_in(_NET.ctx, xs)
+        _NET.recv_from_king(xs.data_ptr() if rank == 0 else None, nbytes=out.numel() * out.element_size(), recv=out.data_ptr(), mem=1)
+        return _after_consume(_NET.ctx, out)
     gloo = dist.get_backend() == "gloo"
     out = torch.empty_like(like.cpu() if gloo else like)
     parts = None
@@ -246,6 +316,17 @@ def atomic_broadcast(ctx, x: torch.Tensor, rand32: bytes | None = None) -> torch
     import numpy as np
     world, rank = _world_rank()
     n = x.shape[0]
+    if _NET is not None and x.is_cuda:
+        x = x.contiguous()
+        data = torch.empty((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        _net_in(ctx, x)
+        try:
+            _NET.atomic_broadcast(x.data_ptr(), n, data.data_ptr(), rand32=rand32)
+        except Exception as e:
+            if getattr(e, "code", None) == 6:            # CZK_ERR_CHECK
+                raise MpcCheckError(str(e)) from e
+            raise
+        return _after_consume(ctx, data)
     rep = torch.empty_like(x)
     ctx.fr_into_repr(x.data_ptr(), out=rep.data_ptr(), n=n, mem=1)
     ctx.sync()
@@ -274,6 +355,19 @@ def spdz_batch_open(ctx, sh: torch.Tensor, mac: torch.Tensor, mac_share, commit:
     sum must vanish.  MAC shares themselves never leave the party.  sh, mac: (n, 4) device tensors; mac_share: (4,) uint64."""
     world, _ = _world_rank()
     n = sh.shape[0]
+    if _NET is not None and sh.is_cuda:                                     # one C-ABI call: czk_spdz_batch_open
+        sh, mac = sh.contiguous(), mac.contiguous()
+        vals = torch.empty_like(sh)
+        _net_in(ctx, sh)
+        try:
+            bad = _NET.spdz_batch_open(sh.data_ptr(), mac.data_ptr(), mac_share, n, vals.data_ptr(), commit=commit)
+        except Exception as e:
+            if getattr(e, "code", None) == 6:
+                raise MpcCheckError(str(e)) from e
+            raise
+        if bad != 0:
+            raise MpcCheckError(f"SPDZ MAC check failed on {bad} of {n} opened values")
+        return _after_consume(ctx, vals)
     gathered = all_gather_shares(sh, ctx)                                  # Net::broadcast(&s_vals); stream hand-over by events (sh may be in flight)
     vals = torch.empty_like(sh)
     ctx.fr_lanes_sum(gathered.data_ptr(), world, n, out_ptr=vals.data_ptr())
@@ -291,6 +385,14 @@ def gsz_batch_open(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
     inverse DFT with the degree check, p(0)."""
     world, _ = _world_rank()
     n = val.shape[0]
+    if _NET is not None and val.is_cuda:                                    # czk_gsz_batch_open
+        val = val.contiguous()
+        out = torch.empty_like(val)
+        _net_in(ctx, val)
+        bad = _NET.gsz_batch_open(val.data_ptr(), n, out.data_ptr(), degree=degree)
+        if bad != 0:
+            raise MpcCheckError(f"GSZ open: {bad} of {n} share polynomials exceed their degree bound")
+        return _after_consume(ctx, out)
     gathered = all_gather_shares(val, ctx)
     out = torch.empty_like(val)
     bad = ctx.fr_gsz_open(gathered.data_ptr(), world, n, out.data_ptr(), degree=degree)
@@ -299,11 +401,44 @@ def gsz_batch_open(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
     return _after_consume(ctx, out)
 
 
+def gsz_batch_king_compute(ctx, val: torch.Tensor, degree: int) -> torch.Tensor:
+    """gsz20::batch_king_compute(shares, new_degree, |r| r) (mpc-algebra/src/share/gsz20/mod.rs:494-527), the degree reduction inside batch_mult:
+    every party's lane to the king, who opens each element with the degree bound and sends the VALUE back to every party as its new share."""
+    world, rank = _world_rank()
+    n = val.shape[0]
+    if _NET is not None and val.is_cuda:                                    # czk_gsz_batch_king_compute
+        val = val.contiguous()
+        out = torch.empty_like(val)
+        _net_in(ctx, val)
+        bad = _NET.gsz_batch_king_compute(val.data_ptr(), n, out.data_ptr(), degree=degree)
+        if bad != 0:
+            raise MpcCheckError(f"GSZ king_compute: {bad} of {n} share polynomials exceed their degree bound")
+        return _after_consume(ctx, out)
+    _before_exchange(ctx, val)
+    got = send_to_king(val)
+    ans = None
+    if rank == 0:
+        opened = torch.empty_like(val)
+        got = got.contiguous()
+        bad = ctx.fr_gsz_open(got.data_ptr(), world, n, opened.data_ptr(), degree=degree)
+        if bad != 0:
+            raise MpcCheckError(f"GSZ king_compute: {bad} of {n} share polynomials exceed their degree bound")
+        ctx.sync()
+        ans = opened.unsqueeze(0).expand(world, *opened.shape)            # vec![output; n]
+    return recv_from_king(ans, val)
+
+
 def additive_batch_open(ctx, val: torch.Tensor) -> torch.Tensor:
     """AdditiveFieldShare::batch_open (mpc-algebra/src/share/add.rs:256-259; the reference's `--alg hbc`): broadcast the shares,
     sum them.  No MAC, no check.  val: (n, 4) device tensor."""
     world, _ = _world_rank()
     n = val.shape[0]
+    if _NET is not None and val.is_cuda:                                    # czk_add_batch_open
+        val = val.contiguous()
+        out = torch.empty_like(val)
+        _net_in(ctx, val)
+        _NET.add_batch_open(val.data_ptr(), n, out.data_ptr())
+        return _after_consume(ctx, out)
     gathered = all_gather_shares(val, ctx)
     out = torch.empty_like(val)
     ctx.fr_lanes_sum(gathered.contiguous().data_ptr(), world, n, out_ptr=out.data_ptr())

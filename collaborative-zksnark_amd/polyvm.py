@@ -276,7 +276,7 @@ class GpuBackend(Backend):
         self.base_seed, self.n_bases = base_seed, n
         self.msm_count = self.ntt_count = 0
         self._pending = []      # commitments / evaluations enqueued since the last transcript_point()
-        self._ring, self._ring_at = None, 0
+        self._vals, self._vals_at = None, 0      # evaluation buffer (_val_slot)
         self.opener = None      # party-per-rank layouts: callable(backend, (k, lanes, 4) device tensor) -> opened values, run over torch.distributed
         self.opened = []        # what the opener returned, in order
         self.msm_points = 0
@@ -305,49 +305,86 @@ class GpuBackend(Backend):
     def lanes_of(self, a):
         return a.shape[0]
 
+    # ---- data movement: every re-layout between transforms is ONE czk_fr_copy_3d (or a copy-engine transfer when both sides are dense) on the
+    # context's stream -- no tensor-library kernels in the provers' timelines (round 4: at::native fill / copy kernels were 45 % of the kernel
+    # time inside Marlin's accumulate gaps).  torch only owns the allocations.  All arrays here are dense (lanes, n, 4) int64 tensors.
+    def _new(self, lanes, n):
+        return self.torch.empty((lanes, n, 4), dtype=self.torch.int64, device=self.dev)
+
+    def _copy(self, dst, dst_off, dst_stride, src, src_off, src_stride, n3):
+        """dst / src: tensors (src None: zero fill); offsets and strides in Fr elements"""
+        if n3[0] * n3[1] * n3[2]:
+            self.ctx.fr_copy_3d(dst.data_ptr() + 32 * dst_off, dst_stride, None if src is None else src.data_ptr() + 32 * src_off, src_stride, n3)
+
     def zeros(self, lanes, n):
-        return self.torch.zeros((lanes, n, 4), dtype=self.torch.int64, device=self.dev)
+        out = self._new(lanes, n)
+        self._copy(out, 0, (0, n, 1), None, 0, None, (1, lanes, n))
+        return out
 
     def lane_stack(self, parts):
-        return self.torch.cat(parts, dim=0).contiguous()
+        n = parts[0].shape[1]
+        out = self._new(sum(p.shape[0] for p in parts), n)
+        at = 0
+        for p in parts:
+            assert p.shape[1] == n
+            self._copy(out, at * n, (0, n, 1), p, 0, (0, n, 1), (1, p.shape[0], n))
+            at += p.shape[0]
+        return out
 
     def resized(self, a, n):
-        out = self.torch.empty((a.shape[0], n, 4), dtype=self.torch.int64, device=self.dev)
-        m = min(n, a.shape[1])
-        out[:, :m] = a[:, :m]
-        if n > m:
-            out[:, m:].zero_()      # only the tail is cleared (a full zero fill + copy moved every byte twice)
+        lanes, have = a.shape[0], a.shape[1]
+        out = self._new(lanes, n)
+        m = min(n, have)
+        self._copy(out, 0, (0, n, 1), a, 0, (0, have, 1), (1, lanes, m))
+        self._copy(out, m, (0, n, 1), None, 0, None, (1, lanes, n - m))      # only the tail is cleared
         return out
 
     def drop_first(self, a, k):
-        return a[:, k:].contiguous()
+        lanes, have = a.shape[0], a.shape[1]
+        out = self._new(lanes, have - k)
+        self._copy(out, 0, (0, have - k, 1), a, k, (0, have, 1), (1, lanes, have - k))
+        return out
 
     def concat(self, parts):
-        return self.torch.cat(parts, dim=1).contiguous()
+        lanes, total = parts[0].shape[0], sum(p.shape[1] for p in parts)
+        out = self._new(lanes, total)
+        at = 0
+        for p in parts:
+            assert p.shape[0] == lanes
+            self._copy(out, at, (0, total, 1), p, 0, (0, p.shape[1], 1), (1, lanes, p.shape[1]))
+            at += p.shape[1]
+        return out
 
     def strided_split(self, a, n):
+        """out[l * n + j][k] = a[l][k * n + j]"""
         lanes, total = a.shape[0], a.shape[1]
-        return a.reshape(lanes, total // n, n, 4).permute(0, 2, 1, 3).reshape(lanes * n, total // n, 4).contiguous()
+        L = total // n
+        out = self._new(lanes * n, L)
+        self._copy(out, 0, (n * L, L, 1), a, 0, (total, 1, n), (lanes, n, L))
+        return out
 
     def strided_merge(self, a, n, lanes):
+        """out[l][k * n + j] = a[l * n + j][k]"""
         L = a.shape[1]
-        return a.reshape(lanes, n, L, 4).permute(0, 2, 1, 3).reshape(lanes, L * n, 4).contiguous()
+        out = self._new(lanes, L * n)
+        self._copy(out, 0, (L * n, n, 1), a, 0, (n * L, 1, L), (lanes, L, n))
+        return out
 
     def _bc(self, a, b):
         la, lb = a.shape[0], b.shape[0]
         if la != lb:
-            if la == 1:
-                a = a.expand(lb, -1, -1).contiguous()
-            else:
-                b = b.expand(la, -1, -1).contiguous()
-        return a.contiguous(), b.contiguous()
+            one, many = (a, lb) if la == 1 else (b, la)
+            n = one.shape[1]
+            rep = self._new(many, n)
+            self._copy(rep, 0, (0, n, 1), one, 0, (0, 0, 1), (1, many, n))      # lane stride 0: the single lane on every lane
+            a, b = (rep, b) if la == 1 else (a, rep)
+        return a, b
 
     def _vec(self, op, a, b):
         if op == 2:
             a, b = self._bc(a, b)
         assert a.shape == b.shape, (a.shape, b.shape)
-        a, b = a.contiguous(), b.contiguous()
-        out = self.torch.empty_like(a)
+        out = self._new(a.shape[0], a.shape[1])
         self.ctx.fr_vec_op(op, a.data_ptr(), b.data_ptr(), out=out.data_ptr(), n=a.shape[0] * a.shape[1], mem=self.M)
         return out
 
@@ -360,29 +397,16 @@ class GpuBackend(Backend):
     def mul(self, a, b):
         return self._vec(2, a, b)
 
-    def _scalar(self, k):
-        """One field element on the device without blocking the host: a pageable host-to-device copy would wait for everything
-        enqueued so far, so the element goes through a ring of pinned staging slots (re-used after the next synchronisation)."""
-        if self._ring is None or self._ring_at == self._ring.shape[0]:
-            if self._ring is not None:
-                self.ctx.sync()
-            else:
-                self._ring = self.torch.empty((1024, 4), dtype=self.torch.int64).pin_memory()
-            self._ring_at = 0
-        slot = self._ring[self._ring_at]
-        self._ring_at += 1
-        slot.copy_(self.torch.from_numpy(mont(k).view(np.int64)))
-        return slot.to(self.dev, non_blocking=True)
-
     def scale(self, a, k):
-        a = a.contiguous()
-        out = self.torch.empty_like(a)
-        kd = self._scalar(k)                                                # device memory mode: the scalar is read from the device too
-        self.ctx.fr_vec_scale(a.data_ptr(), kd.data_ptr(), out=out.data_ptr(), n=a.shape[0] * a.shape[1], mem=self.M)
+        out = self._new(a.shape[0], a.shape[1])
+        # the scalar travels with the launch (CZK_MEM_SCALAR_HOST): no staging slot, no 32-byte host-to-device copy per call
+        self.ctx.fr_vec_scale(a.data_ptr(), mont(k), out=out.data_ptr(), n=a.shape[0] * a.shape[1], mem=self.M | self.czk.binding.CZK_MEM_SCALAR_HOST)
         return out
 
     def const(self, k, n):
-        return self._scalar(k).reshape(1, 1, 4).expand(1, n, 4).contiguous()
+        out = self._new(1, n)
+        self.ctx.fr_powers(mont(1), n, c=mont(k), out=out.data_ptr(), mem=self.M)       # k * 1^i
+        return out
 
     def powers(self, g, n):
         out = self.torch.empty((1, n, 4), dtype=self.torch.int64, device=self.dev)
@@ -394,20 +418,32 @@ class GpuBackend(Backend):
         buf = self.torch.empty((a.shape[0], size, 4), dtype=self.torch.int64, device=self.dev)   # not zero-filled: the first pass zero-extends
         if size & (size - 1) == 0 and m > 0 and not self.ntt_copy_first:
             # radix-2 domain: the transform reads the source lanes itself (EvaluationDomain::fft(&coeffs) -> Vec: no copy of the operand)
-            a = a.contiguous()
             self.ctx.ntt_fr_to(a.data_ptr(), a.shape[1], buf.data_ptr(), size.bit_length() - 1, kind, lanes=buf.shape[0], in_len=m)
             self.ntt_count += buf.shape[0]
             return buf
-        buf[:, :m] = a[:, :m]                                                                   # beyond in_len itself (czk_ntt_fr_mixed)
+        self._copy(buf, 0, (0, size, 1), a, 0, (0, a.shape[1], 1), (1, a.shape[0], m))          # beyond in_len itself (czk_ntt_fr_mixed)
         self.ctx.ntt_fr_mixed(buf.data_ptr(), size, kind, lanes=buf.shape[0], in_len=m, mem=self.M)
         self.ntt_count += buf.shape[0]
         return buf
+
+    def _val_slot(self, rows):
+        """`rows` Fr of the evaluation buffer: every value produced between two transcript points lands in ONE device array, so settling
+        them is one device-to-host copy (no gather kernel)"""
+        if self._vals is None:
+            self._vals = self.torch.empty((4096, 4), dtype=self.torch.int64, device=self.dev)
+        if self._vals_at + rows > self._vals.shape[0]:       # (a prover evaluates a few dozen values per round)
+            self.ctx.sync()
+            self._vals = self.torch.empty((max(2 * self._vals.shape[0], rows), 4), dtype=self.torch.int64, device=self.dev)
+            self._vals_at = 0
+        v = self._vals[self._vals_at:self._vals_at + rows]
+        self._vals_at += rows
+        return v
 
     def _div_linear_dev(self, a, z):
         a = a.contiguous()
         lanes, n = a.shape[0], a.shape[1]
         q = self.torch.empty((lanes, max(n - 1, 0), 4), dtype=self.torch.int64, device=self.dev)
-        rem = self.torch.empty((lanes, 4), dtype=self.torch.int64, device=self.dev)
+        rem = self._val_slot(lanes)
         self.ctx.poly_div_linear(a.data_ptr(), mont(z), lanes=lanes, n=n, quotient=q.data_ptr(), remainder=rem.data_ptr(), mem=self.M)
         return q, rem
 
@@ -426,7 +462,7 @@ class GpuBackend(Backend):
 
     def _evaluate_dev(self, a, x):
         a = a.contiguous()
-        val = self.torch.empty((a.shape[0], 4), dtype=self.torch.int64, device=self.dev)
+        val = self._val_slot(a.shape[0])
         self.ctx.poly_evaluate(a.data_ptr(), mont(x), lanes=a.shape[0], n=a.shape[1], values=val.data_ptr(), mem=self.M)
         return val
 
@@ -490,9 +526,11 @@ class GpuBackend(Backend):
 
     def transcript_point(self):
         if not self._pending:
+            if self._vals_at:
+                self.ctx.sync()              # slots handed out for blocking reads (div_linear) may still be in flight
+                self._vals_at = 0
             return
         self.ctx.sync()
-        self._ring_at = 0
         commits = [p for p in self._pending if p._src[0] == "commit"]
         if commits:                                                    # one conversion to affine for all of them
             aff, inf = self.ctx.jac_to_affine(self.czk.CZK_G1, np.concatenate([p._src[1] for p in commits]))
@@ -503,12 +541,12 @@ class GpuBackend(Backend):
                 at += k
         values = [p for p in self._pending if p._src[0] != "commit"]
         if values:
-            host = self.torch.cat([p._src[1] for p in values]).cpu().numpy().view(np.uint64)
-            at = 0
+            base = self._vals.data_ptr()
+            host = self._vals[:self._vals_at].cpu().numpy().view(np.uint64)      # one copy: every slot handed out since the last settle
             for p in values:
-                k = p._src[1].shape[0]
+                k, at = p._src[1].shape[0], (p._src[1].data_ptr() - base) // 32
+                assert 0 <= at and at + k <= self._vals_at
                 p.value = host[at:at + k].copy()
-                at += k
             opened = [p._src[1] for p in values if p._src[0] == "open_value"]
             if opened and self.opener is not None:
                 # `y.publicize()` of every evaluation made since the last challenge, as ONE batch_open over the parties
@@ -516,6 +554,7 @@ class GpuBackend(Backend):
         for p in self._pending:
             p._src = None
         self._pending = []
+        self._vals_at = 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------

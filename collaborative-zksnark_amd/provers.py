@@ -2,7 +2,8 @@
 C ABI (binding.py).  Mirrors the reference's call sequences, not its protocol logic:
 
   Groth16Local   R1CStoQAP::witness_map (mpc-snarks/src/groth/r1cs_to_qap.rs:47-113) + the MSM sequence of create_proof
-                 (mpc-snarks/src/groth/prover.rs:66-178), Beaver local half (mpc-algebra/src/share/field.rs:97-127)
+                 (mpc-snarks/src/groth/prover.rs:66-178), Beaver local half (mpc-algebra/src/share/field.rs:97-127);
+                 create_proof's O(1) group steps and the Proof{a, b, c} share of every lane for public r, s (prover.rs:110-178, 216-232)
 
 Used by bench.py (timed) and tests/ (parity against the checker).  torch provides device memory and streams only.
 """
@@ -56,6 +57,15 @@ def to_mont_limbs(vals):
     return np.frombuffer(buf, dtype=np.uint64).reshape(-1, 4).copy()
 
 
+Q_MOD = 258664426012969094010652733694893533536393512754914660539884262666720468348340822774968888139573360124440321458177
+
+
+def to_mont_limbs_fq(v: int) -> np.ndarray:
+    """canonical integer -> (6,) uint64 Montgomery limbs of Fq (R = 2^384)"""
+    x = v % Q_MOD * ((1 << 384) % Q_MOD) % Q_MOD
+    return np.array([(x >> (64 * i)) & _MASK64 for i in range(6)], dtype=np.uint64)
+
+
 BASE_SEED = 0xBA5E5   # P_i = [k_i] G with k_i = rand_fr_canonical(BASE_SEED + query id, n)  (SURVEY.md section 8d)
 QUERIES = (("h", 1), ("l", 2), ("a", 3), ("b_g1", 4), ("b_g2", 5))
 
@@ -79,8 +89,14 @@ class Groth16Local:
         # scheme "spdz": two lanes per party (sh, mac; share/spdz.rs:50-53), opens carry the MAC check.  scheme "hbc": the reference's
         # honest-but-curious additive sharing (mpc-snarks/src/proof.rs:379-387 `--alg hbc`; AdditiveFieldShare, share/add.rs:26-29):
         # ONE lane per party, an open is the sum of the parties' lanes (add.rs:256-259), no MAC lane and no check.
-        assert scheme in ("spdz", "hbc")
+        # scheme "gsz": the reference's honest-majority Shamir sharing (`--alg gsz`; GszFieldShare, share/gsz20/mod.rs:115-118): ONE lane per party
+        # holding p(w^j) of a degree-t polynomial with p(0) = the value (t = (n - 1) / 2, :94-96); add / scale are lane-wise, a public addend goes to
+        # EVERY lane (:266-269 shift), and a product is batch_mult (:556-595): lane-wise x * y + r2, the king opens the degree-2t result and
+        # hands the value back to everyone (batch_king_compute with f = identity, :494-527), minus r -- with the reference's stubbed double share
+        # r = r2 = 1 (:394-407).  No Beaver triples.
+        assert scheme in ("spdz", "hbc", "gsz")
         self.scheme = scheme
+        self.gsz_t = (parties - 1) // 2
         self.lpp = 2 if scheme == "spdz" else 1       # share lanes per party
         assert not (mac_msm_from_sh and scheme != "spdz")
         # mac_msm_from_sh: the reference's SPDZ multi_scale_pub_group computes BOTH group shares from the `sh` scalars
@@ -127,6 +143,12 @@ class Groth16Local:
         self.a_query = mk_bases(czk.CZK_G1, N + 1, 3)             # a_query[1..]
         self.b_g1_query = mk_bases(czk.CZK_G1, N + 1, 4, True)
         self.b_g2_query = mk_bases(czk.CZK_G2, N + 1, 5, True)
+        # the rest of the proving key (groth16/src/data_structures.rs:132-149): vk.alpha_g1, beta_g1, delta_g1, a_query[0] in G1 and
+        # vk.beta_g2, vk.delta_g2 in G2, synthetic like the queries; b_g1_query[0] / b_g2_query[0] are infinity in the real key (the constant-one
+        # variable has no B entry).  Host values: create_proof uses them in O(1) group steps.
+        g1x = ctx.fixed_base_points(czk.CZK_G1, rand_fr_canonical(BASE_SEED + 6, 4))
+        g2x = ctx.fixed_base_points(czk.CZK_G2, rand_fr_canonical(BASE_SEED + 7, 2))
+        self.pk = {"alpha_g1": g1x[0], "beta_g1": g1x[1], "delta_g1": g1x[2], "a_query0": g1x[3], "beta_g2": g2x[0], "delta_g2": g2x[1]}
         self.setup_key_s = time.time() - t0
         # czk_ctx_reserve: NTT tables of the witness-map domain and the MSM workspaces for this key's call shapes, built here (like the window
         # tables above) instead of inside the first proof; reported separately (bench.py: reserve_s, part of one_shot_s)
@@ -144,18 +166,41 @@ class Groth16Local:
             chain.append(chain[-1] * chain[-1] % R_MOD)
         wm = to_mont_limbs(chain)                                  # w_0 .. w_N (w_N = public output)
         one = to_mont_limbs([1])[0]
-        # additive sharing on the GPU: parties 0..P-2 uniform, last = value - sum (share/spdz.rs:150-162)
         wd = torch.from_numpy(wm.view(np.int64)).to(dev)
         sh = []
-        rest = wd.clone()
-        for p in range(parties - 1):
-            r = torch.from_numpy(rand_fr_canonical(seed + 17 * (p + 1), N + 1).view(np.int64)).to(dev)
-            rm = torch.empty_like(r)
-            ctx.fr_from_repr(r.data_ptr(), out=rm.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
-            ctx.fr_vec_op(1, rest.data_ptr(), rm.data_ptr(), out=rest.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
-            sh.append(rm)
-        sh.append(rest)
+        if scheme == "gsz":
+            # Shamir sharing on the GPU: party j holds w + sum_{k=1..t} w_n^(j k) c_k, w_n = the order-n root of the share domain (gsz20/mod.rs:98-105),
+            # c_k uniform (poly_share, :214-232: a random polynomial of degree t with the value as its constant coefficient)
+            wn = ctx.share_domain_constants(parties)["group_gen"]
+            wn_int = sum(int(wn[i]) << (64 * i) for i in range(4)) * pow(1 << 256, -1, R_MOD) % R_MOD
+            coef = []
+            for k in range(1, self.gsz_t + 1):
+                c = torch.from_numpy(rand_fr_canonical(seed + 31 * k, N + 1).view(np.int64)).to(dev)
+                ctx.fr_from_repr(c.data_ptr(), out=c.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+                coef.append(c)
+            for j in range(parties):
+                acc = wd.clone()
+                for k, c in enumerate(coef, start=1):
+                    sc = torch.from_numpy(to_mont_limbs([pow(wn_int, j * k, R_MOD)]).view(np.int64)).to(dev)
+                    tmp = torch.empty_like(c)
+                    ctx.fr_vec_scale(c.data_ptr(), sc.data_ptr(), out=tmp.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+                    ctx.fr_vec_op(0, acc.data_ptr(), tmp.data_ptr(), out=acc.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+                    ctx.sync()                         # `sc` / `tmp` are read in stream order: keep them alive until the kernels have run
+                sh.append(acc)
+        else:
+            # additive sharing on the GPU: parties 0..P-2 uniform, last = value - sum (share/spdz.rs:150-162)
+            rest = wd.clone()
+            for p in range(parties - 1):
+                r = torch.from_numpy(rand_fr_canonical(seed + 17 * (p + 1), N + 1).view(np.int64)).to(dev)
+                rm = torch.empty_like(r)
+                ctx.fr_from_repr(r.data_ptr(), out=rm.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+                ctx.fr_vec_op(1, rest.data_ptr(), rm.data_ptr(), out=rest.data_ptr(), n=N + 1, mem=czk.CZK_MEM_DEVICE)
+                sh.append(rm)
+            sh.append(rest)
         ctx.sync()
+        # lanes that take PUBLIC addends (Public + Shared = shift): the king's for additive sharings (spdz.rs:204-208, add.rs:141-146), every lane for
+        # Shamir shares (a constant is added to the polynomial: gsz20/mod.rs:266-269)
+        pub_party = (lambda p: True) if scheme == "gsz" else (lambda p: p == 0)
         one_t = torch.from_numpy(one.view(np.int64)).to(dev)
 
         def lanes_buf():
@@ -173,7 +218,7 @@ class Groth16Local:
                 self.a0[ln, :N] = sh[p][:N]
                 self.b0[ln, :N] = sh[p][:N]
                 self.c0[ln, :N] = sh[p][1:N + 1]
-                if p == 0:
+                if pub_party(p):
                     self.a0[ln, N] = one_t
                 self.a0[ln, N + 1] = sh[p][N]
                 self.wit[ln] = sh[p][:N]
@@ -184,7 +229,7 @@ class Groth16Local:
         for j, p in enumerate(self.local):
             for m in range(lpp):
                 ln = lpp * j + m
-                if p == 0:
+                if pub_party(p):
                     self.full[ln, 0] = one_t
                 self.full[ln, 1] = sh[p][N]
                 self.full[ln, 2:] = sh[p][:N]
@@ -197,10 +242,14 @@ class Groth16Local:
         self.mat_c = ctx.r1cs_matrix_register(rp[: N + 1], np.concatenate([wcols[1:], np.array([1], dtype=np.uint32)]), ones[:N], N + 2)
         # dummy Beaver triples (wire/field.rs:41-60): king holds (1,1,1), everyone else (0,0,0)
         self.tx, self.ty, self.tz = lanes_buf(), lanes_buf(), lanes_buf()
-        self.king_lanes = [lpp * j + m for j, p in enumerate(self.local) if p == 0 for m in range(lpp)]
-        for t in (self.tx, self.ty, self.tz):
-            for ln in self.king_lanes:
-                t[ln, :] = one_t
+        self.king_lanes = [lpp * j + m for j, p in enumerate(self.local) if pub_party(p) for m in range(lpp)]
+        if scheme == "gsz":
+            self.ones = torch.zeros((D, 4), dtype=torch.int64, device=dev)      # the stubbed double share r = r2 = 1 on every party (gsz20/mod.rs:394-407)
+            self.ones[:] = one_t
+        else:
+            for t in (self.tx, self.ty, self.tz):
+                for ln in self.king_lanes:
+                    t[ln, :] = one_t
         self.a, self.b, self.c = lanes_buf(), lanes_buf(), lanes_buf()
         self.sx, self.oy = (torch.zeros((D, 4), dtype=torch.int64, device=dev) for _ in range(2))
         self.chk = torch.zeros((2, D, 4), dtype=torch.int64, device=dev)
@@ -222,14 +271,15 @@ class Groth16Local:
     def _sl(self, t, n):
         """the scalars of this rank's base range, contiguous per lane (the MSM entry points take lanes x n_scalars without a stride)"""
         lo, hi = self.base_range(n)
-        return t if (lo, hi) == (0, n) and t.shape[1] == n else t[:, lo:hi].contiguous()
+        return t if (lo, hi) == (0, n) and t.shape[1] == n and t.is_contiguous() else t[:, lo:hi].contiguous()
 
     def ntt_lanes_per_step(self):
         return 7 * self.lanes
 
     def describe(self):
         return (f"{7 * self.lanes} Fr NTT lanes of 2^{self.log_d} + 5 MSMs x {self.lanes} share lanes per GPU"
-                + ("" if self.scheme == "spdz" else " (HBC: one additive-share lane per party, no MAC lane)"))
+                + {"spdz": "", "hbc": " (HBC: one additive-share lane per party, no MAC lane)",
+                   "gsz": " (GSZ: one Shamir-share lane per party; products by batch_mult with the king's degree-2t open)"}[self.scheme])
 
     # one open of a share vector: value = sum of sh lanes; MAC check vector = mac_share*value - sum(mac lanes)
     def _open(self, shares, out, chk):
@@ -248,6 +298,9 @@ class Groth16Local:
                 vals = parallel.spdz_batch_open(ctx, shares[0], shares[1], self.mac_share, commit=self.commit_opens)
             out.copy_(vals)
             return
+        if self.scheme == "hbc" and self.P == 1:     # a single prover: the "share" is the value
+            out.copy_(shares[0])
+            return
         if self.scheme == "hbc":                     # AdditiveFieldShare::batch_open (share/add.rs:256-259): the sum of the parties' lanes
             ctx.fr_vec_op(ADD, shares[0].data_ptr(), shares[1].data_ptr(), out=out.data_ptr(), n=D, mem=M)
             for p in range(2, self.P):
@@ -259,6 +312,25 @@ class Groth16Local:
         ctx.fr_vec_op(SUB, out.data_ptr(), shares[1].data_ptr(), out=chk.data_ptr(), n=D, mem=M)
         for p in range(1, self.P):
             ctx.fr_vec_op(SUB, chk.data_ptr(), shares[2 * p + 1].data_ptr(), out=chk.data_ptr(), n=D, mem=M)
+
+    def _gsz_batch_mult(self):
+        """gsz20::batch_mult (share/gsz20/mod.rs:556-595) on the lanes of a, b -> ab: x.val *= y.val; x.degree *= 2; x.val += r2.val; the king opens
+        the degree-2t shares and hands the value to every party (batch_king_compute, f = identity: :494-527); shift_res.val -= r.val."""
+        czk, ctx, D, L = self.czk, self.ctx, self.D, self.lanes
+        M, ADD, SUB, MUL = czk.CZK_MEM_DEVICE, 0, 1, 2
+        ctx.fr_vec_op(MUL, self.a.data_ptr(), self.b.data_ptr(), out=self.ab.data_ptr(), n=L * D, mem=M)
+        for ln in range(L):
+            ctx.fr_vec_op(ADD, self.ab[ln].data_ptr(), self.ones.data_ptr(), out=self.ab[ln].data_ptr(), n=D, mem=M)
+        if len(self.local) < self.P:                 # one party per rank: send_to_king, open on the king, recv_from_king
+            assert len(self.local) == 1
+            from . import parallel
+            self.sx.copy_(parallel.gsz_batch_king_compute(ctx, self.ab[0], 2 * self.gsz_t))
+        else:                                        # every party's lane is on this GPU: the king's open is local, its answer is every lane's new share
+            bad = ctx.fr_gsz_open(self.ab.data_ptr(), self.P, D, self.sx.data_ptr(), degree=2 * self.gsz_t)
+            if bad:
+                raise RuntimeError(f"GSZ degree check failed on {bad} of {D} products (assert!(p.degree() <= d), share/gsz20/mod.rs:452)")
+        for ln in range(L):
+            ctx.fr_vec_op(SUB, self.sx.data_ptr(), self.ones.data_ptr(), out=self.ab[ln].data_ptr(), n=D, mem=M)
 
     def new_results(self):
         L = self.lanes // 2 if self.mac_msm_from_sh else self.lanes
@@ -297,14 +369,17 @@ class Groth16Local:
         ctx.r1cs_matvec(self.mat_b, self.full.data_ptr(), lanes=L, out=self.b.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
         ctx.r1cs_matvec(self.mat_c, self.full.data_ptr(), lanes=L, out=self.c.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
         ctx.witness_map_pre(self.a.data_ptr(), self.b.data_ptr(), ld, L, a_len=N + 2, b_len=N)   # ifft, ifft, coset_fft, coset_fft
-        # batch_product_in_place -> S::batch_mul (share/field.rs:97-127): (s + x), (o + y), two opens, combine
-        ctx.fr_vec_op(ADD, self.a.data_ptr(), self.tx.data_ptr(), out=self.a.data_ptr(), n=L * D, mem=M)
-        ctx.fr_vec_op(ADD, self.b.data_ptr(), self.ty.data_ptr(), out=self.b.data_ptr(), n=L * D, mem=M)
-        self._open(self.a, self.sx, self.chk[0])
-        self._open(self.b, self.oy, self.chk[1])
-        for ln in range(L):
-            ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
-                                  self.oy.data_ptr(), ln in self.king_lanes, out=self.ab[ln].data_ptr(), n=D, mem=M)
+        if self.scheme == "gsz":
+            self._gsz_batch_mult()
+        else:
+            # batch_product_in_place -> S::batch_mul (share/field.rs:97-127): (s + x), (o + y), two opens, combine
+            ctx.fr_vec_op(ADD, self.a.data_ptr(), self.tx.data_ptr(), out=self.a.data_ptr(), n=L * D, mem=M)
+            ctx.fr_vec_op(ADD, self.b.data_ptr(), self.ty.data_ptr(), out=self.b.data_ptr(), n=L * D, mem=M)
+            self._open(self.a, self.sx, self.chk[0])
+            self._open(self.b, self.oy, self.chk[1])
+            for ln in range(L):
+                ctx.fr_beaver_combine(self.tx[ln].data_ptr(), self.ty[ln].data_ptr(), self.tz[ln].data_ptr(), self.sx.data_ptr(),
+                                      self.oy.data_ptr(), ln in self.king_lanes, out=self.ab[ln].data_ptr(), n=D, mem=M)
         ctx.witness_map_post(self.ab.data_ptr(), self.c.data_ptr(), ld, L, c_len=N)     # h = ab
         # --- the h MSM (prover.rs:104) needs the witness map's output; NOT flagged stable: the next proof's witness
         # map overwrites `ab`, so the context's stream waits for this MSM's digit extraction (library-side ordering)
@@ -341,6 +416,53 @@ class Groth16Local:
         ctx.msm_async(self.h_query, self.ab_sh.data_ptr(), D, P, MONT, r["h"])
         if sync:
             ctx.sync()
+
+    def create_proof(self, res, r, s):
+        """The rest of create_proof (mpc-snarks/src/groth/prover.rs:110-178) after the five MSMs `res` of step(): calculate_coeff (:216-232:
+        `initial + query[0] + acc + vk_param`) for A, B in G1 and B in G2, and C = s A + r B1 - r s delta + l_acc + h_acc, for PUBLIC r, s
+        (canonical (4,) uint64) -- the case that needs no group-level Beaver step: every operation is linear in the shares.  Public group
+        elements meet a share through `shift` (MpcGroup Public + Shared: share/spdz.rs group shift, add.rs:141-146): the king adds them on
+        its lanes (sh, and mac with the stand-in key 1), every other lane adds nothing.  Returns the lanes' shares of Proof{a, b, c} as
+        Jacobian limbs {"a": (L, 18), "b": (L, 36), "c": (L, 18)}; summing the parties' sh lanes gives the proof itself.  Host-side O(1)
+        group arithmetic through the C ABI (czk_jac_scalar_mul / czk_jac_add / czk_jac_add_mixed / czk_jac_neg)."""
+        czk, ctx = self.czk, self.ctx
+        G1, G2 = czk.CZK_G1, czk.CZK_G2
+        res = self.expand_results(res)
+        pk = self.pk
+        r, s = np.ascontiguousarray(r, np.uint64).reshape(4), np.ascontiguousarray(s, np.uint64).reshape(4)
+
+        def proj(group, aff):                                   # GroupAffine::into_projective
+            one = to_mont_limbs_fq(1)
+            return np.concatenate([aff, one if group == G1 else np.concatenate([one, np.zeros(6, np.uint64)])]).astype(np.uint64)
+        delta_g1, delta_g2 = proj(G1, pk["delta_g1"]), proj(G2, pk["delta_g2"])
+        r_s_delta_g1 = ctx.jac_scalar_mul(G1, ctx.jac_scalar_mul(G1, delta_g1, r), s)            # :113-117
+        r_g1 = ctx.jac_scalar_mul(G1, delta_g1, r)                                               # :128
+        s_g1 = ctx.jac_scalar_mul(G1, delta_g1, s)                                               # :144
+        s_g2 = ctx.jac_scalar_mul(G2, delta_g2, s)                                               # :156
+
+        def calculate_coeff(group, initial, el_aff, el_inf, acc, vk_param, king):               # :216-232, on one share lane
+            if not king:                                        # Public + Shared = shift: only the king's lanes take the public addends
+                return acc.copy()
+            out = ctx.jac_add_mixed(group, initial, el_aff, el_inf)                              # res = initial; res.add_assign_mixed(&el)
+            out = ctx.jac_add(group, out, acc)                                                   # res += &acc
+            return ctx.jac_add_mixed(group, out, vk_param, False)                                # res.add_assign_mixed(&vk_param)
+        L = res["h"].shape[0]
+        out = {"a": np.zeros((L, 18), np.uint64), "b": np.zeros((L, 36), np.uint64), "c": np.zeros((L, 18), np.uint64)}
+        inf1, inf2 = np.zeros(12, np.uint64), np.zeros(24, np.uint64)
+        for ln in range(L):
+            king = ln in self.king_lanes
+            g_a = calculate_coeff(G1, r_g1, pk["a_query0"], False, res["a"][ln], pk["alpha_g1"], king)          # :135
+            s_g_a = ctx.jac_scalar_mul(G1, g_a, s)                                                                # :138
+            g1_b = calculate_coeff(G1, s_g1, inf1, True, res["b_g1"][ln], pk["beta_g1"], king)                   # :145
+            g2_b = calculate_coeff(G2, s_g2, inf2, True, res["b_g2"][ln], pk["beta_g2"], king)                   # :157
+            r_g1_b = ctx.jac_scalar_mul(G1, g1_b, r)                                                              # :158
+            g_c = ctx.jac_add(G1, s_g_a, r_g1_b)                                                                  # :165-166
+            if king:
+                g_c = ctx.jac_add(G1, g_c, ctx.jac_neg(G1, r_s_delta_g1))                                         # g_c -= &r_s_delta_g1
+            g_c = ctx.jac_add(G1, g_c, res["l"][ln])                                                              # :168
+            g_c = ctx.jac_add(G1, g_c, res["h"][ln])                                                              # :169
+            out["a"][ln], out["b"][ln], out["c"][ln] = g_a, g2_b, g_c
+        return out
 
     def msm_scalars(self):
         """{query: device tensor of the Montgomery scalars its MSM consumed (lanes, n, 4)}; `h` is the LAST proof's."""

@@ -71,7 +71,10 @@ typedef enum {
      * -- what the reference does when it deserialises a key (:868, :881) -- and keeps the handle on the complete XYZZ kernels when any
      * base fails, exactly as CZK_MEM_ANY_POINTS would.  czk_bases_check_subgroup then reports the count without re-running.  Costs about
      * as much as building the window tables (252 doublings + 87 additions per point; 2^20 G1 points: ~0.1 s). */
-    CZK_MEM_CHECK_SUBGROUP = 128
+    CZK_MEM_CHECK_SUBGROUP = 128,
+    /* czk_fr_vec_scale only, OR-ed with CZK_MEM_DEVICE: the vectors are device memory, the scalar `k` is HOST memory, read when the call is
+     * made and handed to the kernel with the launch -- no device copy of a 32-byte value, no lifetime to observe. */
+    CZK_MEM_SCALAR_HOST = 256
 } czk_mem;
 
 /* EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (algebra/poly/src/domain/mod.rs:79,90,139,155) */
@@ -138,6 +141,14 @@ int czk_lanes_copy(czk_ctx* ctx, czk_lanes* dst, size_t dst_lane, size_t dst_ele
                    size_t n);
 int czk_lanes_zero(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t elem, size_t n);
 
+/* Strided copy / zero fill of Fr elements in DEVICE memory, in stream order: for i0 < n[0], i1 < n[1], i2 < n[2]
+ *     dst[i0 * dst_stride[0] + i1 * dst_stride[1] + i2 * dst_stride[2]] = src[i0 * src_stride[0] + i1 * src_stride[1] + i2 * src_stride[2]]
+ * (strides in Fr elements; src NULL: the destination elements become zero).  One kernel for every re-layout a prover's polynomial code does
+ * between transforms -- `resize`, `coeffs[k..].to_vec()`, concatenation of coefficient ranges, stacking share lanes, and the interleave /
+ * de-interleave by a stride of mpc-plonk's `shift` products (mpc-plonk/src/lib.rs:150-200) and Marlin's matrix polynomials
+ * (marlin/src/ahp/prover.rs:500-640) -- so a host needs no tensor library for them.  Source and destination ranges must not overlap. */
+int czk_fr_copy_3d(czk_ctx* ctx, uint64_t* dst, const size_t* dst_stride, const uint64_t* src, const size_t* src_stride, const size_t* n);
+
 /* ---- NTT ---------------------------------------------------------------------------------------- */
 /* Replaces Radix2EvaluationDomain<Fr>::{fft,ifft,coset_ifft}_in_place (algebra/poly/src/domain/radix2/mod.rs:99-117)
  * and the trait-default coset_fft_in_place (domain/mod.rs:139-142) for T = Fr lanes (an MpcField<Fr, SpdzFieldShare>
@@ -174,7 +185,9 @@ int czk_mixed_domain_constants(czk_ctx* ctx, size_t size, uint64_t* out24);
 /* out[i] = a[i] op b[i], n elements of 4 u64; out may alias a or b.  r1cs_to_qap.rs:92 (plain product), :105-107 (sub). */
 typedef enum { CZK_OP_ADD = 0, CZK_OP_SUB = 1, CZK_OP_MUL = 2 } czk_binop;
 int czk_fr_vec_op(czk_ctx* ctx, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n, int mem);
-/* out[i] = a[i] * k  (k: one Montgomery Fr in the SAME memory space as a / out; domain/mod.rs:184-191) */
+/* out[i] = a[i] * k  (k: one Montgomery Fr in the SAME memory space as a / out; domain/mod.rs:184-191).  In DEVICE memory the call only
+ * enqueues and the kernel reads `k` in stream order: `k` must stay valid and unmodified until the context's stream has passed this call (the
+ * same holds for czk_ntt_fr_to's `src`). */
 int czk_fr_vec_scale(czk_ctx* ctx, const uint64_t* a, const uint64_t* k, uint64_t* out, size_t n, int mem);
 /* out[i] = c * g^i for i < n (g, c: one Montgomery Fr each, HOST memory; c NULL = one): the table behind
  * EvaluationDomain::distribute_powers / distribute_powers_and_mul_by_const (algebra/poly/src/domain/mod.rs:93-106) for any g --
@@ -414,6 +427,12 @@ int czk_jac_to_affine(czk_ctx* ctx, int group, const uint64_t* jac, size_t n, ui
  * `commitment.add_assign_mixed(&random_commitment)`, poly-commit/src/kzg10/mod.rs:188).  Host arithmetic; ctx may be NULL. */
 int czk_jac_add(czk_ctx* ctx, int group, const uint64_t* a_jac, const uint64_t* b_jac, uint64_t* out_jac);
 int czk_jac_add_mixed(czk_ctx* ctx, int group, const uint64_t* a_jac, const uint64_t* b_aff, int b_inf, uint64_t* out_jac);
+/* ProjectiveCurve::mul / scalar_mul (algebra/ec/src/lib.rs:215-230: double-and-add over the scalar's bits, most significant first) and Neg
+ * (short_weierstrass_jacobian.rs:737-748: (x, -y, z)) on host Jacobian values: `pk.delta_g1.scalar_mul(r)`, `g_a.scalar_mul(&s)`,
+ * `g_c -= &r_s_delta_g1` of create_proof (mpc-snarks/src/groth/prover.rs:113-165).  k: one Fr, HOST memory, `scalar_form` as for the MSM.
+ * Host arithmetic (about a millisecond per G1 multiplication); ctx may be NULL. */
+int czk_jac_scalar_mul(czk_ctx* ctx, int group, const uint64_t* a_jac, const uint64_t* k, int scalar_form, uint64_t* out_jac);
+int czk_jac_neg(czk_ctx* ctx, int group, const uint64_t* a_jac, uint64_t* out_jac);
 
 /* Synthetic public bases P_i = [k_i] * generator for i < n, k_i = canonical scalars (n x 4 u64), written as
  * affine Montgomery points to `out` (device or host).  Stands in for a trusted-setup run when benchmarking

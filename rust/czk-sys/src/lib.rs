@@ -16,6 +16,10 @@ pub struct czk_lanes {
     _private: [u8; 0],
 }
 #[repr(C)]
+pub struct czk_net {
+    _private: [u8; 0],
+}
+#[repr(C)]
 pub struct czk_r1cs_matrix {
     _private: [u8; 0],
 }
@@ -25,12 +29,15 @@ pub const CZK_ERR_SIZE: c_int = 1; // czk_status
 pub const CZK_ERR_HIP: c_int = 2; // czk_status
 pub const CZK_ERR_ARG: c_int = 3; // czk_status
 pub const CZK_ERR_NOMEM: c_int = 4; // czk_status
+pub const CZK_ERR_NET: c_int = 5; // czk_status
+pub const CZK_ERR_CHECK: c_int = 6; // czk_status
 pub const CZK_MEM_HOST: c_int = 0; // czk_mem
 pub const CZK_MEM_DEVICE: c_int = 1; // czk_mem
 pub const CZK_MEM_STABLE: c_int = 16; // czk_mem
 pub const CZK_MEM_NO_TABLES: c_int = 32; // czk_mem
 pub const CZK_MEM_ANY_POINTS: c_int = 64; // czk_mem
 pub const CZK_MEM_CHECK_SUBGROUP: c_int = 128; // czk_mem
+pub const CZK_MEM_SCALAR_HOST: c_int = 256; // czk_mem
 pub const CZK_FFT: c_int = 0; // czk_ntt_kind
 pub const CZK_IFFT: c_int = 1; // czk_ntt_kind
 pub const CZK_COSET_FFT: c_int = 2; // czk_ntt_kind
@@ -42,6 +49,10 @@ pub const CZK_G2: c_int = 2; // czk_group
 pub const CZK_OP_ADD: c_int = 0; // czk_binop
 pub const CZK_OP_SUB: c_int = 1; // czk_binop
 pub const CZK_OP_MUL: c_int = 2; // czk_binop
+pub const CZK_NET_RCCL: c_int = 1; // czk_net_transport
+pub const CZK_NET_SHM: c_int = 2; // czk_net_transport
+pub const CZK_NET_UNIQUE_ID_BYTES: c_int = 128; // #define
+pub const CZK_OPEN_COMMIT: c_int = 1; // #define
 
 #[link(name = "czk_hip")]
 extern "C" {
@@ -63,6 +74,7 @@ extern "C" {
     pub fn czk_lanes_download(ctx: *mut czk_ctx, src: *const czk_lanes, lane: usize, elem: usize, host: *mut u64, n: usize) -> c_int;
     pub fn czk_lanes_copy(ctx: *mut czk_ctx, dst: *mut czk_lanes, dst_lane: usize, dst_elem: usize, src: *const czk_lanes, src_lane: usize, src_elem: usize, n: usize) -> c_int;
     pub fn czk_lanes_zero(ctx: *mut czk_ctx, dst: *mut czk_lanes, lane: usize, elem: usize, n: usize) -> c_int;
+    pub fn czk_fr_copy_3d(ctx: *mut czk_ctx, dst: *mut u64, dst_stride: *const usize, src: *const u64, src_stride: *const usize, n: *const usize) -> c_int;
     pub fn czk_ntt_fr(ctx: *mut czk_ctx, data: *mut u64, log_d: c_uint, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
     pub fn czk_ntt_fr_to(ctx: *mut czk_ctx, src: *const u64, src_stride: usize, dst: *mut u64, log_d: c_uint, lanes: usize, kind: c_int, in_len: usize, mem: c_int) -> c_int;
     pub fn czk_domain_constants(ctx: *mut czk_ctx, log_d: c_uint, out24: *mut u64) -> c_int;
@@ -77,6 +89,29 @@ extern "C" {
     pub fn czk_fr_spdz_dx(ctx: *mut czk_ctx, value: *const u64, mac: *const u64, mac_share: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn czk_share_domain_constants(ctx: *mut czk_ctx, parties: usize, out12: *mut u64) -> c_int;
     pub fn czk_fr_gsz_open(ctx: *mut czk_ctx, shares: *const u64, parties: usize, n: usize, degrees: *const u32, degree: c_uint, out_value: *mut u64, out_bad: *mut u64) -> c_int;
+    pub fn czk_net_unique_id(transport: c_int, out: *mut u8, cap: usize, len: *mut usize) -> c_int;
+    pub fn czk_net_create(ctx: *mut czk_ctx, transport: c_int, rank: c_int, world: c_int, id: *const u8, id_len: usize, out: *mut *mut czk_net) -> c_int;
+    pub fn czk_net_destroy(net: *mut czk_net);
+    pub fn czk_net_rank(net: *const czk_net) -> c_int;
+    pub fn czk_net_world(net: *const czk_net) -> c_int;
+    pub fn czk_net_set_option(net: *mut czk_net, name: *const c_char, value: c_long) -> c_int;
+    pub fn czk_net_last_error(net: *const czk_net) -> *const c_char;
+    pub fn czk_net_stats(net: *const czk_net, out5: *mut u64) -> c_int;
+    pub fn czk_net_stats_reset(net: *mut czk_net);
+    pub fn czk_net_broadcast(net: *mut czk_net, send: *const c_void, bytes: usize, recv: *mut c_void, mem: c_int) -> c_int;
+    pub fn czk_net_send_to_king(net: *mut czk_net, send: *const c_void, bytes: usize, recv: *mut c_void, mem: c_int) -> c_int;
+    pub fn czk_net_recv_from_king(net: *mut czk_net, send: *const c_void, bytes: usize, recv: *mut c_void, mem: c_int) -> c_int;
+    pub fn czk_net_barrier(net: *mut czk_net) -> c_int;
+    pub fn czk_net_atomic_broadcast(net: *mut czk_net, x: *const u64, n: usize, recv: *mut u64, rand32: *const u8, mem: c_int) -> c_int;
+    pub fn czk_spdz_batch_open(net: *mut czk_net, sh: *const u64, mac: *const u64, mac_share: *const u64, n: usize, out_value: *mut u64, flags: c_int, out_bad: *mut u64) -> c_int;
+    pub fn czk_add_batch_open(net: *mut czk_net, val: *const u64, n: usize, out_value: *mut u64) -> c_int;
+    pub fn czk_gsz_batch_open(net: *mut czk_net, val: *const u64, n: usize, degrees: *const u32, degree: c_uint, out_value: *mut u64, out_bad: *mut u64) -> c_int;
+    pub fn czk_fr_send_to_king(net: *mut czk_net, x: *const u64, n: usize, gathered: *mut u64) -> c_int;
+    pub fn czk_fr_recv_from_king(net: *mut czk_net, parts: *const u64, n: usize, out: *mut u64) -> c_int;
+    pub fn czk_gsz_batch_king_compute(net: *mut czk_net, val: *const u64, n: usize, degrees: *const u32, degree: c_uint, out: *mut u64, out_bad: *mut u64) -> c_int;
+    pub fn czk_fr_vec_serialize(ctx: *mut czk_ctx, a: *const u64, n: usize, mem: c_int, out: *mut u8) -> c_int;
+    pub fn czk_fr_vec_deserialize(ctx: *mut czk_ctx, bytes: *const u8, len: usize, out: *mut u64, cap: usize, mem: c_int, n: *mut usize) -> c_int;
+    pub fn czk_sha256(data: *const c_void, len: usize, out32: *mut u8);
     pub fn czk_r1cs_matrix_register(ctx: *mut czk_ctx, row_ptr: *const u64, col_idx: *const u32, coeff: *const u64, m: usize, nnz: usize, n_vars: usize, mem: c_int, out: *mut *mut czk_r1cs_matrix) -> c_int;
     pub fn czk_r1cs_matrix_release(a: *mut czk_r1cs_matrix);
     pub fn czk_r1cs_matvec(ctx: *mut czk_ctx, a: *const czk_r1cs_matrix, z: *const u64, z_stride: usize, lanes: usize, out: *mut u64, out_stride: usize, mem: c_int) -> c_int;
@@ -101,6 +136,8 @@ extern "C" {
     pub fn czk_jac_to_affine(ctx: *mut czk_ctx, group: c_int, jac: *const u64, n: usize, out_aff: *mut u64, out_inf: *mut u8) -> c_int;
     pub fn czk_jac_add(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, b_jac: *const u64, out_jac: *mut u64) -> c_int;
     pub fn czk_jac_add_mixed(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, b_aff: *const u64, b_inf: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_jac_scalar_mul(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, k: *const u64, scalar_form: c_int, out_jac: *mut u64) -> c_int;
+    pub fn czk_jac_neg(ctx: *mut czk_ctx, group: c_int, a_jac: *const u64, out_jac: *mut u64) -> c_int;
     pub fn czk_fixed_base_points(ctx: *mut czk_ctx, group: c_int, k: *const u64, n: usize, out: *mut u64, mem: c_int) -> c_int;
     pub fn czk_witness_map_pre(ctx: *mut czk_ctx, a: *mut u64, a_len: usize, b: *mut u64, b_len: usize, log_d: c_uint, lanes: usize) -> c_int;
     pub fn czk_witness_map_post(ctx: *mut czk_ctx, ab: *mut u64, c: *mut u64, c_len: usize, log_d: c_uint, lanes: usize) -> c_int;

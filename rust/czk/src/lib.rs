@@ -9,6 +9,10 @@
 //! * resident path -- share vectors that stay on the GPU across the witness map and feed the `h` MSM
 //!   (mpc-snarks/src/groth/r1cs_to_qap.rs:85-110, mpc-snarks/src/groth/prover.rs:104): [`resident::DeviceLanes`],
 //!   [`resident::witness_map`], [`msm::Pinned::msm_resident`] -- `czk_lanes_*` handles, no HIP allocator on the Rust side
+//! * opens -- `MpcMultiNet::{broadcast, send_to_king, recv_from_king}` (mpc-net/src/multi.rs:145-242) and
+//!   `SpdzFieldShare / AdditiveFieldShare / GszFieldShare::batch_open` (share/spdz.rs:166-185, add.rs:256-259, gsz20/mod.rs:286-300)
+//!   between parties that are GPUs: [`net::Net`] -- `czk_net_*`: RCCL over xGMI (or shared memory between processes of one node), on
+//!   resident lanes, enqueued on the party's stream
 //!
 //! Error convention: the reference panics (`assert!`, `unwrap()`, `None.unwrap()`); every wrapper here `expect()`s the C
 //! status with the library's error text, so behaviour at the seams is unchanged.
@@ -653,5 +657,127 @@ pub mod resident {
         }
         ab.len = d;
         c.len = d;
+    }
+}
+
+pub mod net {
+    //! mpc-net between GPUs.  The reference's parties exchange share vectors through the process-global `MpcMultiNet`
+    //! (mpc-net/src/multi.rs:15-23, one TCP connection per pair); with the share lanes resident in HBM the same four primitives and
+    //! the three batch opens run through a `czk_net` communicator instead -- RCCL over xGMI when every party owns a GPU, shared
+    //! memory when parties share one -- enqueued on the party's stream, so `witness_map` never leaves HBM.  The
+    //! communicator id travels over the reference's own sockets once, at start-up (`Net::init_rccl`).
+    //! Compiled and GPU-tested as C++: `czk::Net` (include/czk.hpp), `tools/host_demo.cpp party`.
+    use super::resident::DeviceLanes;
+    use super::{sys, CTX};
+    use ark_bls12_377::Fr;
+    use std::ffi::CStr;
+    use std::os::raw::c_int;
+
+    pub struct Net {
+        raw: *mut sys::czk_net,
+    }
+    unsafe impl Send for Net {}
+
+    /// mpc-net/src/lib.rs `Stats`
+    #[derive(Debug, Default, Clone, Copy)]
+    pub struct Stats {
+        pub bytes_sent: u64,
+        pub bytes_recv: u64,
+        pub broadcasts: u64,
+        pub to_king: u64,
+        pub from_king: u64,
+    }
+
+    impl Net {
+        /// rank 0 only: the 128 bytes the other parties need for `init_rccl` -- send them with `MpcMultiNet::recv_from_king`
+        pub fn unique_id_rccl() -> Vec<u8> {
+            let mut id = vec![0u8; sys::CZK_NET_UNIQUE_ID_BYTES as usize];
+            let mut len = 0usize;
+            let rc = unsafe { sys::czk_net_unique_id(sys::CZK_NET_RCCL, id.as_mut_ptr(), id.len(), &mut len) };
+            assert!(rc == sys::CZK_OK, "czk_net_unique_id: status {} (librccl.so.1 not loadable?)", rc);
+            id.truncate(len);
+            id
+        }
+        /// one party per GPU: `party_id` / `n_parties` as `MpcMultiNet` reports them, `id` from rank 0's `unique_id_rccl`
+        pub fn init_rccl(party_id: usize, n_parties: usize, id: &[u8]) -> Net {
+            Net::create(sys::CZK_NET_RCCL, party_id, n_parties, id)
+        }
+        /// parties are processes of one node in any assignment to GPUs (tests, rigs with fewer GPUs than parties): `id` = 1..32 bytes
+        pub fn init_shm(party_id: usize, n_parties: usize, id: &[u8]) -> Net {
+            Net::create(sys::CZK_NET_SHM, party_id, n_parties, id)
+        }
+        fn create(transport: c_int, party_id: usize, n_parties: usize, id: &[u8]) -> Net {
+            let ctx = CTX.lock().unwrap();
+            let mut raw: *mut sys::czk_net = std::ptr::null_mut();
+            let rc = unsafe { sys::czk_net_create(ctx.as_ptr(), transport, party_id as c_int, n_parties as c_int, id.as_ptr(), id.len(), &mut raw) };
+            ctx.expect(rc, "czk_net_create");
+            Net { raw }
+        }
+        fn expect(&self, rc: c_int, what: &str) {
+            if rc != sys::CZK_OK {
+                let msg = unsafe { CStr::from_ptr(sys::czk_net_last_error(self.raw)) }.to_string_lossy().into_owned();
+                panic!("{}: czk status {}: {}", what, rc, msg);
+            }
+        }
+        pub fn party_id(&self) -> usize {
+            unsafe { sys::czk_net_rank(self.raw) as usize }
+        }
+        pub fn n_parties(&self) -> usize {
+            unsafe { sys::czk_net_world(self.raw) as usize }
+        }
+        pub fn am_king(&self) -> bool {
+            self.party_id() == 0
+        }
+        pub fn stats(&self) -> Stats {
+            let mut s = [0u64; 5];
+            let rc = unsafe { sys::czk_net_stats(self.raw, s.as_mut_ptr()) };
+            self.expect(rc, "czk_net_stats");
+            Stats { bytes_sent: s[0], bytes_recv: s[1], broadcasts: s[2], to_king: s[3], from_king: s[4] }
+        }
+        /// `Net::broadcast_bytes` on host bytes (mpc-net/src/lib.rs:44-47)
+        pub fn broadcast_bytes(&self, out: &[u8]) -> Vec<Vec<u8>> {
+            let mut flat = vec![0u8; out.len() * self.n_parties()];
+            let rc = unsafe { sys::czk_net_broadcast(self.raw, out.as_ptr() as *const _, out.len(), flat.as_mut_ptr() as *mut _, sys::CZK_MEM_HOST) };
+            self.expect(rc, "czk_net_broadcast");
+            flat.chunks(out.len().max(1)).take(self.n_parties()).map(|c| c.to_vec()).collect()
+        }
+        /// `SpdzFieldShare::batch_open` (share/spdz.rs:166-185) on resident lanes: lane 0 of `shares` = sh, lane 1 = mac; the opened
+        /// (public) vector lands in lane 0 of `out`.  Panics where the reference asserts (MAC check).
+        pub fn spdz_batch_open(&self, shares: &DeviceLanes, mac_share: &Fr, n: usize, out: &mut DeviceLanes, commit: bool) {
+            let mut ms = [0u64; 4];
+            super::limbs::fr_to(mac_share, &mut ms);
+            let mut bad = 0u64;
+            let rc = unsafe {
+                sys::czk_spdz_batch_open(self.raw, shares.data(0, 0), shares.data(1, 0), ms.as_ptr(), n, out.data(0, 0),
+                                         if commit { sys::CZK_OPEN_COMMIT } else { 0 }, &mut bad)
+            };
+            self.expect(rc, "czk_spdz_batch_open");
+            assert!(bad == 0, "assertion failed: sum.is_zero() (SPDZ MAC check on {} values)", bad);
+        }
+        /// `AdditiveFieldShare::batch_open` (share/add.rs:256-259)
+        pub fn add_batch_open(&self, val: &DeviceLanes, n: usize, out: &mut DeviceLanes) {
+            let rc = unsafe { sys::czk_add_batch_open(self.raw, val.data(0, 0), n, out.data(0, 0)) };
+            self.expect(rc, "czk_add_batch_open");
+        }
+        /// `GszFieldShare::batch_open` (share/gsz20/mod.rs:286-300) with one degree bound
+        pub fn gsz_batch_open(&self, val: &DeviceLanes, n: usize, degree: u32, out: &mut DeviceLanes) {
+            let mut bad = 0u64;
+            let rc = unsafe { sys::czk_gsz_batch_open(self.raw, val.data(0, 0), n, std::ptr::null(), degree, out.data(0, 0), &mut bad) };
+            self.expect(rc, "czk_gsz_batch_open");
+            assert!(bad == 0, "assertion failed: p.degree() <= d ({} values)", bad);
+        }
+        /// `gsz20::batch_king_compute(shares, new_degree, |r| r)` (share/gsz20/mod.rs:494-527): the degree reduction inside `batch_mult`
+        pub fn gsz_batch_king_compute(&self, val: &DeviceLanes, n: usize, degree: u32, out: &mut DeviceLanes) {
+            let mut bad = 0u64;
+            let rc = unsafe { sys::czk_gsz_batch_king_compute(self.raw, val.data(0, 0), n, std::ptr::null(), degree, out.data(0, 0), &mut bad) };
+            self.expect(rc, "czk_gsz_batch_king_compute");
+            assert!(bad == 0, "assertion failed: p.degree() <= d on the king ({} values)", bad);
+        }
+    }
+
+    impl Drop for Net {
+        fn drop(&mut self) {
+            unsafe { sys::czk_net_destroy(self.raw) }
+        }
     }
 }

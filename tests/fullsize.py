@@ -115,7 +115,7 @@ def _groth16_case(log_n):
         del a0, b0
         want = orc.groth16_local_par(log_d, N, a1, b1, c1, wit, asg, keys["h"], keys["l"], keys["a"], keys["b_g1"], keys["b_g2"], infs["b_g1"],
                                      threads=min(orc.max_threads(), 32))
-        out = {f"h_lane{ln}": a1[ln].tobytes() for ln in range(L)}          # a1 ends as h (in place)
+        out = {f"hvec_lane{ln}": a1[ln].tobytes() for ln in range(L)}       # a1 ends as h (in place): the quotient's coefficients on every lane
         for q, (name, g, _, _) in enumerate(GROTH16_QUERIES):
             w = 18 if g == 1 else 36
             for ln in range(L):
@@ -152,6 +152,7 @@ def load() -> dict:
 
 
 _live = None
+_live_results = {}     # the live case's recomputed parts (two hosts may be checked against the same case)
 live_log = []          # (case id, "live") of what this session recomputed: tests may assert / report on it
 
 
@@ -172,7 +173,10 @@ def expect(case_id: str, got: dict, orc, parts=None):
     for k in names:
         assert hashlib.sha256(got[k]).hexdigest() == want[k], f"{case_id}/{k}: the GPU result differs from the checker's committed digest"
     if live_case() in (case_id, "all"):
-        live = CASES[case_id](orc)
+        if case_id not in _live_results:
+            _live_results.clear()
+            _live_results[case_id] = CASES[case_id](orc)
+        live = _live_results[case_id]
         for k in names:
             assert got[k] == live[k], f"{case_id}/{k}: the GPU result differs from the checker's live result"
         assert digest_parts(live) == want, f"{case_id}: the checker's live result differs from its committed digest (regenerate tests/golden/fullsize_digests.json?)"

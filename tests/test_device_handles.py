@@ -92,6 +92,54 @@ def beaver_shortcut_lanes(orc, a0, b0, c0):
     return a1, b1, c0.copy()
 
 
+def groth16_pk_extras(orc_or_ctx_points):
+    """the synthetic key's remaining elements (provers.py / groth16_host.hpp): G1 [alpha_g1, beta_g1, delta_g1, a_query0] = [k] G for
+    k = rand_fr_canonical(0xBA5E5 + 6, 4), G2 [beta_g2, delta_g2] for rand_fr_canonical(0xBA5E5 + 7, 2); `orc_or_ctx_points(g, k)` -> affine"""
+    g1 = orc_or_ctx_points(1, rand_fr_canonical(0xBA5E5 + 6, 4))
+    g2 = orc_or_ctx_points(2, rand_fr_canonical(0xBA5E5 + 7, 2))
+    return {"alpha_g1": g1[0], "beta_g1": g1[1], "delta_g1": g1[2], "a_query0": g1[3], "beta_g2": g2[0], "delta_g2": g2[1]}
+
+
+def checker_create_proof(orc, pk, res, r, s, king_lanes):
+    """create_proof after its MSMs (mpc-snarks/src/groth/prover.rs:110-178) and calculate_coeff (:216-232) restated with the CHECKER's group
+    law, lane by lane, for public r, s (canonical limbs).  res: {"h","l","a","b_g1","b_g2"} -> per-lane Jacobian limbs.  Public group elements
+    are added on the king's lanes only (Public + Shared = shift).  Returns per lane {"a","b","c"} -> (affine limbs, infinity flag)."""
+    from util import ints_to_limbs
+    neg_one = ints_to_limbs([R_MOD - 1], 4)[0]
+
+    def mul(g, jac, k):                                            # ProjectiveCurve::mul (algebra/ec/src/lib.rs:215-226) through the affine form
+        aff, inf = orc.jac_to_affine(g, jac)
+        return orc.scalar_mul(g, aff, bool(inf), k)
+
+    def proj(g, aff):                                              # into_projective
+        return orc.scalar_mul(g, aff, False, ints_to_limbs([1], 4)[0])
+    delta_g1, delta_g2 = proj(1, pk["delta_g1"]), proj(2, pk["delta_g2"])
+    r_s_delta_g1 = mul(1, mul(1, delta_g1, r), s)
+    r_g1, s_g1, s_g2 = mul(1, delta_g1, r), mul(1, delta_g1, s), mul(2, delta_g2, s)
+
+    def calculate_coeff(g, initial, el, el_inf, acc, vk_param, king):
+        if not king:
+            return acc
+        out = orc.jac_add_mixed(g, initial, el, el_inf)            # res = initial; res.add_assign_mixed(&el)
+        out = orc.jac_add(g, out, acc)                              # res += &acc
+        return orc.jac_add_mixed(g, out, vk_param, False)          # res.add_assign_mixed(&vk_param)
+    out = []
+    for ln in range(len(res["h"])):
+        king = ln in king_lanes
+        g_a = calculate_coeff(1, r_g1, pk["a_query0"], False, res["a"][ln], pk["alpha_g1"], king)
+        s_g_a = mul(1, g_a, s)
+        g1_b = calculate_coeff(1, s_g1, np.zeros(12, np.uint64), True, res["b_g1"][ln], pk["beta_g1"], king)
+        g2_b = calculate_coeff(2, s_g2, np.zeros(24, np.uint64), True, res["b_g2"][ln], pk["beta_g2"], king)
+        r_g1_b = mul(1, g1_b, r)
+        g_c = orc.jac_add(1, s_g_a, r_g1_b)
+        if king:
+            g_c = orc.jac_add(1, g_c, mul(1, r_s_delta_g1, neg_one))   # g_c -= &r_s_delta_g1  (-X = [r - 1] X in the prime-order subgroup)
+        g_c = orc.jac_add(1, g_c, res["l"][ln])
+        g_c = orc.jac_add(1, g_c, res["h"][ln])
+        out.append({"a": orc.jac_to_affine(1, g_a), "b": orc.jac_to_affine(2, g2_b), "c": orc.jac_to_affine(1, g_c)})
+    return out
+
+
 def test_beaver_shortcut_equals_explicit_sequence(orc):
     """CPU: the algebraic shortcut the full-size GPU test feeds to the all-core checker is the explicit Beaver sequence."""
     a0, b0, c0, _, _, log_d, one = groth16_inputs(orc, 50)
@@ -206,6 +254,14 @@ def _read_dump(path):
         inf = raw[off:off + L].copy()
         off += L
         pts[name] = (aff, inf)
+    proofs = []                                                    # per lane: {"a": (aff, inf), "b": ..., "c": ...} -- create_proof for public r, s
+    for _ in range(L):
+        pr = {}
+        for key, aw in (("a", 12), ("b", 24), ("c", 12)):
+            pr[key] = (raw[off:off + aw * 8].view(np.uint64).copy(), int(raw[off + aw * 8]))
+            off += aw * 8 + 1
+        proofs.append(pr)
+    pts["proofs"] = proofs
     assert off == raw.size
     return N, D, L, h, pts
 
@@ -240,36 +296,56 @@ def test_cpp_host_on_device_handles_matches_checker(ctx, czk, orc, tmp_path, n_c
     for ln in range(L):
         assert np.array_equal(h_gpu[ln], want_h[ln]), ln
     scal = {"h": h_gpu, "l": wit, "a": asg, "b_g1": asg, "b_g2": asg}
+    want_jac = {}
     for name, (g, bases, inf) in _query_bases(ctx, czk, N, D).items():
+        want_jac[name] = []
         for ln in range(L):
-            want, winf = orc.jac_to_affine(g, orc.multi_scalar_mul(g, bases, inf, scal[name][ln].reshape(-1, 4)))
+            jac = orc.multi_scalar_mul(g, bases, inf, scal[name][ln].reshape(-1, 4))
+            want_jac[name].append(jac)
+            want, winf = orc.jac_to_affine(g, jac)
             assert bool(pts[name][1][ln]) == winf and (winf or np.array_equal(pts[name][0][ln], want)), (name, ln)
+    # ... and the PROOF: every lane's share of Proof{a, b, c} (create_proof for public r, s) against the checker's restatement of prover.rs:110-178
+    pk = groth16_pk_extras(lambda g, k: orc.fixed_base_points(g, k)[0])
+    rs = rand_fr_canonical(0xC0FFEE + 99, 2)
+    want_pf = checker_create_proof(orc, pk, want_jac, rs[0], rs[1], king_lanes=(0, 1))
+    for ln in range(L):
+        for key in ("a", "b", "c"):
+            waff, winf = want_pf[ln][key]
+            gaff, ginf = pts["proofs"][ln][key]
+            assert bool(ginf) == bool(winf) and (winf or np.array_equal(gaff, waff)), ("proof", ln, key)
 
 
 @pytest.mark.gpu
 def test_groth16_full_size_end_to_end_matches_checker(czk, orc, tmp_path):
     """BASELINE configs[1] at its FULL size -- Groth16, SPDZ, 2 parties, 2^20 constraints, domain 2^21, four share lanes -- one
     complete step of both hosts (the Python driver bench.py times, and the torch-free C++ host on device handles) against the
-    checker on the same inputs: h bit-exact on all four lanes, all 20 group elements equal in affine.  The checker side is
-    the all-core run of the C restatement (orc.groth16_local_par: io/oi FFTs and Pippenger of the reference, ~40 s) on the lanes
-    of `beaver_shortcut_lanes` (equivalence with the explicit Beaver sequence: test_beaver_shortcut_equals_explicit_sequence)."""
+    checker on the same inputs: h bit-exact on all four lanes, all 20 group elements equal in affine, and the five queries of the
+    synthetic key equal to the checker's FixedBaseMSM.  The checker side is the all-core run of the C restatement
+    (orc.groth16_local_par: io/oi FFTs and Pippenger of the reference) on the lanes of `beaver_shortcut_lanes` (equivalence with the
+    explicit Beaver sequence: test_beaver_shortcut_equals_explicit_sequence); its answers are the committed digests of
+    tests/golden/fullsize_digests.json (tests/fullsize.py; when this case is the session's live one the checker runs here, ~40 s)."""
     import torch
+    import fullsize
     from czk_amd.provers import Groth16Local
     N = 1 << 20
-    a0, b0, c0, wit, asg, log_d, one = groth16_inputs(orc, N)
-    D, L = 1 << log_d, 4
+    log_d, L = 21, 4
+    D = 1 << log_d
     # the product, host 1: the Python driver
     ts = torch.cuda.Stream()
     with torch.cuda.stream(ts):
         c2 = czk.Context(0, ts.cuda_stream)
         p = Groth16Local(czk, c2, N, 2)
+        a0, _, _, _, asg, log_d2, _ = groth16_inputs(orc, N)          # the driver's lanes are the seeds' lanes
+        assert log_d2 == log_d
         assert np.array_equal(p.a0.cpu().numpy().view(np.uint64), a0) and np.array_equal(p.asg.cpu().numpy().view(np.uint64), asg)
+        del a0, asg
         p.step()
         torch.cuda.synchronize()
         h_py = p.ab.cpu().numpy().view(np.uint64).copy()
         res_py = {k: c2.jac_to_affine(czk.CZK_G2 if k == "b_g2" else czk.CZK_G1, v) for k, v in p.results.items()}
         assert not bool(p.chk.any().item())
-        keys = _query_bases(c2, czk, N, D)
+        for name, (g, bases, inf) in _query_bases(c2, czk, N, D).items():   # the synthetic key both hosts register
+            fullsize.expect(f"bases_groth16_{name}_2e20", {"points": bases.tobytes()}, orc)
         del p
         c2.close()
     torch.cuda.empty_cache()
@@ -279,20 +355,13 @@ def test_groth16_full_size_end_to_end_matches_checker(czk, orc, tmp_path):
     assert out.returncode == 0 and '"pipelined_proofs_equal": true' in out.stdout, out.stdout + out.stderr
     _, D2, L2, h_cpp, pts = _read_dump(dump)
     assert (D2, L2) == (D, L)
-    # the checker
-    a1, b1, c1 = beaver_shortcut_lanes(orc, a0, b0, c0)
-    del a0, b0
-    want = orc.groth16_local_par(log_d, N, a1, b1, c1, wit, asg, keys["h"][1], keys["l"][1], keys["a"][1], keys["b_g1"][1], keys["b_g2"][1],
-                                 keys["b_g1"][2], threads=min(orc.max_threads(), 32))
-    for ln in range(L):                                            # a1 ends as h (in place)
-        assert np.array_equal(h_py[ln], a1[ln]), ("python host h", ln)
-        assert np.array_equal(h_cpp[ln], a1[ln]), ("c++ host h", ln)
-    for q, (name, g, w) in enumerate((("h", 1, 18), ("l", 1, 18), ("a", 1, 18), ("b_g1", 1, 18), ("b_g2", 2, 36))):
-        for ln in range(L):
-            waff, winf = orc.jac_to_affine(g, want[ln, 18 * q:18 * q + w])
-            assert not winf
-            assert not res_py[name][1][ln] and np.array_equal(res_py[name][0][ln], waff), ("python host", name, ln)
-            assert not pts[name][1][ln] and np.array_equal(pts[name][0][ln], waff), ("c++ host", name, ln)
+    for host, h, res in (("python", h_py, res_py), ("c++", h_cpp, pts)):
+        got = {f"hvec_lane{ln}": h[ln].tobytes() for ln in range(L)}
+        for name in ("h", "l", "a", "b_g1", "b_g2"):
+            for ln in range(L):
+                assert not res[name][1][ln], (host, name, ln)
+                got[f"{name}_lane{ln}"] = fullsize.affine_bytes(res[name][0][ln], res[name][1][ln])
+        fullsize.expect("groth16_spdz2_2e20", got, orc)
 
 
 @pytest.mark.gpu

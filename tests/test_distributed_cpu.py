@@ -80,13 +80,45 @@ def test_bench_launcher_starts_one_rank_per_gpu(gpus, layout):
     import json
     import subprocess
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-run", "--layout", layout, "--parties", str(gpus if layout == "party" else 2)]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-run", "--layout", layout, "--parties", str(gpus if layout == "party" else 2),
+           "--no-multi-gpu-report"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
-    assert d["dry_run"] and d["n_gpus"] == gpus and d["ranks_seen_by_backend"] == gpus
+    assert d["dry_run"] and d["n_gpus"] == gpus and d["ranks_seen_by_backend"] == gpus and "multi_gpu_report" not in d
     assert abs(d["max_over_ranks_s"] - 0.001 * gpus) < 1e-9      # the slowest rank's time
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_multi_gpu_report_shape(gpus):
+    """`bench.py --gpus N` on N > 1 GPUs (the driver's SCALE run) follows its replica line with the party / split layout children
+    (bench.multi_gpu_report); --dry-run produces the report's shape on CPU: one launch per kind of child (one-GPU reference, party layout
+    over N ranks, split layout over N ranks), the rest as planned commands.  Every party child names the one-GPU run whose digest it must
+    reproduce, covers both exchange patterns and both transports, and the config is the BASELINE one whose party count is N."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry-run"], capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                        # ONE JSON line, whatever the children print
+    d = json.loads(lines[0])
+    rep = d["multi_gpu_report"]
+    assert d["n_gpus"] == gpus and d["ranks_seen_by_backend"] == gpus
+    baseline_cfg = {2: "marlin_spdz2_2e20", 3: "plonk_gsz3_2e18"}[gpus]
+    party = {k: v for k, v in rep.items() if "/party/" in k}
+    assert {k.split("/", 2)[2] for k in party if k.startswith(baseline_cfg)} == {"torch/ring", "torch/p2p", "czk/ring", "czk/p2p"}
+    for k, v in party.items():
+        assert v["reference"] == k.split("/")[0] + "/one_gpu" and v["reference"] in rep, k
+        assert f"--gpus {gpus} --layout party" in v["command"] and f"--parties {gpus}" in v["command"]
+    launched = {k: v for k, v in rep.items() if v.get("dry_run") is True}
+    assert {k.split("/")[1] for k in launched} == {"one_gpu", "party", "split"}
+    for k, v in launched.items():
+        want = 1 if k.endswith("/one_gpu") else gpus
+        assert v["n_gpus"] == want and v["ranks_seen_by_backend"] == want, (k, v)
+    assert rep["groth16_spdz2_2e20/split"]["reference"] == "headline"
+    assert not any("error" in v for v in rep.values()), rep
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():

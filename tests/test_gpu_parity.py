@@ -77,20 +77,22 @@ def test_ntt_all_kinds_bit_exact(ctx, czk, orc, log_d):
 def test_ntt_large_sizes_bit_exact_four_lanes(ctx, czk, orc, log_d):
     """Every output limb of all four transform kinds against the checker's io/oi restatement (radix2/fft.rs:140-260) at
     2^17 .. 2^21 (the three-pass decompositions, incl. the 2^21 BASELINE domain), 4 share lanes in device memory; the
-    inverse kinds run on a ragged prefix with a garbage tail (resize(size, zero), radix2/mod.rs:100-101)."""
+    inverse kinds run on a ragged prefix with a garbage tail (resize(size, zero), radix2/mod.rs:100-101).  The checker's
+    answers are the committed digests of tests/golden/fullsize_digests.json (tests/fullsize.py; one case per session is
+    also recomputed live)."""
     import torch
+    import fullsize
     d, lanes = 1 << log_d, 4
-    x = orc.fr_from_repr(rand_fr_canonical(4242 + log_d, lanes * d)).reshape(lanes, d, 4)
+    x = fullsize.ntt_input(orc, log_d, lanes)
     for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
-        in_len = d if kind in (czk.CZK_FFT, czk.CZK_COSET_FFT) else d - 12345
+        in_len = fullsize.ntt_in_len(kind, d)
         buf = x.copy()
         buf[:, in_len:] = 0xDEADBEEFDEADBEEF
         t = torch.from_numpy(buf.view(np.int64)).cuda()
         ctx.ntt_fr(t.data_ptr(), log_d, kind, lanes=lanes, in_len=in_len, mem=czk.CZK_MEM_DEVICE)
         ctx.sync()
         got = t.cpu().numpy().view(np.uint64)
-        for ln in range(lanes):
-            assert np.array_equal(got[ln], orc.ntt_fr(x[ln, :in_len], log_d, kind, in_len)), (log_d, kind, ln)
+        fullsize.expect(f"ntt_2e{log_d}_{fullsize.KINDS[kind]}", {f"lane{ln}": got[ln].tobytes() for ln in range(lanes)}, orc)
 
 
 def test_ntt_size_errors(ctx, czk):
@@ -266,9 +268,13 @@ def test_msm_full_size_known_discrete_logs(ctx, czk, orc, g, n):
 def test_msm_full_size_matches_reference_pippenger(ctx, czk, orc, g, n, oracle_lanes):
     """The a/b-query MSM of BASELINE configs[1] (2^20 + 1 points, 4 share lanes, one infinity base like the real key)
     against the checker's Pippenger itself (variable_base.rs:12-106: c = 16, 16 windows of 65 535 buckets) -- not only via
-    discrete logs -- compared in affine.  Lanes the checker does not recompute are covered by the discrete-log identity."""
+    discrete logs -- compared in affine.  Lanes the checker does not recompute are covered by the discrete-log identity.
+    The checker's answers -- and its FixedBaseMSM answer for the 2^20 + 1 bases czk_fixed_base_points generates -- are the committed
+    digests of tests/golden/fullsize_digests.json (tests/fullsize.py; one case per session is also recomputed live)."""
     import torch
+    import fullsize
     lanes = 4
+    assert n == fullsize.FULL_N
     k = rand_fr_canonical(0xBA5E5 + 3, n)
     aw = 12 if g == 1 else 24
     kd = torch.from_numpy(k.view(np.int64)).cuda()
@@ -279,13 +285,13 @@ def test_msm_full_size_matches_reference_pippenger(ctx, czk, orc, g, n, oracle_l
     infd = torch.from_numpy(inf).cuda()
     b = ctx.register_bases(g, pts.data_ptr(), infd.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE)
     bases_host = pts.cpu().numpy().view(np.uint64)
-    s = orc.fr_from_repr(rand_fr_canonical(0xFACE, lanes * n)).reshape(lanes, n, 4)       # Montgomery scalars, as the MPC wrappers pass them
-    s[2, 5] = orc.fr_from_repr(ints_to_limbs([1], 4))[0]                                 # a unit scalar (variable_base.rs:44-48) and a zero
-    s[2, 6] = 0
+    fullsize.expect(f"bases_g{g}_seed3_2e20p1", {"points": bases_host.tobytes()}, orc)      # the GPU's synthetic key = the reference generator's algorithm
+    s = fullsize.msm_scalars(orc, n, lanes)                                                  # Montgomery scalars, as the MPC wrappers pass them; a unit and a zero on lane 2
     sd = torch.from_numpy(s.view(np.int64)).cuda()
     out = ctx.msm(b, sd.data_ptr(), n_scalars=n, lanes=lanes, scalar_form=czk.CZK_SCALAR_MONTGOMERY, mem=czk.CZK_MEM_DEVICE)
+    aff, ainf = ctx.jac_to_affine(g, out)
     for ln in oracle_lanes:
-        assert _same_point(ctx, orc, g, out[ln], orc.multi_scalar_mul(g, bases_host, inf, s[ln])), (g, ln)
+        fullsize.expect(f"msm_g{g}_2e20p1_lane{ln}", {"affine": fullsize.affine_bytes(aff[ln], ainf[ln])}, orc)
     gen = ctx.fixed_base_points(g, ints_to_limbs([1], 4))[0]
     k[0] = 0
     for ln in set(range(lanes)) - set(oracle_lanes):
@@ -1302,6 +1308,110 @@ def test_groth16_local_hbc_scheme_matches_reference(ctx, czk, orc, n_constraints
     c2.close()
 
 
+@pytest.mark.parametrize("n_constraints,parties", [(10, 3), (1000, 4)])
+def test_groth16_local_gsz_scheme_matches_reference(ctx, czk, orc, n_constraints, parties):
+    """The reference's `--alg gsz` (mpc-snarks/src/proof.rs:379-387): GszFieldShare (share/gsz20/mod.rs:115-118), ONE Shamir-share lane per party
+    (degree t = (n - 1) / 2), public addends on every lane, products by batch_mult (:556-595): x y + r2, the king opens at degree 2t and hands the
+    value back (batch_king_compute, f = identity), minus r, with the stubbed double share r = r2 = 1.  Groth16Local(scheme="gsz") against the
+    checker's lane-wise restatement (its own Shamir open, share/gsz20/mod.rs:440-466); the lanes of h must open (degree t) to the single prover's
+    h; the five MSMs against the checker's Pippenger on every lane."""
+    import torch
+    from czk_amd.provers import Groth16Local
+    ts = torch.cuda.Stream()
+    with torch.cuda.stream(ts):
+        c2 = czk.Context(0, ts.cuda_stream)
+        p = Groth16Local(czk, c2, n_constraints, parties, scheme="gsz")
+        t = (parties - 1) // 2
+        assert p.lanes == parties and p.lpp == 1 and p.king_lanes == list(range(parties)) and p.gsz_t == t
+        a0, b0, c0 = (v.cpu().numpy().view(np.uint64).copy() for v in (p.a0, p.b0, p.c0))
+        wit, asg = p.wit.cpu().numpy().view(np.uint64).copy(), p.asg.cpu().numpy().view(np.uint64).copy()
+        p.step()
+        torch.cuda.synchronize()
+        h_gpu = p.ab.cpu().numpy().view(np.uint64)
+    L, D, ld, N = parties, p.D, p.log_d, p.N
+    one = orc.fr_from_repr(ints_to_limbs([1], 4))
+    ones = np.tile(one[0], (D, 1))
+    # the lanes really are degree-t Shamir shares of the witness: they open to the squaring chain, and a tighter bound fails
+    w_open, bad = orc.gsz_open(wit, degree=t)
+    assert bad == 0 and orc.gsz_open(wit, degree=t - 1)[1] > 0
+    assert np.array_equal(orc.fr_mul(w_open[:-1], w_open[:-1]), w_open[1:])
+    A = [orc.witness_map_pre(a0[ln], b0[ln], ld) for ln in range(L)]
+    prod = np.stack([orc.fr_add(orc.fr_mul(A[ln][0], A[ln][1]), ones) for ln in range(L)])       # x * y + r2
+    value, bad = orc.gsz_open(prod, degree=2 * t)                                                  # the king's open_degree_vec
+    assert bad == 0
+    ab = orc.fr_sub(value, ones)                                                                   # - r
+    for ln in range(L):
+        assert np.array_equal(h_gpu[ln], orc.witness_map_post(ab, c0[ln], ld)), ln
+    h_open, bad = orc.gsz_open(h_gpu, degree=t)
+    a_open, b_open, c_open = (orc.gsz_open(v, degree=t)[0] for v in (a0, b0, c0))
+    assert bad == 0 and np.array_equal(h_open, orc.witness_map_plain(a_open, b_open, c_open, ld))
+    for name, g, n, sd, inf_first, scal in (("h", 1, D - 1, 1, False, h_gpu), ("l", 1, N, 2, False, wit), ("a", 1, N + 1, 3, False, asg),
+                                             ("b_g1", 1, N + 1, 4, True, asg), ("b_g2", 2, N + 1, 5, True, asg)):
+        bases = ctx.fixed_base_points(g, rand_fr_canonical(0xBA5E5 + sd, n))
+        inf = np.zeros(n, dtype=np.uint8)
+        inf[0] = 1 if inf_first else 0
+        for ln in range(L):
+            assert _same_point(ctx, orc, g, p.results[name][ln], orc.multi_scalar_mul(g, bases, inf, scal[ln].reshape(-1, 4))), (name, ln)
+    c2.close()
+
+
+@pytest.mark.parametrize("n_constraints,parties,scheme", [(10, 2, "spdz"), (1000, 2, "spdz"), (1000, 3, "hbc"), (1000, 1, "hbc"), (1000, 3, "gsz")])
+def test_create_proof_matches_checker(ctx, czk, orc, n_constraints, parties, scheme):
+    """The whole of create_proof (mpc-snarks/src/groth/prover.rs:66-178) for public r, s: the five MSMs of step(), then calculate_coeff
+    (:216-232: query[0], vk_param and r delta / s delta on the king's lanes) and Proof{a, b, c} per share lane (Groth16Local.create_proof)
+    against the checker's restatement fed with the checker's own Pippenger results, in affine.  With the parties' sh lanes added up the
+    proof must be the SINGLE prover's (parties = 1: T = Fr, no sharing), element for element."""
+    import torch
+    from czk_amd.provers import Groth16Local
+    from test_device_handles import checker_create_proof, groth16_pk_extras
+    rs = rand_fr_canonical(0xC0FFEE + 99, 2)
+
+    def prove(parties, scheme):
+        ts = torch.cuda.Stream()
+        with torch.cuda.stream(ts):
+            c2 = czk.Context(0, ts.cuda_stream)
+            p = Groth16Local(czk, c2, n_constraints, parties, scheme=scheme)
+            p.step()
+            torch.cuda.synchronize()
+            scal = {"h": p.ab.cpu().numpy().view(np.uint64).copy(), "l": p.wit.cpu().numpy().view(np.uint64).copy(),
+                    "a": p.asg.cpu().numpy().view(np.uint64).copy()}
+            scal["b_g1"] = scal["b_g2"] = scal["a"]
+            res = {k: v.copy() for k, v in p.results.items()}
+            proof = p.create_proof(res, rs[0], rs[1])
+            aff = [{k: c2.jac_to_affine(2 if k == "b" else 1, proof[k][ln]) for k in ("a", "b", "c")} for ln in range(p.lanes)]
+            out = (p.lanes, p.lpp, list(p.king_lanes), p.D, p.N, scal, res, proof, aff)
+            del p
+            c2.close()
+        return out
+    L, lpp, king, D, N, scal, res, proof, aff = prove(parties, scheme)
+    # the checker's MSM results on the lanes' scalars, then its create_proof
+    want_jac = {}
+    for name, g, n, sd, inf_first in (("h", 1, D - 1, 1, False), ("l", 1, N, 2, False), ("a", 1, N + 1, 3, False), ("b_g1", 1, N + 1, 4, True), ("b_g2", 2, N + 1, 5, True)):
+        bases = ctx.fixed_base_points(g, rand_fr_canonical(0xBA5E5 + sd, n))
+        inf = np.zeros(n, dtype=np.uint8)
+        inf[0] = 1 if inf_first else 0
+        want_jac[name] = [orc.multi_scalar_mul(g, bases, inf, scal[name][ln].reshape(-1, 4)) for ln in range(L)]
+    pk = groth16_pk_extras(lambda g, k: orc.fixed_base_points(g, k)[0])
+    want = checker_create_proof(orc, pk, want_jac, rs[0], rs[1], king_lanes=king)
+    for ln in range(L):
+        for key in ("a", "b", "c"):
+            waff, winf = want[ln][key]
+            assert bool(aff[ln][key][1][0]) == bool(winf) and (winf or np.array_equal(aff[ln][key][0][0], waff)), (ln, key)
+    if parties > 1:
+        # open the proof: sum of the parties' sh lanes (czk_jac_add) -- times 1 / n for Shamir shares on the n-th roots of unity, whose
+        # interpolating polynomial has p(0) = (1 / n) sum_j p(w^j) -- == the single prover's proof
+        _, _, _, _, _, _, _, _, aff1 = prove(1, "hbc")
+        for key, g in (("a", 1), ("b", 2), ("c", 1)):
+            acc = proof[key][0]
+            for j in range(1, parties):
+                acc = ctx.jac_add(g, acc, proof[key][lpp * j])
+            if scheme == "gsz":
+                from util import R_MOD
+                acc = ctx.jac_scalar_mul(g, acc, ints_to_limbs([pow(parties, -1, R_MOD)], 4)[0])
+            got = ctx.jac_to_affine(g, acc)
+            assert not got[1][0] and np.array_equal(got[0][0], aff1[0][key][0][0]), key
+
+
 @pytest.mark.parametrize("ranks,size", [(2, ["--constraints", "1000"]), (3, ["--log-n", "12"])])
 def test_groth16_intra_party_split_matches_the_one_gpu_layout(ranks, size):
     """SURVEY.md section 8e, "optional intra-party split (MSM by base range -> one extra point-add)": bench.py --layout split runs ONE proof over N
@@ -1326,3 +1436,72 @@ def test_groth16_intra_party_split_matches_the_one_gpu_layout(ranks, size):
     assert d2["n_gpus"] == ranks and d2["ranks_seen_by_backend"] == ranks and d2["config"]["layout"] == "split" and d2["scaling"] == "strong"
     assert d1["results_checked"] and d2["results_checked"]
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
+
+
+def test_fr_copy_3d_matches_numpy_indexing(ctx, czk):
+    """czk_fr_copy_3d: the one strided copy / fill behind every re-layout of the polynomial provers -- dense copies (copy-engine path), prefix
+    copies with different lane strides, zero fill of a tail, interleave / de-interleave by a stride, a lane broadcast (source stride 0)."""
+    import torch
+    lanes, n = 3, 60
+    src = torch.from_numpy(rand_fr_canonical(77, lanes * n).reshape(lanes, n, 4).view(np.int64)).cuda()
+    h = src.cpu().numpy()
+
+    def run(dst_shape, dst_off, ds, s_off, ss, n3, fill=False):
+        dst = torch.full(dst_shape + (4,), -1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.fr_copy_3d(dst.data_ptr() + 32 * dst_off, ds, None if fill else src.data_ptr() + 32 * s_off, None if fill else ss, n3)
+        ctx.sync()
+        return dst.cpu().numpy()
+    got = run((lanes, n), 0, (0, n, 1), 0, (0, n, 1), (1, lanes, n))                       # dense
+    assert np.array_equal(got, h)
+    got = run((lanes, 100), 0, (0, 100, 1), 0, (0, n, 1), (1, lanes, 40))                  # resized: prefix into wider lanes, the rest untouched
+    assert np.array_equal(got[:, :40], h[:, :40]) and (got[:, 40:] == -1).all()
+    got = run((lanes, 100), 40, (0, 100, 1), 0, None, (1, lanes, 60), fill=True)           # ... and the tail cleared
+    assert (got[:, 40:] == 0).all() and (got[:, :40] == -1).all()
+    got = run((lanes, 50), 0, (0, 50, 1), 10, (0, n, 1), (1, lanes, 50))                   # drop_first
+    assert np.array_equal(got, h[:, 10:])
+    k = 4                                                                                  # strided_split: out[l * k + j][i] = a[l][i * k + j]
+    got = run((lanes * k, n // k), 0, (k * (n // k), n // k, 1), 0, (n, 1, k), (lanes, k, n // k))
+    want = h.reshape(lanes, n // k, k, 4).transpose(0, 2, 1, 3).reshape(lanes * k, n // k, 4)
+    assert np.array_equal(got, want)
+    got = run((5, n), 0, (0, n, 1), n, (0, 0, 1), (1, 5, n))                               # lane 1 of the source on five lanes
+    assert all(np.array_equal(got[j], h[1]) for j in range(5))
+    ctx.fr_copy_3d(0, (0, 0, 1), None, None, (0, 3, 3))                                     # nothing to do: no dereference
+    with pytest.raises(czk.CzkError):
+        ctx.fr_copy_3d(0, (0, 0, 1), None, None, (1, 1, 1))
+
+
+def test_vec_scale_with_a_host_scalar(ctx, czk, orc):
+    """czk_fr_vec_scale with CZK_MEM_DEVICE | CZK_MEM_SCALAR_HOST: device vectors, the scalar by value with the launch"""
+    import torch
+    from czk_amd import binding
+    n = 1000
+    a = orc.fr_from_repr(rand_fr_canonical(5, n))
+    k = orc.fr_from_repr(rand_fr_canonical(6, 1))[0]
+    ad = torch.from_numpy(a.view(np.int64)).cuda()
+    out = torch.empty_like(ad)
+    ctx.fr_vec_scale(ad.data_ptr(), k, out=out.data_ptr(), n=n, mem=czk.CZK_MEM_DEVICE | binding.CZK_MEM_SCALAR_HOST)
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), orc.fr_mul(a, np.tile(k, (n, 1))))
+
+
+@pytest.mark.parametrize("g", [1, 2])
+def test_jac_scalar_mul_and_neg_match_reference_group_law(ctx, czk, orc, g):
+    """czk_jac_scalar_mul = ProjectiveCurve::mul (algebra/ec/src/lib.rs:215-226), czk_jac_neg = Neg (short_weierstrass_jacobian.rs:737-748),
+    host-side: against the checker's double-and-add, for canonical and Montgomery scalars, 0, 1, r - 1 and the identity"""
+    from util import R_MOD
+    _, bases = _bases(ctx, g, 3, 91)
+    ks = np.concatenate([rand_fr_canonical(92, 3), ints_to_limbs([0, 1, R_MOD - 1], 4)])
+    one = orc.fr_from_repr(ints_to_limbs([1], 4))[0]
+    for i, k in enumerate(ks):
+        base = bases[i % 3]
+        jac = orc.scalar_mul(g, base, False, ints_to_limbs([1], 4)[0])                     # into_projective
+        want = orc.scalar_mul(g, base, False, k)
+        assert _same_point(ctx, orc, g, ctx.jac_scalar_mul(g, jac, k), want), i
+        km = orc.fr_from_repr(k.reshape(1, 4))[0]
+        assert _same_point(ctx, orc, g, ctx.jac_scalar_mul(g, jac, km, czk.CZK_SCALAR_MONTGOMERY), want), i
+        neg = ctx.jac_neg(g, want)
+        assert ctx.jac_to_affine(g, ctx.jac_add(g, want, neg))[1][0] == 1                 # P + (-P) = identity
+    zero = np.zeros(18 if g == 1 else 36, dtype=np.uint64)
+    assert ctx.jac_to_affine(g, ctx.jac_scalar_mul(g, zero, ks[0]))[1][0] == 1
+    assert one.any()

@@ -80,6 +80,8 @@ def generate() -> str:
     out.append("")
     for ty, name, val in enums:
         out.append(f"pub const {name}: c_int = {val}; // {ty}")
+    for name, val in re.findall(r"^#define (CZK_[A-Z0-9_]+) (\d+)\s*$", text, flags=re.M):
+        out.append(f"pub const {name}: c_int = {val}; // #define")
     out += ["", "#[link(name = \"czk_hip\")]", "extern \"C\" {"]
     for name, ret, params in funcs:
         ps = ", ".join(f"{('type_' if p == 'type' else p)}: {rust_type(t)}" for p, t in params)

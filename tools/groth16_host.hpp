@@ -7,6 +7,7 @@
 //   SpdzFieldShare::batch_open                           share/spdz.rs:166-185     Groth16Host::open: all parties' lanes on this GPU -> lane sums;
 //                                                                                  one party per process -> czk::Net::spdz_batch_open (czk_net)
 //   create_proof's five MSMs          mpc-snarks/src/groth/prover.rs:104-156       czk::multi_scalar_mul_async
+//   create_proof's O(1) group steps, calculate_coeff, Proof{a, b, c}  prover.rs:110-178, 216-232   Groth16Host::create_proof (public r, s)
 //
 // Inputs are host `std::vector`s, as the reference holds `Vec`s: the share lanes of the assignment go up ONCE
 // (DeviceLanes::upload), every transform / pointwise step / MSM runs on the resident lanes, the 20 group elements of a proof come
@@ -147,6 +148,12 @@ struct ProofElements {   // the group elements of one proof, per share lane (Jac
     explicit ProofElements(size_t lanes) : h(lanes), l(lanes), a(lanes), b_g1(lanes), b_g2(lanes) {}
 };
 
+struct ProofShare {   // one share lane's part of Proof{a, b, c} (groth16/src/data_structures.rs:13-20), Jacobian
+    czk::G1Projective a;
+    czk::G2Projective b;
+    czk::G1Projective c;
+};
+
 class Groth16Host {
   public:
     static constexpr uint64_t BASE_SEED = 0xBA5E5;
@@ -178,6 +185,15 @@ class Groth16Host {
         a_query_ = mk_bases<CZK_G1>(N + 1, 3, false, no_tables);
         b_g1_query_ = mk_bases<CZK_G1>(N + 1, 4, true, no_tables);
         b_g2_query_ = mk_bases<CZK_G2>(N + 1, 5, true, no_tables);
+        // the rest of the key (groth16/src/data_structures.rs:132-149), synthetic like the queries: G1 [vk.alpha_g1, beta_g1, delta_g1, a_query[0]],
+        // G2 [vk.beta_g2, vk.delta_g2]; b_g1_query[0] and b_g2_query[0] are infinity in the real key (the constant-one variable has no B entry)
+        {
+            std::vector<Fr> k1 = rand_fr_canonical(BASE_SEED + 6, 4), k2 = rand_fr_canonical(BASE_SEED + 7, 2);
+            pk_g1_.resize(4 * 12);
+            pk_g2_.resize(2 * 24);
+            ctx.check(czk_fixed_base_points(ctx.raw(), CZK_G1, k1[0].l, 4, pk_g1_.data(), CZK_MEM_HOST));
+            ctx.check(czk_fixed_base_points(ctx.raw(), CZK_G2, k2[0].l, 2, pk_g2_.data(), CZK_MEM_HOST));
+        }
         // NTT tables of the witness-map domain and the MSM workspaces of this key's largest G1 and G2 calls: at key load, not inside the first proof
         ctx.reserve(log_d, L, h_query_->raw(), D, L);
         ctx.reserve(0, 0, b_g2_query_->raw(), N + 1, L);
@@ -267,6 +283,43 @@ class Groth16Host {
         return r;
     }
 
+    // The rest of create_proof after the five MSMs (prover.rs:110-178) for PUBLIC r, s (canonical limbs) -- every step is then linear in the
+    // shares: calculate_coeff (:216-232: initial + query[0] + acc + vk_param) for A, B1, B2 and C = s A + r B1 - r s delta + l_acc + h_acc.
+    // A public group element meets a share through `shift`: the king's lanes (sh, and mac under the stand-in key 1) add it, the others do not.
+    // Returns every local lane's share of the proof; the parties' sh lanes sum to Proof{a, b, c}.
+    std::vector<ProofShare> create_proof(const ProofElements& e, const czk::BigInteger256& r, const czk::BigInteger256& s) const {
+        const czk_ctx* c = ctx.raw();
+        auto mul1 = [&](const czk::G1Projective& p, const czk::BigInteger256& k) { czk::G1Projective o; ctx.check(czk_jac_scalar_mul(ctx.raw(), CZK_G1, p.x.l, k.l, CZK_SCALAR_CANONICAL, o.x.l)); return o; };
+        auto mul2 = [&](const czk::G2Projective& p, const czk::BigInteger256& k) { czk::G2Projective o; ctx.check(czk_jac_scalar_mul(ctx.raw(), CZK_G2, p.x.c0.l, k.l, CZK_SCALAR_CANONICAL, o.x.c0.l)); return o; };
+        auto add1 = [&](const czk::G1Projective& p, const czk::G1Projective& q) { czk::G1Projective o; ctx.check(czk_jac_add(ctx.raw(), CZK_G1, p.x.l, q.x.l, o.x.l)); return o; };
+        auto add2 = [&](const czk::G2Projective& p, const czk::G2Projective& q) { czk::G2Projective o; ctx.check(czk_jac_add(ctx.raw(), CZK_G2, p.x.c0.l, q.x.c0.l, o.x.c0.l)); return o; };
+        auto mix1 = [&](const czk::G1Projective& p, const uint64_t* aff, bool inf) { czk::G1Projective o; ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, p.x.l, aff, inf, o.x.l)); return o; };
+        auto mix2 = [&](const czk::G2Projective& p, const uint64_t* aff, bool inf) { czk::G2Projective o; ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G2, p.x.c0.l, aff, inf, o.x.c0.l)); return o; };
+        (void)c;
+        const czk::G1Projective zero1{};   // z == 0: the identity (is_zero tests z alone)
+        const czk::G2Projective zero2{};
+        const czk::G1Projective delta_g1 = mix1(zero1, &pk_g1_[2 * 12], false);        // pk.delta_g1.into_projective()
+        const czk::G2Projective delta_g2 = mix2(zero2, &pk_g2_[1 * 24], false);
+        const czk::G1Projective r_s_delta_g1 = mul1(mul1(delta_g1, r), s), r_g1 = mul1(delta_g1, r), s_g1 = mul1(delta_g1, s);   // :113-117, :128, :144
+        const czk::G2Projective s_g2 = mul2(delta_g2, s);                                                                            // :156
+        czk::G1Projective neg_rs;
+        ctx.check(czk_jac_neg(ctx.raw(), CZK_G1, r_s_delta_g1.x.l, neg_rs.x.l));
+        const uint64_t inf_aff[24] = {0};
+        std::vector<ProofShare> out(L);
+        for (size_t ln = 0; ln < L; ln++) {
+            const bool king = king_lane(ln);
+            // calculate_coeff: res = initial; res.add_assign_mixed(&query[0]); res += &acc; res.add_assign_mixed(&vk_param)   (:224-229)
+            const czk::G1Projective g_a = king ? mix1(add1(mix1(r_g1, &pk_g1_[3 * 12], false), e.a[ln]), &pk_g1_[0 * 12], false) : e.a[ln];      // a_query[0], vk.alpha_g1
+            const czk::G1Projective g1_b = king ? mix1(add1(mix1(s_g1, inf_aff, true), e.b_g1[ln]), &pk_g1_[1 * 12], false) : e.b_g1[ln];       // b_g1_query[0] = infinity, beta_g1
+            const czk::G2Projective g2_b = king ? mix2(add2(mix2(s_g2, inf_aff, true), e.b_g2[ln]), &pk_g2_[0 * 24], false) : e.b_g2[ln];       // b_g2_query[0] = infinity, vk.beta_g2
+            czk::G1Projective g_c = add1(mul1(g_a, s), mul1(g1_b, r));          // s_g_a + r_g1_b (:138, :158, :165-166)
+            if (king) g_c = add1(g_c, neg_rs);                                  // g_c -= &r_s_delta_g1
+            g_c = add1(add1(g_c, e.l[ln]), e.h[ln]);                            // += l_aux_acc, += h_acc
+            out[ln] = ProofShare{g_a, g2_b, g_c};
+        }
+        return out;
+    }
+
     // number of non-zero entries of the two MAC-check vectors (share/spdz.rs:176-183: the reference asserts zero).  Party layout: the
     // check is part of czk::Net::spdz_batch_open, which panics on a failure; the vectors stay zero.
     uint64_t mac_check_failures() const {
@@ -325,6 +378,7 @@ class Groth16Host {
     bool commit_opens_ = false;
     std::vector<size_t> local_;
     Fr mac_share_{};
+    std::vector<uint64_t> pk_g1_, pk_g2_;
     std::optional<czk::Radix2EvaluationDomain> domain_;
     std::unique_ptr<czk::G1Bases> h_query_, l_query_, a_query_, b_g1_query_;
     std::unique_ptr<czk::G2Bases> b_g2_query_;

@@ -86,7 +86,8 @@ static std::vector<std::vector<uint8_t>> proof_bytes(const Context& ctx, const g
 // the timed loop: host vectors -> share lanes up once -> K pipelined proofs -> 20 group elements per proof down.  Prints one JSON
 // line; bench.py reports it as `seam_device_handles`.  --dump writes the h lanes and the proof elements of the last proof for
 // tests/test_gpu_parity.py to compare with the checker: u64 header {N, D, lanes}, lanes x D Fr, then per query (h, l, a, b_g1:
-// lanes x 12 u64 affine + lanes flag bytes; b_g2: lanes x 24 u64 + flags).
+// lanes x 12 u64 affine + lanes flag bytes; b_g2: lanes x 24 u64 + flags), then per lane its share of Proof{a, b, c} for public r, s
+// (Groth16Host::create_proof: a 12 u64 + flag, b 24 u64 + flag, c 12 u64 + flag).
 static int bench(const Context& ctx, int argc, char** argv) {
     size_t n = (size_t)1 << 20, parties = 2, steps = 20, warmup = 2;
     bool no_tables = false;
@@ -158,6 +159,19 @@ static int bench(const Context& ctx, int argc, char** argv) {
             const size_t aw = q < 4 ? 12 : 24;
             fwrite(&ref_aff[q * L * 12], 8, L * aw, f);
             fwrite(&ref_inf[q * L], 1, L, f);
+        }
+        // ... then every lane's share of Proof{a, b, c} for the public r, s = rand_fr_canonical(0xC0FFEE + 99, 2): a, c as 12 u64 + flag, b as 24 u64 + flag
+        std::vector<Fr> rs = g16::rand_fr_canonical(0xC0FFEE + 99, 2);
+        const BigInteger256 r{{rs[0].l[0], rs[0].l[1], rs[0].l[2], rs[0].l[3]}}, s_{{rs[1].l[0], rs[1].l[1], rs[1].l[2], rs[1].l[3]}};
+        for (const g16::ProofShare& ps : prover.create_proof(prover.results[0], r, s_)) {
+            uint64_t a1[12], a2[24];
+            uint8_t fl = 0;
+            ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, ps.a.x.l, 1, a1, &fl));
+            fwrite(a1, 8, 12, f), fwrite(&fl, 1, 1, f);
+            ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G2, ps.b.x.c0.l, 1, a2, &fl));
+            fwrite(a2, 8, 24, f), fwrite(&fl, 1, 1, f);
+            ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, ps.c.x.l, 1, a1, &fl));
+            fwrite(a1, 8, 12, f), fwrite(&fl, 1, 1, f);
         }
         fclose(f);
     }
