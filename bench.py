@@ -39,6 +39,12 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 # initialises, hence from argv.
 _POLYIOP = any(a in ("plonk", "marlin") for a in sys.argv)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24" if _POLYIOP else "8")
+if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+    # one node: rendezvous and bootstrap sockets on the loopback interface, no InfiniBand probing -- the ranks' data path is xGMI (RCCL) or
+    # shared memory; without these gloo / RCCL enumerate interfaces and resolve the container's hostname first, which stalls for minutes where
+    # the resolver times out (seen on the GPU boxes: "[c10d] The hostname of the client socket cannot be retrieved")
+    for _k, _v in (("GLOO_SOCKET_IFNAME", "lo"), ("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
+        os.environ.setdefault(_k, _v)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
@@ -133,7 +139,21 @@ def other_workloads_report(device: int) -> dict:
             out[key] = {"proofs_per_s": j["value"], "ms_per_proof": j["ms_per_step"], "results_checked": bool(j.get("results_checked")),
                         "accumulate_busy_frac": j.get("accumulate_busy_frac"), "steps": j["steps"], "metric": j["metric"],
                         "proofs_in_flight": j["config"].get("proofs_in_flight", "pipelined"), "wall_s": time.time() - t0,
+                        # the same roofline block as the headline, for this workload's dominant kernel (HIP-event timed inside the child)
+                        "roofline": {k: (j.get("roofline") or {}).get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches")},
                         "command": "python bench.py " + " ".join(argv)}
+            if argv[1] in ("plonk", "marlin"):
+                # the same workload from the compiled host (tools/polyvm_host.hpp over include/czk.h: no torch, no Python, one device arena)
+                try:
+                    hd = [host_demo_exe(), argv[1]] + argv[2:]
+                    r2 = subprocess.run(hd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"})
+                    l2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("{")]
+                    j2 = json.loads(l2[-1]) if r2.returncode == 0 and l2 else None
+                    out[key]["cpp_host"] = ({k: j2[k] for k in ("harness", "proofs_per_s", "ms_per_proof", "latency_ms_single_proof", "proofs_in_flight", "arena_peak_gb",
+                                                                "in_flight_provers_equal", "output_sha256")} | {"fraction_of_python_host": j2["proofs_per_s"] / j["value"]}) \
+                        if j2 else {"error": (r2.stdout + r2.stderr)[-300:]}
+                except Exception as e:      # noqa: BLE001
+                    out[key]["cpp_host"] = {"error": repr(e)[-300:]}
         except Exception as e:      # noqa: BLE001 -- the report must not take the headline down with it
             out[key] = {"error": repr(e)[-400:]}
     return out
@@ -412,17 +432,20 @@ def cpu_baseline(log_n_sample: int, log_n_full: int, parties: int, all_cores_log
         orc.multi_scalar_mul(2, b2[:N + 1], inf, x[:N + 1])
     dt = time.perf_counter() - t0
     scale = _ref_work(1 << log_n_full) / _ref_work(1 << log_n_sample)
-    cal = 1.0   # measured (one full single-thread run at 2^20 on the GPU box's host) / (model prediction from the 2^14 sample)
-    try:
-        if log_n_sample == 14 and log_n_full == 20:
-            cal = float(json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_baseline_validation.json")))["calibration_2^14_to_2^20"])
-    except Exception:
-        cal = 1.0
+    cal, cal_src, full_s = 1.0, None, None   # measured (one full single-thread run at 2^20 on the GPU box's host) / (model prediction from the 2^14 sample)
+    if log_n_sample == 14 and log_n_full == 20:
+        for name in ("r05_cpu_baseline_validation.json", "r02_cpu_baseline_validation.json"):     # the newest validation run wins
+            try:
+                v = json.load(open(os.path.join(ROOT, "profiles", name)))
+                cal, cal_src, full_s = float(v["calibration_2^14_to_2^20"]), "profiles/" + name, v.get("single_thread_2^20_seconds", 513.9)
+                break
+            except Exception:      # noqa: BLE001
+                continue
     out = {"value": 1.0 / (dt * scale * cal), "unit": "proofs/s", "cores": 1, "kind": "port",
            "sample": f"oracle C restatement, 1 thread: full local compute of one proof ({lanes} share lanes: witness map + 5 MSMs each) "
                      f"at 2^{log_n_sample} constraints took {dt:.2f} s; scaled x{scale:.1f} to 2^{log_n_full} by the reference algorithm's "
-                     f"field-multiplication count and x{cal:.3f} by the measured error of that model at full size (one complete single-thread "
-                     f"2^20 run on this host class: 513.9 s; profiles/r02_cpu_baseline_validation.json)"}
+                     f"field-multiplication count and x{cal:.3f} by the measured error of that model at full size"
+                     + (f" (one complete single-thread 2^20 run on this host class: {full_s:.1f} s; {cal_src})" if cal_src else "")}
     # (ii) all host cores
     if all_cores_log_n is None:
         all_cores_log_n = log_n_full if cores >= 64 else min(log_n_full, 16)
@@ -734,17 +757,27 @@ def mac_shortcut_report(czk, device, tstream, n_constraints, args, value, check_
         return {"error": repr(e)[-400:]}
 
 
+def host_demo_exe() -> str:
+    """tools/host_demo.bin, compiled with g++ against the built libczk_hip.so when it is older than its sources (the compiled hosts of
+    INTEGRATION.md: tools/host_demo.cpp over include/czk.hpp, tools/groth16_host.hpp, tools/polyvm_host.hpp)"""
+    exe = os.path.join(ROOT, "tools", "host_demo.bin")
+    pkg = os.path.join(ROOT, "collaborative-zksnark_amd")
+    deps = [os.path.join(ROOT, "tools", f) for f in ("host_demo.cpp", "groth16_host.hpp", "polyvm_host.hpp")] + \
+           [os.path.join(ROOT, "include", f) for f in ("czk.h", "czk.hpp")] + [os.path.join(pkg, "libczk_hip.so")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "host_demo.cpp"), "-L" + pkg,
+                               "-lczk_hip", "-lpthread", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
 def seam_device_handles(n_constraints: int, parties: int, steps: int, warmup: int, value: float) -> dict:
     """The same step from a torch-free, Python-free host: tools/host_demo.cpp `bench` (C++ over include/czk.hpp, the mirror of the
     Rust shim) builds the same circuit, key and shares from host vectors, uploads the share lanes ONCE into czk_lanes handles,
     runs `steps` pipelined proofs on the resident lanes and downloads the 20 group elements of each -- what a reference caller
     that follows INTEGRATION.md reaches through the C ABI alone.  Runs as a separate process on the same GPU (this process is
     idle meanwhile); compiled here with g++ against the built libczk_hip.so."""
-    exe = os.path.join(ROOT, "tools", "host_demo.bin")
-    pkg = os.path.join(ROOT, "collaborative-zksnark_amd")
     try:
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "host_demo.cpp"), "-L" + pkg,
-                               "-lczk_hip", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+        exe = host_demo_exe()
         res = subprocess.run([exe, "bench", "--constraints", str(n_constraints), "--parties", str(parties), "--steps", str(steps), "--warmup", str(max(1, warmup))],
                              capture_output=True, text=True, timeout=900)
         line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -955,13 +988,13 @@ def main():
     mad2_gops = MADS_PER_MIXED_ADD_G2 * madds2 / (acc2_ms / 1e3) / 1e9 if acc2_ms > 0 else 0.0
     # HBM traffic and the effective clock of the dominant kernels: PMC counters cannot be read from inside this process; the figures
     # are per-launch averages of the same command under `rocprofv3 --pmc` (separate passes), stored with the commit they were taken at
-    traffic, traffic_src, pmc = None, None, {}
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    traffic, traffic_src, pmc, traffic_raw, traffic_cal = None, None, {}, None, None
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tf = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tf):
             try:
                 pmc = json.load(open(tf))
-                traffic = pmc.get("msm_accumulate_g1_bytes_per_launch")
+                traffic_raw = pmc.get("msm_accumulate_g1_bytes_per_launch")
                 traffic_src = f"profiles/{name}" + (f" @ {pmc['commit']}" if "commit" in pmc else "")
                 if "csrc_sha256" in pmc:
                     traffic_src += "; kernel sources unchanged since" if pmc["csrc_sha256"] == csrc_digest() else \
@@ -969,8 +1002,25 @@ def main():
                 break
             except Exception:
                 pmc = {}
+    # FETCH_SIZE under-reports: x 1/2 on wide coalesced streams (MI355X_MICROARCH.md), x 0.666 on this kernel's own access pattern -- random 192-byte
+    # table entries of a multi-GB table -- measured with a known byte count (tools/fetch_calib.hip, profiles/r05_fetch_size_calibration.json).
+    # traffic = fetch / factor + write (WRITE_SIZE uncalibrated, 3 % of the total)
+    try:
+        traffic_cal = json.load(open(os.path.join(ROOT, "profiles", "r05_fetch_size_calibration.json")))["k_gather"]["factor"]
+    except Exception:      # noqa: BLE001
+        traffic_cal = None
+
+    def calibrated(tag):
+        f, w = pmc.get(f"msm_accumulate_{tag}_fetch_bytes_per_launch"), pmc.get(f"msm_accumulate_{tag}_write_bytes_per_launch")
+        if f is None or w is None:
+            return pmc.get(f"msm_accumulate_{tag}_bytes_per_launch")
+        return f / traffic_cal + w if traffic_cal else f + w
+    traffic = calibrated("g1") if pmc else None
+    traffic_note = (f"HBM bytes per launch = FETCH_SIZE / {traffic_cal:.3f} + WRITE_SIZE: the FETCH_SIZE factor is this kernel's own (random 192-byte gathers, "
+                    "profiles/r05_fetch_size_calibration.json; the guide's 1/2 holds for wide coalesced streams and is reproduced there); raw counter sum in traffic_raw") \
+        if traffic_cal else "raw FETCH_SIZE + WRITE_SIZE (no calibration file)"
     if args.no_tables or n_constraints != 1 << 20 or args.parties != 2 or party_layout:
-        traffic, traffic_src, pmc = None, None, {}        # the profile is of the default configuration only
+        traffic, traffic_src, pmc, traffic_raw = None, None, {}, None        # the profile is of the default configuration only
     clk1 = pmc.get("k_accumulate_u_effective_clock_ghz")   # GRBM_GUI_ACTIVE / XCDs / duration under the same command
     clk2 = pmc.get("k_accumulate_u2_effective_clock_ghz")
 
@@ -1033,8 +1083,8 @@ def main():
                    "layout": args.layout, "results_sha256": digest, "window_tables": not args.no_tables},
         "roofline": {"bound": "hbm", "kernel": ("k_accumulate_te (G1 bucket accumulation, twisted Edwards extended coordinates, unsaturated limbs)" if te else
                                                 "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)"), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                     "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": traffic_note if traffic is not None else None,
+                     "traffic_source": traffic_src, "avg_launch_ms": acc_ms / max(1, acc_n), "launches": int(acc_n),
                      "algorithmic_bytes_per_launch": alg_bytes / launches,
                      "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md",
                      "valu": valu_view(mad_gops, mads_g1, madds, acc_ms, clk1,
@@ -1044,7 +1094,8 @@ def main():
                                        "under one reduction (574) -> 3416 per mixed addition, no carry instructions (csrc/fqu.h)")},
         # the second kernel of the critical stream: the same view for the G2 bucket accumulation (one launch per proof)
         "roofline_g2": {"bound": "hbm", "kernel": "k_accumulate_u2 (G2 bucket accumulation, Fq2 over unsaturated limbs)", "achieved": achieved2, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved2 / HBM_PEAK_GBS, "traffic": pmc.get("msm_accumulate_g2_bytes_per_launch"), "traffic_source": traffic_src,
+                        "unit": "GB/s", "frac": achieved2 / HBM_PEAK_GBS, "traffic": calibrated("g2") if pmc else None, "traffic_raw": pmc.get("msm_accumulate_g2_bytes_per_launch"),
+                        "traffic_source": traffic_src,
                         "avg_launch_ms": acc2_ms / max(1, acc2_n), "launches": int(acc2_n), "algorithmic_bytes_per_launch": alg2,
                         "valu": valu_view(mad2_gops, MADS_PER_MIXED_ADD_G2, madds2, acc2_ms, clk2,
                                           "Fq2 XYZZ mixed add: 6 Fq2 products (schoolbook, one reduction per component: 1148), 2 Fq2 squarings (756), Y3 as two "

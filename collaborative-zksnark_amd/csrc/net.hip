@@ -430,7 +430,11 @@ int exchange(czk_net* n, Op op, const void* send, size_t bytes, void* recv, int 
     if (bytes && ((sb && !send) || (rb && !recv))) return net_err(n, CZK_ERR_ARG, "czk_net: null buffer");
     if (mem == CZK_MEM_DEVICE && !n->ctx) return net_err(n, CZK_ERR_ARG, "czk_net: device buffers need a communicator created with a context");
     if (n->ctx) NET_HIP(n, hipSetDevice(n->ctx->device));
-    if (n->transport == CZK_NET_SHM) return shm_exchange(n, op, (const char*)send, bytes, (char*)recv, mem);
+    if (n->transport == CZK_NET_SHM) {
+        const int rc = shm_exchange(n, op, (const char*)send, bytes, (char*)recv, mem);
+        if (rc != CZK_OK) n->hdr->abort.store(1, std::memory_order_release);   // the peers leave their barrier at once instead of after timeout_ms
+        return rc;
+    }
     if (mem == CZK_MEM_DEVICE) return rccl_exchange_dev(n, op, (const char*)send, bytes, (char*)recv);
     // host buffers over RCCL (commitments, digests): staged through the communicator's device scratch, blocking
     const size_t ro = (sb + 15) & ~(size_t)15;

@@ -18,6 +18,10 @@ def init(backend: str | None = None):
     """Initialises the default process group from the torchrun environment (no-op for a single process)."""
     rank, world, local_rank = env_rank_world()
     if world > 1 and not dist.is_initialized():
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost", "::1"):
+            # one node: sockets on the loopback interface (gloo / RCCL bootstrap otherwise resolve the host's name first -- minutes where the resolver times out)
+            for k, v in (("GLOO_SOCKET_IFNAME", "lo"), ("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1")):
+                os.environ.setdefault(k, v)
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}

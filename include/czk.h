@@ -245,7 +245,9 @@ int czk_fr_gsz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t
  *   CZK_NET_SHM   parties are processes of one node in ANY assignment to GPUs -- several parties on ONE GPU included -- staged through a
  *                 POSIX shared-memory segment named by the id bytes (pinned by every party: two DMA copies per buffer).  For rigs with
  *                 fewer GPUs than parties and for tests; blocks the host for the duration of each exchange.  id: 1..32 arbitrary bytes
- *                 the launcher chooses, the same on every rank.  ctx may be NULL: host-memory primitives only (no composite opens).
+ *                 the launcher chooses, the same on every rank and FRESH for every communicator (czk_net_unique_id(CZK_NET_SHM) draws 16 random
+ *                 bytes: a rank that finds the segment of an earlier run under its id would wait there until the timeout).  ctx may be NULL:
+ *                 host-memory primitives only (no composite opens).  A failure on one rank aborts the communicator for all of them.
  * czk_net_create is collective (returns once every rank has joined; CZK_ERR_NET after the timeout).  All ranks call the same
  * sequence of exchanges, like the reference's lock-step rounds.  Buffers: `mem` = CZK_MEM_DEVICE (on the context's GPU, used in
  * stream order) or CZK_MEM_HOST (read / written before the call returns).  Byte counts must be equal on all ranks (mpc-net asserts it).

@@ -148,6 +148,9 @@ def _spdz_inputs(orc, world, n):
 
 def _open_worker(rank, world, q, idb, transport, share_device, n, slot_bytes):
     os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    # single node: RCCL's bootstrap on the loopback interface, no InfiniBand / MSCCL probing (they can stall for minutes on a box without network)
+    for k, v in (("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_IB_DISABLE", "1"), ("RCCL_MSCCL_ENABLE", "0"), ("RCCL_MSCCLPP_ENABLE", "0")):
+        os.environ.setdefault(k, v)
     for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     import torch
@@ -194,6 +197,7 @@ def _open_worker(rank, world, q, idb, transport, share_device, n, slot_bytes):
     check(5, net.spdz_batch_open(sh.data_ptr(), bad_mac.data_ptr(), alpha[rank], n, out.data_ptr()) == 2)
     # atomic_broadcast: the gathered vectors, deterministic commitment bytes; then a party whose data differs from what it committed to
     allx = torch.empty((world, n, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
     net.atomic_broadcast(sh.data_ptr(), n, allx.data_ptr(), rand32=bytes([rank + 1]) * 32)
     check(6, all(np.array_equal(host(allx)[p], shs[p]) for p in range(world)))
     # GSZ: degree-t shares; batch open, then king_compute with f = identity (the degree reduction of a product share)
@@ -211,6 +215,7 @@ def _open_worker(rank, world, q, idb, transport, share_device, n, slot_bytes):
             check(10, bad == (n if rank == 0 else 0))
     # king gather / scatter on Fr lanes
     g = torch.zeros((world, n, 4), dtype=torch.int64, device="cuda") if rank == 0 else None
+    torch.cuda.synchronize()                                  # (the fill runs on torch's stream, the gather on the context's)
     net.fr_send_to_king(sh.data_ptr(), n, g.data_ptr() if g is not None else None)
     if rank == 0:
         check(11, all(np.array_equal(host(g)[p], shs[p]) for p in range(world)))

@@ -6,8 +6,11 @@
 #include <cstdio>
 #include <cstring>
 
+#include <thread>
+
 #include "czk.hpp"
 #include "groth16_host.hpp"
+#include "polyvm_host.hpp"
 
 using namespace czk;
 
@@ -309,8 +312,194 @@ static int dump_inputs(int argc, char** argv) {
     return 0;
 }
 
+// `host_demo.bin plonk|marlin [--log-n K | --constraints N] [--parties P] [--steps S] [--warmup W] [--inflight F] [--arena-gb G] [--dump FILE]`:
+// BASELINE configs[2] / [3] (mpc-plonk's prover on GSZ lanes; Marlin's AHP rounds, commitments and batched openings on SPDZ lanes) from this
+// process alone -- tools/polyvm_host.hpp over include/czk.h, no torch, no Python: the synthetic circuit / index goes up once, S proofs run with F
+// in flight (one czk context and host thread each, sharing the registered SRS), commitments / evaluations / opening proofs come down.  Prints one
+// JSON line; --dump writes the last proof's outputs in the canonical text form tests/test_pipelines.py compares with the Python host's.
+static int polyiop(const char* workload, int argc, char** argv) {
+    const bool plonk = !strcmp(workload, "plonk");
+    size_t n = (size_t)1 << (plonk ? 18 : 20), parties = plonk ? 3 : 2, steps = 8, warmup = 2, inflight = 4;
+    double arena_gb = 0;
+    const char* dump = nullptr;
+    int rank = -1, world = 0, transport = CZK_NET_SHM, device = 0;
+    std::vector<uint8_t> id;
+    for (int i = 2; i < argc; i++) {
+        auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
+        if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
+        else if (!strcmp(argv[i], "--rank")) rank = atoi(val());
+        else if (!strcmp(argv[i], "--world")) world = atoi(val());
+        else if (!strcmp(argv[i], "--id")) id = unhex(val());
+        else if (!strcmp(argv[i], "--device")) device = atoi(val());
+        else if (!strcmp(argv[i], "--transport")) transport = !strcmp(val(), "rccl") ? CZK_NET_RCCL : CZK_NET_SHM;
+        else if (!strcmp(argv[i], "--constraints")) n = (size_t)atoll(val());
+        else if (!strcmp(argv[i], "--parties")) parties = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--steps")) steps = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--warmup")) warmup = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--inflight")) inflight = (size_t)atoi(val());
+        else if (!strcmp(argv[i], "--arena-gb")) arena_gb = atof(val());
+        else if (!strcmp(argv[i], "--dump")) dump = val();
+        else { printf("unknown argument %s\n", argv[i]); return 2; }
+    }
+    if (steps < 1 || inflight < 1 || parties < 1) { printf("%s: bad arguments\n", workload); return 2; }
+    // --world W: the reference's own layout, one process per party (parties = W), evaluations opened through czk::Net.  Without --rank this
+    // process only launches the W ranks (fork + exec with a fresh communicator id); rank r writes its dump to FILE.rank<r>.
+    const bool party = world > 0;
+    if (party && rank < 0) {
+        std::vector<uint8_t> b = Net::unique_id(transport);
+        const std::string hid = hex(b.data(), b.size());
+        std::vector<pid_t> kids;
+        for (int r = 0; r < world; r++) {
+            const pid_t pid = fork();
+            if (pid == 0) {
+                std::vector<std::string> a(argv, argv + argc);
+                a.insert(a.end(), {"--rank", std::to_string(r), "--id", hid});
+                std::vector<char*> av;
+                for (auto& x : a) av.push_back(&x[0]);
+                av.push_back(nullptr);
+                execv(argv[0], av.data());
+                _exit(127);
+            }
+            kids.push_back(pid);
+        }
+        int rc = 0;
+        for (pid_t k : kids) {
+            int st = 0;
+            waitpid(k, &st, 0);
+            if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;
+        }
+        return rc;
+    }
+    if (party) {
+        if (rank >= world || id.empty() || world < 2) { printf("%s: --world needs >= 2 ranks, --rank < world and --id\n", workload); return 2; }
+        parties = (size_t)world;
+        inflight = 1;
+        if (transport == CZK_NET_RCCL) device = rank;
+    }
+    inflight = std::min(inflight, steps);
+    // before HIP initialises: every context has four streams, so several proofs in flight need more hardware queues than the library's default
+    // of 8 (which its loader has already put into the environment: overwrite it)
+    if (inflight > 1) setenv("GPU_MAX_HW_QUEUES", "24", 1);
+    const size_t per_party = plonk ? 1 : 2;                         // GSZ: one lane per party; SPDZ: sh + mac
+    const size_t lanes = party ? per_party : per_party * parties;
+    std::vector<int> lift(lanes, plonk ? 1 : 0);                    // public addends: every GSZ lane; the king's sh and mac lanes
+    if (!plonk && (!party || rank == 0)) lift[0] = lift[1] = 1;
+    const size_t max_deg = plonk ? pvm::plonk_max_degree(n) : pvm::marlin_max_degree(n);
+    // arena: the live arrays of one proof peak at ~40 (plonk) / ~60 (marlin) arrays of the longest polynomial on every lane
+    const size_t arena_elems = arena_gb > 0 ? (size_t)(arena_gb * 1e9 / 32) : (size_t)(plonk ? 48 : 64) * lanes * (max_deg + 1) + (1 << 20);
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    struct Prover {
+        std::unique_ptr<Context> ctx;
+        std::unique_ptr<pvm::Machine> B;
+        pvm::PlonkInputs pin;
+        pvm::MarlinInputs min;
+        pvm::Output last;
+    };
+    std::vector<Prover> provers(inflight);
+    auto t_setup = clk::now();
+    std::unique_ptr<Net> net;
+    for (size_t k = 0; k < inflight; k++) {
+        provers[k].ctx.reset(new Context(device));
+        provers[k].B.reset(new pvm::Machine(*provers[k].ctx, lanes, max_deg, lift, arena_elems, k ? provers[0].B->srs : nullptr));
+        if (party) {
+            net.reset(new Net(*provers[0].ctx, transport, rank, world, id));
+            pvm::Machine& M = *provers[0].B;
+            M.net = net.get();
+            M.net_gsz = plonk;
+            M.gsz_degree = (unsigned)((parties - 1) / 2);              // t = (n - 1) / 2 (share/gsz20/mod.rs:94-96)
+            M.mac_share = rank == 0 ? pvm::fr_one() : pvm::fr_zero();   // mac_share() = 1 on the king, 0 elsewhere (share/spdz.rs:30-37)
+        }
+        if (k == 0) provers[0].B->prepare(plonk ? pvm::plonk_commit_sizes(n) : pvm::marlin_commit_sizes(n));
+        if (plonk) provers[k].pin = pvm::plonk_inputs(*provers[k].B, n);
+        else provers[k].min = pvm::marlin_inputs(*provers[k].B, n);
+        provers[k].ctx->sync();
+    }
+    const double setup_s = secs(t_setup, clk::now());
+    auto prove = [&](Prover& p) { p.last = plonk ? pvm::plonk_prove(*p.B, p.pin) : pvm::marlin_prove(*p.B, p.min); };
+    auto run = [&](const std::vector<size_t>& share) {
+        std::vector<std::thread> th;
+        std::vector<std::string> errs(share.size());
+        for (size_t k = 0; k < share.size(); k++)
+            th.emplace_back([&, k] {
+                try {
+                    for (size_t i = 0; i < share[k]; i++) prove(provers[k]);
+                } catch (const Panic& e) {
+                    errs[k] = e.what();
+                }
+            });
+        for (auto& t : th) t.join();
+        for (auto& e : errs)
+            if (!e.empty()) throw Panic(CZK_ERR_HIP, e);
+    };
+    auto t0 = clk::now();
+    prove(provers[0]);
+    const double first_ms = secs(t0, clk::now()) * 1e3;
+    run(std::vector<size_t>(inflight, std::max<size_t>(1, warmup ? warmup - 1 : 0)));
+    t0 = clk::now();
+    prove(provers[0]);                                             // one proof alone
+    const double alone_ms = secs(t0, clk::now()) * 1e3;
+    for (auto& p : provers) p.B->msm_count = p.B->ntt_count = p.B->msm_points = 0;
+    std::vector<size_t> share(inflight);
+    for (size_t k = 0; k < inflight; k++) share[k] = steps / inflight + (k < steps % inflight ? 1 : 0);
+    t0 = clk::now();
+    run(share);
+    const double dt = secs(t0, clk::now());
+    const std::string ref = pvm::dump_output(provers[0].last);
+    for (size_t k = 1; k < inflight; k++) REQUIRE(pvm::dump_output(provers[k].last) == ref);   // the in-flight provers run the same deterministic inputs
+    uint8_t digest[32];
+    czk_sha256(ref.data(), ref.size(), digest);
+    if (dump) {
+        const std::string path = party ? std::string(dump) + ".rank" + std::to_string(rank) : std::string(dump);
+        FILE* f = fopen(path.c_str(), "w");
+        REQUIRE(f != nullptr);
+        fputs(ref.c_str(), f);
+        fclose(f);
+    }
+    if (party) {
+        net->barrier();
+        if (rank != 0) {
+            provers[0].last = pvm::Output();
+            provers[0].pin = pvm::PlonkInputs();
+            provers[0].min = pvm::MarlinInputs();
+            provers[0].B->net = nullptr;
+            net.reset();
+            return 0;
+        }
+    }
+    size_t msms = 0, ntts = 0;
+    for (auto& p : provers) msms += p.B->msm_count, ntts += p.B->ntt_count;
+    printf("{\"harness\": \"tools/host_demo.cpp %s (C++ over include/czk.h: tools/polyvm_host.hpp; no torch, no Python)\", \"workload\": \"%s\", \"constraints\": %zu, "
+           "\"parties\": %zu, \"layout\": \"%s\", \"share_lanes\": %zu, \"steps\": %zu, \"warmup\": %zu, \"proofs_in_flight\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, "
+           "\"latency_ms_single_proof\": %.3f, \"first_proof_ms\": %.3f, \"setup_s\": %.3f, \"msms_per_proof\": %.1f, \"ntt_lanes_per_proof\": %.1f, "
+           "\"arena_peak_gb\": %.2f, \"in_flight_provers_equal\": true, \"output_sha256\": \"%s\"}\n",
+           workload, workload, n, parties, party ? "party (one process per party, evaluations opened through czk_net)" : "one process", lanes, steps, warmup,
+           inflight, dt / steps * 1e3, steps / dt, alone_ms, first_ms, setup_s, (double)msms / steps,
+           (double)ntts / steps, provers[0].B->arena_peak_bytes() / 1e9, hex(digest, 32).c_str());
+    if (net) {
+        provers[0].B->net = nullptr;
+        net.reset();   // the communicator goes before its context
+    }
+    // the machines go before their contexts, the shared SRS last
+    for (size_t k = provers.size(); k-- > 1;) {
+        provers[k].last = pvm::Output();
+        provers[k].pin = pvm::PlonkInputs();
+        provers[k].min = pvm::MarlinInputs();
+        provers[k].B.reset();
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && strcmp(argv[1], "inputs") == 0) return dump_inputs(argc, argv);
+    if (argc > 1 && (strcmp(argv[1], "plonk") == 0 || strcmp(argv[1], "marlin") == 0)) {
+        try {
+            return polyiop(argv[1], argc, argv);
+        } catch (const Panic& p) {
+            printf("FAILED: czk::Panic %d: %s\n", p.code, p.what());
+            return 1;
+        }
+    }
     if (argc > 1 && strcmp(argv[1], "party-launch") == 0) return party_launch(argc, argv);
     if (argc > 1 && strcmp(argv[1], "party") == 0) {
         try {
