@@ -347,8 +347,8 @@ def _json_tail(proc):
 def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, extra):
     """One process per MPC party, each a C++ host over include/czk.hpp whose opens run through czk::Net (SHM transport: the processes
     share this box's GPU): the proof's group elements (digest over all parties' affine results, bench.py's order) must equal
-    (a) the same C++ host with all parties' lanes in one process, (b) bench.py's one-GPU layout and (c) bench.py's party layout over
-    torch.distributed -- four hosts / layouts, one digest."""
+    (a) the same C++ host with all parties' lanes in one process, (b) bench.py's one-GPU layout, (c) bench.py's party layout over
+    torch.distributed and (d) over czk_net -- five hosts / layouts, one digest."""
     import subprocess
     from test_abi import _build_host_demo
     exe = _build_host_demo()
@@ -367,6 +367,13 @@ def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, e
     py_one = _json_tail(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
     py_party = _json_tail(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--layout", "party", "--backend", "gloo", "--device", "0"]
                                          + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
-    assert py_one["results_checked"] and py_party["results_checked"]
-    digests = {cpp_party["results_sha256"], cpp_one["results_sha256"], py_one["config"]["results_sha256"], py_party["config"]["results_sha256"]}
-    assert len(digests) == 1, (cpp_party["results_sha256"], cpp_one["results_sha256"], py_one["config"]["results_sha256"], py_party["config"]["results_sha256"])
+    # (d) the Python host in the party layout with the opens through the SAME communicator calls the C++ host makes (bench.py --net czk:
+    # parallel.use_net; shared-memory transport, torch.distributed only carries the communicator id)
+    py_party_czk = _json_tail(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--layout", "party", "--backend", "gloo", "--device", "0",
+                                              "--net", "czk"] + common + (["--commit-opens"] if "--commit-opens" in extra else []),
+                                             capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
+    assert py_one["results_checked"] and py_party["results_checked"] and py_party_czk["results_checked"]
+    assert py_party["net"] == "torch.distributed" and py_party_czk["net"] == "czk_net shm"
+    all_digests = (cpp_party["results_sha256"], cpp_one["results_sha256"], py_one["config"]["results_sha256"], py_party["config"]["results_sha256"],
+                   py_party_czk["config"]["results_sha256"])
+    assert len(set(all_digests)) == 1, all_digests
