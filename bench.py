@@ -217,15 +217,37 @@ def multi_gpu_plan(n: int) -> list:
             ("groth16_spdz8_2e22_no_tables", ["--workload", "groth16", "--parties", "8", "--log-n", "22", "--steps", "3", "--warmup", "1", "--no-seam-report",
                                               "--no-tables"])],
     }.get(n, [(f"groth16_spdz{n}_2e20", g16_20 + ["--parties", str(n)])])
+    # Most decisive first (the budget may cut the list short): the party layout through the library's own communicator, then through torch.distributed,
+    # ring before p2p; then the one-GPU reference runs that the digests are compared with (a party digest that equals the other party digests of
+    # its config is already strong evidence); then the split layout.
     plan = []
+    for net, exch in (("czk", "ring"), ("torch", "ring"), ("czk", "p2p"), ("torch", "p2p")):
+        for key, argv in cfgs:
+            if key.endswith("_no_tables") and exch == "p2p":
+                continue
+            plan.append((f"{key}/party/{net}/{exch}", ["--gpus", str(n), "--layout", "party", "--exchange", exch, "--net", net] + argv, key + "/one_gpu"))
+    plan.append(("groth16_spdz2_2e20/split", ["--gpus", str(n), "--layout", "split", "--parties", "2"] + g16_20, "headline"))
     for key, argv in cfgs:
         one_gpu = argv + (["--no-tables"] if "--log-n" in argv and argv[argv.index("--log-n") + 1] == "22" and "--no-tables" not in argv else [])
-        ref = key + "/one_gpu"
-        plan.append((ref, ["--gpus", "1", "--inflight", "1"] + one_gpu, None))           # all parties' lanes on ONE GPU: the digest every party layout must reproduce
-        for exch, net in (_EXCH if not key.endswith("_no_tables") else _EXCH[:1] + _EXCH[2:3]):
-            plan.append((f"{key}/party/{net}/{exch}", ["--gpus", str(n), "--layout", "party", "--exchange", exch, "--net", net] + argv, ref))
-    plan.append(("groth16_spdz2_2e20/split", ["--gpus", str(n), "--layout", "split", "--parties", "2"] + g16_20, "headline"))
+        plan.append((key + "/one_gpu", ["--gpus", "1", "--inflight", "1"] + one_gpu, None))   # all parties' lanes on ONE GPU: the digest every party layout must reproduce
     return plan
+
+
+def _run_child(cmd, env, timeout):
+    """subprocess.run with the child in its own process group, so that a timeout takes the launcher, its torchrun and every rank down together
+    (an orphaned rank would keep its GPU into the next run)"""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)       # exactly the group this call created
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        return 124, out, err + "\n[bench.py] child exceeded its time budget and was killed with its process group"
+    return p.returncode, out, err
 
 
 def multi_gpu_report(n: int, headline: dict, dry_run: bool, budget_s: float) -> dict:
@@ -254,10 +276,10 @@ def multi_gpu_report(n: int, headline: dict, dry_run: bool, budget_s: float) -> 
         cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-workloads", "--no-multi-gpu-report"] + argv + (["--dry-run"] if dry_run else [])
         t0 = time.time()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=min(600.0, left), env=env)
-            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode != 0 or not line:
-                out[key] = {"error": (r.stdout + r.stderr)[-400:], "command": "python bench.py " + " ".join(argv)}
+            rc, c_out, c_err = _run_child(cmd, env, min(420.0, left))
+            line = [ln for ln in c_out.splitlines() if ln.startswith("{")]
+            if rc != 0 or not line:
+                out[key] = {"error": (c_out + c_err)[-400:], "command": "python bench.py " + " ".join(argv)}
                 continue
             j = json.loads(line[-1])
             if dry_run:
@@ -270,10 +292,17 @@ def multi_gpu_report(n: int, headline: dict, dry_run: bool, budget_s: float) -> 
                         "n_gpus": j["n_gpus"], "ranks_seen_by_backend": j.get("ranks_seen_by_backend"), "backend": j.get("backend"), "net": j.get("net"),
                         "layout": j["config"].get("layout"), "exchange": argv[argv.index("--exchange") + 1] if "--exchange" in argv else None,
                         "per_rank": j.get("per_rank"), "results_checked": bool(j.get("results_checked")), "results_sha256": dg,
-                        "reference": ref, "digest_equals_reference": (dg == digests.get(ref)) if ref and digests.get(ref) else None,
-                        "wall_s": time.time() - t0, "command": "python bench.py " + " ".join(argv)}
+                        "reference": ref, "wall_s": time.time() - t0, "command": "python bench.py " + " ".join(argv)}
         except Exception as e:      # noqa: BLE001 -- the report must not take the replica line down with it
             out[key] = {"error": repr(e)[-400:], "command": "python bench.py " + " ".join(argv)}
+    # digests: against the one-GPU reference where it ran, and among the layouts of one config in any case
+    for key, v in out.items():
+        if "results_sha256" not in v:
+            continue
+        ref = v.get("reference")
+        v["digest_equals_reference"] = (v["results_sha256"] == digests[ref]) if ref and digests.get(ref) else None
+        peers = [w["results_sha256"] for k2, w in out.items() if k2 != key and k2.split("/")[0] == key.split("/")[0] and "/party/" in k2 and "results_sha256" in w]
+        v["digest_equals_other_party_runs"] = all(d == v["results_sha256"] for d in peers) if peers and "/party/" in key else None
     return out
 
 
@@ -837,7 +866,7 @@ def main():
                                                                                              "(e.g. msm_window_g1=18); repeatable")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--no-multi-gpu-report", action="store_true", help="--gpus N > 1, replica layout: skip the party / split layout children rank 0 runs after the replica line")
-    ap.add_argument("--report-budget-s", type=float, default=540.0, help="wall-clock budget of the multi-GPU report; children that would start beyond it are skipped")
+    ap.add_argument("--report-budget-s", type=float, default=240.0, help="wall-clock budget of the multi-GPU report; children that would start beyond it are skipped")
     ap.add_argument("--dry-run", action="store_true", help="launcher / process-group check only: no GPU work (CPU test of --gpus N)")
     args = ap.parse_args()
 

@@ -93,6 +93,13 @@ def test_party_per_rank_layout_of_the_polynomial_provers_matches_the_one_gpu_lay
     assert d1["results_checked"] and d2["results_checked"]
     assert "batches per proof" in d2["config"]["workload"] and ", 0 batches" not in d2["config"]["workload"]
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
+    # the same layout with the opens through the library's own communicator (czk_net, shared-memory transport: parallel.use_net)
+    czkn = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo", "--device", "0", "--net", "czk"]
+                          + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert czkn.returncode == 0, czkn.stderr[-2000:]
+    d3 = json.loads(czkn.stdout.strip().splitlines()[-1])
+    assert d3["net"] == "czk_net shm" and d3["results_checked"] and d3["config"]["results_sha256"] == d1["config"]["results_sha256"]
+    assert "batches per proof" in d3["config"]["workload"] and ", 0 batches" not in d3["config"]["workload"]
 
 
 def _load_cpp_dump(path):
