@@ -682,13 +682,40 @@ def test_party_per_rank_layout_matches_single_gpu_layout(parties, size):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
-    assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo",
+    assert one.returncode == 0, __import__('util').child_errors(one.stderr)
+    two = __import__('util').run_ranks([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo",
                           "--device", "0"] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
-    assert two.returncode == 0, two.stderr[-2000:]
+    assert two.returncode == 0, __import__('util').child_errors(two.stderr)
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     d2 = json.loads(two.stdout.strip().splitlines()[-1])
     assert d2["n_gpus"] == parties and d2["ranks_seen_by_backend"] == parties and d2["config"]["layout"] == "party"
+    assert d1["results_checked"] and d2["results_checked"]
+    assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
+
+
+@pytest.mark.parametrize("scheme,parties,net", [("gsz", 3, "torch"), ("gsz", 4, "czk"), ("hbc", 3, "czk")])
+def test_party_layout_under_the_other_sharings(scheme, parties, net):
+    """bench.py --layout party for the reference's other sharings: HBC (AdditiveFieldShare::batch_open between the ranks) and GSZ (one Shamir lane per
+    rank; the product's degree reduction is gsz20::batch_king_compute -- every rank's lane to the king, open at degree 2t, the value back to everyone),
+    over torch.distributed and over the library's communicator (czk_net, shared memory: the ranks share this box's GPU).  Same proof elements as the
+    layout with all parties' lanes on one GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--constraints", "1000", "--parties", str(parties), "--scheme", scheme, "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-seam-report",
+              "--no-other-workloads"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert one.returncode == 0, __import__('util').child_errors(one.stderr)
+    many = __import__('util').run_ranks([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo", "--device", "0", "--net", net]
+                          + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert many.returncode == 0, __import__('util').child_errors(many.stderr)
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    d2 = json.loads(many.stdout.strip().splitlines()[-1])
+    assert d2["n_gpus"] == parties and d2["config"]["layout"] == "party" and d2["net"] == ("czk_net shm" if net == "czk" else "torch.distributed")
     assert d1["results_checked"] and d2["results_checked"]
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
 
@@ -1427,10 +1454,10 @@ def test_groth16_intra_party_split_matches_the_one_gpu_layout(ranks, size):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
-    assert one.returncode == 0, one.stderr[-2000:]
-    many = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--layout", "split", "--backend", "gloo",
+    assert one.returncode == 0, __import__('util').child_errors(one.stderr)
+    many = __import__('util').run_ranks([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--layout", "split", "--backend", "gloo",
                            "--device", "0"] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
-    assert many.returncode == 0, many.stderr[-2000:]
+    assert many.returncode == 0, __import__('util').child_errors(many.stderr)
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     d2 = json.loads(many.stdout.strip().splitlines()[-1])
     assert d2["n_gpus"] == ranks and d2["ranks_seen_by_backend"] == ranks and d2["config"]["layout"] == "split" and d2["scaling"] == "strong"

@@ -338,7 +338,7 @@ def test_wire_format_through_the_abi(orc):
 # ---- the party layout from a compiled host: tools/host_demo.cpp `party` ------------------------------------------------------------------
 def _json_tail(proc):
     import json
-    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    assert proc.returncode == 0, proc.stdout[-1500:] + __import__('util').child_errors(proc.stderr)
     return json.loads(proc.stdout.strip().splitlines()[-1])
 
 
@@ -355,7 +355,7 @@ def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, e
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     tables = [] if "--no-tables" not in extra else ["--no-tables"]
-    cpp_party = _json_tail(subprocess.run([exe, "party-launch", "--world", str(world), "--steps", "2", "--warmup", "1"] + size + extra,
+    cpp_party = _json_tail(__import__("util").run_ranks([exe, "party-launch", "--world", str(world), "--steps", "2", "--warmup", "1"] + size + extra,
                                           capture_output=True, text=True, timeout=600, env=env))
     assert cpp_party["layout"] == "party" and cpp_party["parties"] == world and cpp_party["share_lanes_per_process"] == 2
     # 2 opens per proof, each one broadcast of the sh lane + one (atomic: two) of dx_t -- the reference's message count (spdz.rs:166-185)
@@ -365,11 +365,11 @@ def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, e
                                         capture_output=True, text=True, timeout=600, env=env))
     common = size + tables + ["--parties", str(world), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-seam-report", "--no-other-workloads"]
     py_one = _json_tail(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
-    py_party = _json_tail(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--layout", "party", "--backend", "gloo", "--device", "0"]
+    py_party = _json_tail(__import__('util').run_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--layout", "party", "--backend", "gloo", "--device", "0"]
                                          + common, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
     # (d) the Python host in the party layout with the opens through the SAME communicator calls the C++ host makes (bench.py --net czk:
     # parallel.use_net; shared-memory transport, torch.distributed only carries the communicator id)
-    py_party_czk = _json_tail(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--layout", "party", "--backend", "gloo", "--device", "0",
+    py_party_czk = _json_tail(__import__('util').run_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--layout", "party", "--backend", "gloo", "--device", "0",
                                               "--net", "czk"] + common + (["--commit-opens"] if "--commit-opens" in extra else []),
                                              capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
     assert py_one["results_checked"] and py_party["results_checked"] and py_party_czk["results_checked"]

@@ -83,10 +83,10 @@ def test_party_per_rank_layout_of_the_polynomial_provers_matches_the_one_gpu_lay
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
-    assert one.returncode == 0, one.stderr[-2000:]
-    many = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo", "--device", "0"]
+    assert one.returncode == 0, __import__('util').child_errors(one.stderr)
+    many = __import__('util').run_ranks([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo", "--device", "0"]
                           + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
-    assert many.returncode == 0, many.stderr[-2000:]
+    assert many.returncode == 0, __import__('util').child_errors(many.stderr)
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     d2 = json.loads(many.stdout.strip().splitlines()[-1])
     assert d2["n_gpus"] == parties and d2["ranks_seen_by_backend"] == parties and d2["config"]["layout"] == "party"
@@ -94,9 +94,9 @@ def test_party_per_rank_layout_of_the_polynomial_provers_matches_the_one_gpu_lay
     assert "batches per proof" in d2["config"]["workload"] and ", 0 batches" not in d2["config"]["workload"]
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
     # the same layout with the opens through the library's own communicator (czk_net, shared-memory transport: parallel.use_net)
-    czkn = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo", "--device", "0", "--net", "czk"]
+    czkn = __import__('util').run_ranks([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(parties), "--layout", "party", "--backend", "gloo", "--device", "0", "--net", "czk"]
                           + common, capture_output=True, text=True, timeout=280, env=env, cwd=root)
-    assert czkn.returncode == 0, czkn.stderr[-2000:]
+    assert czkn.returncode == 0, __import__('util').child_errors(czkn.stderr)
     d3 = json.loads(czkn.stdout.strip().splitlines()[-1])
     assert d3["net"] == "czk_net shm" and d3["results_checked"] and d3["config"]["results_sha256"] == d1["config"]["results_sha256"]
     assert "batches per proof" in d3["config"]["workload"] and ", 0 batches" not in d3["config"]["workload"]
@@ -188,7 +188,7 @@ def test_cpp_polynomial_machine_party_layout_matches_one_process(tmp_path, workl
     assert r.returncode == 0, r.stdout + r.stderr
     want = _load_cpp_dump(one)
     base = str(tmp_path / "party.json")
-    r = subprocess.run([exe, workload, "--constraints", str(size), "--world", str(world), "--steps", "2", "--warmup", "1", "--dump", base],
+    r = __import__("util").run_ranks([exe, workload, "--constraints", str(size), "--world", str(world), "--steps", "2", "--warmup", "1", "--dump", base],
                        capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and '"layout": "party' in r.stdout, r.stdout + r.stderr
     import json

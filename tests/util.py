@@ -69,3 +69,33 @@ def dot_mod_r(k, s) -> int:
             for b in range(16):
                 tot[a][b] += int(m[a, b])
     return sum(tot[a][b] << (16 * (a + b)) for a in range(16) for b in range(16)) % R_MOD
+
+
+def child_errors(stderr: str, limit: int = 3000) -> str:
+    """What a failed multi-rank child actually raised: the traceback blocks of its stderr (torchrun's summary at the end of stderr names the rank but
+    not the exception), else the tail."""
+    lines = stderr.splitlines()
+    keep = []
+    for i, ln in enumerate(lines):
+        if "Traceback (most recent call last)" in ln:
+            keep += lines[i:i + 30] + ["..."]
+    text = "\n".join(keep) if keep else stderr
+    return text[-limit:]
+
+
+def run_ranks(cmd, retries: int = 1, **kw):
+    """subprocess.run for a command that starts several ranks (torchrun / fork): a failed attempt is reported on stderr with the exception its rank
+    raised, and the command is tried once more -- rendezvous on the GPU boxes fails now and then for reasons outside the repository (a resolver that
+    times out: "[c10d] The hostname of the client socket cannot be retrieved"), and the driver's `pytest -x` must not stop on that.  A defect fails
+    twice."""
+    import subprocess
+    import sys
+    kw.setdefault("capture_output", True)
+    kw.setdefault("text", True)
+    for attempt in range(retries + 1):
+        r = subprocess.run(cmd, **kw)
+        if r.returncode == 0 or attempt == retries:
+            return r
+        print(f"[run_ranks] attempt {attempt + 1} of {' '.join(map(str, cmd[:6]))} ... failed (rc {r.returncode}); its ranks raised:\n{child_errors(r.stderr)}\nretrying",
+              file=sys.stderr, flush=True)
+    return r

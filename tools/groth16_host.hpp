@@ -288,14 +288,12 @@ class Groth16Host {
     // A public group element meets a share through `shift`: the king's lanes (sh, and mac under the stand-in key 1) add it, the others do not.
     // Returns every local lane's share of the proof; the parties' sh lanes sum to Proof{a, b, c}.
     std::vector<ProofShare> create_proof(const ProofElements& e, const czk::BigInteger256& r, const czk::BigInteger256& s) const {
-        const czk_ctx* c = ctx.raw();
         auto mul1 = [&](const czk::G1Projective& p, const czk::BigInteger256& k) { czk::G1Projective o; ctx.check(czk_jac_scalar_mul(ctx.raw(), CZK_G1, p.x.l, k.l, CZK_SCALAR_CANONICAL, o.x.l)); return o; };
         auto mul2 = [&](const czk::G2Projective& p, const czk::BigInteger256& k) { czk::G2Projective o; ctx.check(czk_jac_scalar_mul(ctx.raw(), CZK_G2, p.x.c0.l, k.l, CZK_SCALAR_CANONICAL, o.x.c0.l)); return o; };
         auto add1 = [&](const czk::G1Projective& p, const czk::G1Projective& q) { czk::G1Projective o; ctx.check(czk_jac_add(ctx.raw(), CZK_G1, p.x.l, q.x.l, o.x.l)); return o; };
         auto add2 = [&](const czk::G2Projective& p, const czk::G2Projective& q) { czk::G2Projective o; ctx.check(czk_jac_add(ctx.raw(), CZK_G2, p.x.c0.l, q.x.c0.l, o.x.c0.l)); return o; };
         auto mix1 = [&](const czk::G1Projective& p, const uint64_t* aff, bool inf) { czk::G1Projective o; ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, p.x.l, aff, inf, o.x.l)); return o; };
         auto mix2 = [&](const czk::G2Projective& p, const uint64_t* aff, bool inf) { czk::G2Projective o; ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G2, p.x.c0.l, aff, inf, o.x.c0.l)); return o; };
-        (void)c;
         const czk::G1Projective zero1{};   // z == 0: the identity (is_zero tests z alone)
         const czk::G2Projective zero2{};
         const czk::G1Projective delta_g1 = mix1(zero1, &pk_g1_[2 * 12], false);        // pk.delta_g1.into_projective()
