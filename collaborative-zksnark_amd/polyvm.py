@@ -333,10 +333,25 @@ class GpuBackend(Backend):
 
     def resized(self, a, n):
         lanes, have = a.shape[0], a.shape[1]
+        if n == have:
+            return a                      # arrays are never written in place: the same array serves (`resize` to the current length is a no-op)
         out = self._new(lanes, n)
         m = min(n, have)
         self._copy(out, 0, (0, n, 1), a, 0, (0, have, 1), (1, lanes, m))
         self._copy(out, m, (0, n, 1), None, 0, None, (1, lanes, n - m))      # only the tail is cleared
+        return out
+
+    def lifted(self, a_public):
+        """the public array on the lifting lanes, zero elsewhere: runs of equal lanes are one copy (source lane stride 0) or one fill each"""
+        n = a_public.shape[1]
+        out = self._new(self.lanes, n)
+        at = 0
+        while at < self.lanes:
+            end = at
+            while end < self.lanes and self.lift[end] == self.lift[at]:
+                end += 1
+            self._copy(out, at * n, (0, n, 1), a_public if self.lift[at] else None, 0, (0, 0, 1) if self.lift[at] else None, (1, end - at, n))
+            at = end
         return out
 
     def drop_first(self, a, k):

@@ -273,14 +273,20 @@ class Machine {
         }
         return o;
     }
-    Arr lifted(const Arr& a_public) {   // the public array on the lifting lanes, zero elsewhere
-        Arr z = zeros(1, a_public.n);
-        std::vector<Arr> parts;
-        for (int w : lift) parts.push_back(w ? a_public : z);
-        return lane_stack(parts);
+    Arr lifted(const Arr& a_public) {   // the public array on the lifting lanes, zero elsewhere: runs of equal lanes are one copy (source lane stride 0) or one fill
+        const size_t n = a_public.n;
+        Arr o = alloc(lanes, n);
+        for (size_t at = 0; at < lanes;) {
+            size_t end = at;
+            while (end < lanes && lift[end] == lift[at]) end++;
+            copy(o, at * n, {0, n, 1}, lift[at] ? &a_public : nullptr, 0, {0, 0, 1}, {1, end - at, n});
+            at = end;
+        }
+        return o;
     }
     Arr shared_copy(const Arr& a_public) { return lane_stack(std::vector<Arr>(lanes, a_public)); }
     Arr resized(const Arr& a, size_t n) {
+        if (n == a.n) return a;   // arrays are never written in place: the same array serves
         Arr o = alloc(a.lanes, n);
         const size_t m = std::min(n, a.n);
         copy(o, 0, {0, n, 1}, &a, 0, {0, a.n, 1}, {1, a.lanes, m});
