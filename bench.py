@@ -726,7 +726,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     res = {
         "metric": f"collaborative {'Plonk' if plonk else 'Marlin'} proofs/sec (BLS12-377, {size_txt} constraints, {scheme} N={args.parties})",
         "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "ranks_seen_by_backend": world, "backend": args.backend if world > 1 else None,
-        "net": (("czk_net " + ("rccl" if args.backend == "nccl" else "shm")) if parallel.get_net() is not None else "torch.distributed") if party else None,
+        "net": (("czk_net " + args.net_transport) if parallel.get_net() is not None else "torch.distributed") if party else None,
         "steps": args.steps, "warmup": args.warmup, "per_rank": per_rank,
         "ms_per_step": dt / args.steps * 1e3, "first_proof_ms": first_ms, "higher_is_better": True, "scaling": "strong" if party else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic", **checked,
@@ -857,11 +857,12 @@ def main():
                                                                                       "products through the king's degree-reduction open) -- mpc-snarks/src/proof.rs:379-387")
     ap.add_argument("--exchange", choices=("ring", "p2p"), default="ring", help="party layout over RCCL: the opens' share exchange as one ring all-gather or as "
                                                                                  "world - 1 grouped point-to-point copies (parallel.set_exchange)")
-    ap.add_argument("--net", choices=("torch", "czk"), default="torch", help="party layout: the opens' transport.  torch: torch.distributed collectives issued from "
+    ap.add_argument("--net", choices=("torch", "czk", "czk-ipc"), default="torch", help="party layout: the opens' transport.  torch: torch.distributed collectives issued from "
                                                                                "Python (RCCL through torch, or gloo through the host); czk: the library's own communicator "
                                                                                "(czk_net_*, include/czk.h -- what a compiled host calls): RCCL inside the library when --backend nccl, "
-                                                                               "shared memory between the ranks' processes otherwise; torch.distributed then only carries the "
-                                                                               "communicator id and the timing reduction")
+                                                                               "shared memory between the ranks' processes otherwise (czk-ipc: device mailboxes mapped between the "
+                                                                               "processes with hipIpc instead of host staging); torch.distributed then only carries the communicator id "
+                                                                               "and the timing reduction")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE", help="czk_ctx_set_option on every context before any key is registered "
                                                                                              "(e.g. msm_window_g1=18); repeatable")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
@@ -920,8 +921,9 @@ def main():
     ctx = czk.Context(device, tstream.cuda_stream, options=ctx_options)
     assert tstream.cuda_stream != 0
     parallel.set_exchange(args.exchange)
-    if args.net == "czk" and args.layout == "party" and world > 1:
-        parallel.use_net(parallel.make_net(ctx, "rccl" if args.backend == "nccl" else "shm", device=torch.device("cuda", device) if args.backend == "nccl" else None))
+    if args.net != "torch" and args.layout == "party" and world > 1:
+        args.net_transport = "ipc" if args.net == "czk-ipc" else "rccl" if args.backend == "nccl" else "shm"
+        parallel.use_net(parallel.make_net(ctx, args.net_transport, device=torch.device("cuda", device) if args.backend == "nccl" else None))
     if args.workload != "groth16":
         return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)
     if party_layout:
@@ -1072,7 +1074,7 @@ def main():
         "n_gpus": world,
         "ranks_seen_by_backend": ranks_seen,
         "backend": args.backend if world > 1 else None,
-        "net": (("czk_net " + ("rccl" if args.backend == "nccl" else "shm")) if parallel.get_net() is not None else "torch.distributed") if party_layout else None,
+        "net": (("czk_net " + args.net_transport) if parallel.get_net() is not None else "torch.distributed") if party_layout else None,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,

@@ -8,7 +8,7 @@ There is no CPU fallback: importing `czk_amd.lib()` fails loudly if libczk_hip.s
 this package imports the checker under oracle/.
 """
 from .binding import (CZK_FFT, CZK_IFFT, CZK_COSET_FFT, CZK_COSET_IFFT, CZK_MEM_HOST, CZK_MEM_DEVICE, CZK_MEM_NO_TABLES, CZK_MEM_ANY_POINTS, CZK_MEM_CHECK_SUBGROUP,  # noqa: F401
-                      CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY, CZK_G1, CZK_G2, CzkError, Context, Bases, Net, CZK_NET_RCCL, CZK_NET_SHM, lib,
+                      CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY, CZK_G1, CZK_G2, CzkError, Context, Bases, Net, CZK_NET_RCCL, CZK_NET_SHM, CZK_NET_IPC, lib,
                       lib_path, lab_lib, exported_symbols, header_symbols)
 from . import binding  # noqa: F401
 from .build import build  # noqa: F401

@@ -21,7 +21,7 @@ CZK_MEM_CHECK_SUBGROUP = 128  # czk_bases_register: verify [r] P == infinity; a 
 CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY = 0, 1
 CZK_G1, CZK_G2 = 1, 2
 CZK_OP_ADD, CZK_OP_SUB, CZK_OP_MUL = 0, 1, 2
-CZK_NET_RCCL, CZK_NET_SHM = 1, 2
+CZK_NET_RCCL, CZK_NET_SHM, CZK_NET_IPC = 1, 2, 3
 CZK_OPEN_COMMIT = 1
 CZK_ERR_NET, CZK_ERR_CHECK = 5, 6
 _STATUS = {1: "CZK_ERR_SIZE", 2: "CZK_ERR_HIP", 3: "CZK_ERR_ARG", 4: "CZK_ERR_NOMEM", 5: "CZK_ERR_NET", 6: "CZK_ERR_CHECK"}

@@ -176,6 +176,10 @@ struct czk_net {
     char* slots = nullptr;        // world x 2 x slot_bytes
     size_t slot_bytes = (size_t)16 << 20, data_bytes = 0;
     bool data_pinned = false;
+    // IPC (the SHM control block + one device mailbox per rank, mapped into every peer with hipIpc: staging never leaves device memory)
+    char* mailbox = nullptr;                 // this rank's 2 x slot_bytes, device memory
+    std::vector<char*> peer_mail;            // every rank's mailbox as this process sees it (own entry = mailbox)
+    bool shm_like() const { return transport == CZK_NET_SHM || transport == CZK_NET_IPC; }
     uint64_t seq = 0;             // chunk steps so far: parity of the slot in use
     bool reads_in_flight = false;
     // scratch on the context's GPU
@@ -278,7 +282,56 @@ int shm_map(czk_net* n, const std::string& name, size_t bytes, bool create, void
     return CZK_OK;
 }
 
+// IPC transport: every rank allocates its mailbox on its GPU, publishes the hipIpc handle through a small shared segment and maps the others'
+int ipc_data(czk_net* n) {
+    if (!n->peer_mail.empty()) return CZK_OK;
+    const std::string name = n->shm_name + ".h";
+    const size_t hb = (size_t)n->world * sizeof(hipIpcMemHandle_t);
+    if (n->rank == 0) n->hdr->slot_bytes.store(n->slot_bytes, std::memory_order_release);
+    void* p = nullptr;
+    int rc = CZK_OK;
+    if (n->rank == 0) rc = shm_map(n, name, hb, true, &p);
+    if (rc != CZK_OK) n->hdr->abort.store(1, std::memory_order_release);
+    CZK_TRY(rc);
+    CZK_TRY(shm_barrier(n));
+    if (n->rank != 0) {
+        n->slot_bytes = (size_t)n->hdr->slot_bytes.load(std::memory_order_acquire);
+        rc = shm_map(n, name, hb, false, &p);
+        if (rc != CZK_OK) n->hdr->abort.store(1, std::memory_order_release);
+        CZK_TRY(rc);
+    }
+    hipIpcMemHandle_t* handles = (hipIpcMemHandle_t*)p;
+    auto fail = [&](const std::string& msg) {
+        n->hdr->abort.store(1, std::memory_order_release);
+        munmap(p, hb);
+        return net_err(n, CZK_ERR_HIP, msg);
+    };
+    void* mb = nullptr;
+    if (hipMalloc(&mb, 2 * n->slot_bytes) != hipSuccess) return fail("hipMalloc mailbox");
+    n->mailbox = (char*)mb;
+    hipError_t e = hipIpcGetMemHandle(&handles[n->rank], mb);
+    if (e != hipSuccess) return fail(std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e) + " (HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment?)");
+    CZK_TRY(shm_barrier(n));   // every handle is published
+    std::vector<char*> peers((size_t)n->world, nullptr);
+    for (int r = 0; r < n->world; r++) {
+        if (r == n->rank) {
+            peers[r] = n->mailbox;
+            continue;
+        }
+        void* q = nullptr;
+        e = hipIpcOpenMemHandle(&q, handles[r], hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        peers[r] = (char*)q;
+    }
+    CZK_TRY(shm_barrier(n));   // everybody has every mailbox mapped
+    if (n->rank == 0) shm_unlink(name.c_str());
+    munmap(p, hb);
+    n->peer_mail = peers;
+    return CZK_OK;
+}
+
 int shm_data(czk_net* n) {   // the staging slots, created at the first exchange (so "slot_bytes" can be set after czk_net_create)
+    if (n->transport == CZK_NET_IPC) return ipc_data(n);
     if (n->slots) return CZK_OK;
     const std::string name = n->shm_name + ".d";
     if (n->rank == 0) n->hdr->slot_bytes.store(n->slot_bytes, std::memory_order_release);
@@ -306,9 +359,17 @@ int shm_data(czk_net* n) {   // the staging slots, created at the first exchange
     return CZK_OK;
 }
 
-inline char* shm_slot(czk_net* n, int owner, uint64_t parity) { return n->slots + ((size_t)owner * 2 + (parity & 1)) * n->slot_bytes; }
+inline char* shm_slot(czk_net* n, int owner, uint64_t parity) {
+    if (n->transport == CZK_NET_IPC) return n->peer_mail[(size_t)owner] + (parity & 1) * n->slot_bytes;
+    return n->slots + ((size_t)owner * 2 + (parity & 1)) * n->slot_bytes;
+}
 
 int shm_put(czk_net* n, char* slot, const void* src, size_t len, int mem, bool* wrote) {
+    if (n->transport == CZK_NET_IPC) {   // the slot is device memory (this rank's mailbox, or a peer's through its mapping)
+        NET_HIP(n, hipMemcpyAsync(slot, src, len, mem == CZK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, n->ctx->stream));
+        *wrote = true;
+        return CZK_OK;
+    }
     if (mem == CZK_MEM_DEVICE) {
         NET_HIP(n, hipMemcpyAsync(slot, src, len, hipMemcpyDeviceToHost, n->ctx->stream));
         *wrote = true;
@@ -318,6 +379,12 @@ int shm_put(czk_net* n, char* slot, const void* src, size_t len, int mem, bool* 
     return CZK_OK;
 }
 int shm_get(czk_net* n, void* dst, const char* slot, size_t len, int mem) {
+    if (n->transport == CZK_NET_IPC) {
+        NET_HIP(n, hipMemcpyAsync(dst, slot, len, mem == CZK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, n->ctx->stream));
+        if (mem == CZK_MEM_DEVICE) n->reads_in_flight = true;
+        else NET_HIP(n, hipStreamSynchronize(n->ctx->stream));   // host destination: complete before the call returns
+        return CZK_OK;
+    }
     if (mem == CZK_MEM_DEVICE) {
         NET_HIP(n, hipMemcpyAsync(dst, slot, len, hipMemcpyHostToDevice, n->ctx->stream));
         n->reads_in_flight = true;
@@ -430,7 +497,7 @@ int exchange(czk_net* n, Op op, const void* send, size_t bytes, void* recv, int 
     if (bytes && ((sb && !send) || (rb && !recv))) return net_err(n, CZK_ERR_ARG, "czk_net: null buffer");
     if (mem == CZK_MEM_DEVICE && !n->ctx) return net_err(n, CZK_ERR_ARG, "czk_net: device buffers need a communicator created with a context");
     if (n->ctx) NET_HIP(n, hipSetDevice(n->ctx->device));
-    if (n->transport == CZK_NET_SHM) {
+    if (n->shm_like()) {
         const int rc = shm_exchange(n, op, (const char*)send, bytes, (char*)recv, mem);
         if (rc != CZK_OK) n->hdr->abort.store(1, std::memory_order_release);   // the peers leave their barrier at once instead of after timeout_ms
         return rc;
@@ -487,7 +554,7 @@ extern "C" int czk_net_unique_id(int transport, uint8_t* out, size_t cap, size_t
         *len = NCCL_UNIQUE_ID_BYTES;
         return CZK_OK;
     }
-    if (transport == CZK_NET_SHM) {
+    if (transport == CZK_NET_SHM || transport == CZK_NET_IPC) {
         if (cap < 16) return CZK_ERR_ARG;
         if (getrandom(out, 16, 0) != 16) return CZK_ERR_NET;
         *len = 16;
@@ -507,6 +574,9 @@ extern "C" void czk_net_destroy(czk_net* n) {
         if (n->data_pinned) (void)hipHostUnregister(n->slots);
         munmap(n->slots, n->data_bytes);
     }
+    for (size_t r = 0; r < n->peer_mail.size(); r++)
+        if ((int)r != n->rank && n->peer_mail[r]) (void)hipIpcCloseMemHandle(n->peer_mail[r]);
+    if (n->mailbox) (void)hipFree(n->mailbox);   // (a peer that still has it mapped keeps the memory alive until it closes its handle)
     if (n->hdr) munmap(n->hdr, sizeof(ShmHeader));
     for (DeviceBuf* b : {&n->gather, &n->dx, &n->small})
         if (b->p) (void)hipFree(b->p);
@@ -533,8 +603,9 @@ extern "C" int czk_net_create(czk_ctx* ctx, int transport, int rank, int world, 
             NET_NCCL(n, R->CommInitRank(&n->comm, world, uid, rank));
             return CZK_OK;
         }();
-    } else if (transport == CZK_NET_SHM) {
+    } else if (transport == CZK_NET_SHM || transport == CZK_NET_IPC) {
         rc = [&]() -> int {
+            if (transport == CZK_NET_IPC && !ctx) return net_err(n, CZK_ERR_ARG, "czk_net_create: the IPC transport needs a context");
             if (id_len > 32) return net_err(n, CZK_ERR_ARG, "czk_net_create: an SHM id is 1..32 bytes");
             n->shm_name = shm_name_of(id, id_len, "");
             void* p = nullptr;
@@ -578,7 +649,7 @@ extern "C" int czk_net_set_option(czk_net* n, const char* name, long value) {
     const std::string k = name;
     if (k == "exchange" && (value == 0 || value == 1)) n->exchange = value;
     else if (k == "timeout_ms" && value > 0) n->timeout_ms = value;
-    else if (k == "slot_bytes" && value >= 64 && !n->slots) n->slot_bytes = ((size_t)value + 63) & ~(size_t)63;
+    else if (k == "slot_bytes" && value >= 64 && !n->slots && n->peer_mail.empty()) n->slot_bytes = ((size_t)value + 63) & ~(size_t)63;
     else return net_err(n, CZK_ERR_ARG, "czk_net_set_option: unknown name, value out of range, or slot_bytes after the first exchange");
     return CZK_OK;
 }
@@ -609,7 +680,7 @@ extern "C" int czk_net_recv_from_king(czk_net* n, const void* send, size_t bytes
 }
 extern "C" int czk_net_barrier(czk_net* n) {
     if (!n) return CZK_ERR_ARG;
-    if (n->transport == CZK_NET_SHM) {
+    if (n->shm_like()) {
         if (n->ctx) {
             NET_HIP(n, hipSetDevice(n->ctx->device));
             NET_HIP(n, hipStreamSynchronize(n->ctx->stream));

@@ -78,12 +78,13 @@ def get_net():
 
 def make_net(ctx, transport: str | None = None, device=None):
     """A czk_net over the ranks of torch's default process group (which only carries the communicator id here): transport "rccl" (one GPU
-    per rank; default when the group's backend is nccl) or "shm" (ranks of one node in any assignment to GPUs)."""
+    per rank; default when the group's backend is nccl), "shm" (ranks of one node in any assignment to GPUs, staged through shared host memory) or "ipc" (the
+    same with device mailboxes mapped between the processes: nothing leaves device memory)."""
     from . import binding
     world, rank = _world_rank()
     if transport is None:
         transport = "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") else "shm"
-    t = binding.CZK_NET_RCCL if transport == "rccl" else binding.CZK_NET_SHM
+    t = {"rccl": binding.CZK_NET_RCCL, "shm": binding.CZK_NET_SHM, "ipc": binding.CZK_NET_IPC}[transport]
     box = [binding.Net.unique_id(t) if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(box, src=0, **({"device": device} if device is not None else {}))

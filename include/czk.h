@@ -248,6 +248,10 @@ int czk_fr_gsz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t
  *                 the launcher chooses, the same on every rank and FRESH for every communicator (czk_net_unique_id(CZK_NET_SHM) draws 16 random
  *                 bytes: a rank that finds the segment of an earlier run under its id would wait there until the timeout).  ctx may be NULL:
  *                 host-memory primitives only (no composite opens).  A failure on one rank aborts the communicator for all of them.
+ *   CZK_NET_IPC   like CZK_NET_SHM (same id rule, same control block and barrier in shared memory), but the staging slots are DEVICE memory:
+ *                 every rank owns a mailbox on its GPU and maps the others' with hipIpc, so an exchange is device-to-device copies (on one GPU: inside
+ *                 HBM; across GPUs of a node: peer copies) and only the barrier touches the host.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment
+ *                 of this driver stack; a context is required.
  * czk_net_create is collective (returns once every rank has joined; CZK_ERR_NET after the timeout).  All ranks call the same
  * sequence of exchanges, like the reference's lock-step rounds.  Buffers: `mem` = CZK_MEM_DEVICE (on the context's GPU, used in
  * stream order) or CZK_MEM_HOST (read / written before the call returns).  Byte counts must be equal on all ranks (mpc-net asserts it).
@@ -255,7 +259,7 @@ int czk_fr_gsz_open(czk_ctx* ctx, const uint64_t* shares, size_t parties, size_t
  * pair of GPUs of an MI355X node has its own xGMI link -- mpc-net's own star shape); "timeout_ms" (default 120000);
  * "slot_bytes" (SHM: staging slot per rank, default 16 MiB; before the first exchange). */
 typedef struct czk_net czk_net;
-typedef enum { CZK_NET_RCCL = 1, CZK_NET_SHM = 2 } czk_net_transport;
+typedef enum { CZK_NET_RCCL = 1, CZK_NET_SHM = 2, CZK_NET_IPC = 3 } czk_net_transport;
 #define CZK_NET_UNIQUE_ID_BYTES 128
 int czk_net_unique_id(int transport, uint8_t* out, size_t cap, size_t* len);
 int czk_net_create(czk_ctx* ctx, int transport, int rank, int world, const uint8_t* id, size_t id_len, czk_net** out);

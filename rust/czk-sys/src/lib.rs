@@ -51,6 +51,7 @@ pub const CZK_OP_SUB: c_int = 1; // czk_binop
 pub const CZK_OP_MUL: c_int = 2; // czk_binop
 pub const CZK_NET_RCCL: c_int = 1; // czk_net_transport
 pub const CZK_NET_SHM: c_int = 2; // czk_net_transport
+pub const CZK_NET_IPC: c_int = 3; // czk_net_transport
 pub const CZK_NET_UNIQUE_ID_BYTES: c_int = 128; // #define
 pub const CZK_OPEN_COMMIT: c_int = 1; // #define
 

@@ -693,7 +693,7 @@ def test_party_per_rank_layout_matches_single_gpu_layout(parties, size):
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
 
 
-@pytest.mark.parametrize("scheme,parties,net", [("gsz", 3, "torch"), ("gsz", 4, "czk"), ("hbc", 3, "czk")])
+@pytest.mark.parametrize("scheme,parties,net", [("gsz", 3, "torch"), ("gsz", 4, "czk"), ("hbc", 3, "czk-ipc")])
 def test_party_layout_under_the_other_sharings(scheme, parties, net):
     """bench.py --layout party for the reference's other sharings: HBC (AdditiveFieldShare::batch_open between the ranks) and GSZ (one Shamir lane per
     rank; the product's degree reduction is gsz20::batch_king_compute -- every rank's lane to the king, open at degree 2t, the value back to everyone),
@@ -715,7 +715,7 @@ def test_party_layout_under_the_other_sharings(scheme, parties, net):
     assert many.returncode == 0, __import__('util').child_errors(many.stderr)
     d1 = json.loads(one.stdout.strip().splitlines()[-1])
     d2 = json.loads(many.stdout.strip().splitlines()[-1])
-    assert d2["n_gpus"] == parties and d2["config"]["layout"] == "party" and d2["net"] == ("czk_net shm" if net == "czk" else "torch.distributed")
+    assert d2["n_gpus"] == parties and d2["config"]["layout"] == "party" and d2["net"] == {"czk": "czk_net shm", "czk-ipc": "czk_net ipc", "torch": "torch.distributed"}[net]
     assert d1["results_checked"] and d2["results_checked"]
     assert d1["config"]["results_sha256"] == d2["config"]["results_sha256"]
 

@@ -19,16 +19,28 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _spawn(target, world, *args, timeout=280):
     import multiprocessing as mp
+    import queue
+    import time
     c = mp.get_context("spawn")
     q = c.Queue()
     procs = [c.Process(target=target, args=(r, world, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=timeout) for _ in range(world))
+    res, t0 = [], time.time()
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=1.0))
+        except queue.Empty:
+            dead = [(i, p.exitcode) for i, p in enumerate(procs) if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > timeout:            # a rank that died never reports: do not wait out the timeout for it
+                for p in procs:
+                    if p.is_alive():
+                        p.kill()                                # exactly the processes this call started
+                raise AssertionError(f"ranks died (rank, exit code): {dead}" if dead else f"ranks did not report within {timeout} s")
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    return res
+    return sorted(res)
 
 
 def test_sha256_matches_hashlib():
@@ -159,7 +171,7 @@ def _open_worker(rank, world, q, idb, transport, share_device, n, slot_bytes):
     dev = 0 if share_device else rank
     torch.cuda.set_device(dev)
     ctx = czk_amd.Context(dev)
-    net = czk_amd.Net(ctx, transport, rank, world, idb, options={"slot_bytes": slot_bytes} if transport == czk_amd.CZK_NET_SHM else None)
+    net = czk_amd.Net(ctx, transport, rank, world, idb, options={"slot_bytes": slot_bytes} if transport != czk_amd.CZK_NET_RCCL else None)
     secret, alpha, shs, macs = _spdz_inputs(orc, world, n)
     sh = torch.from_numpy(shs[rank].view(np.int64)).cuda()
     mac = torch.from_numpy(macs[rank].view(np.int64)).cuda()
@@ -239,6 +251,16 @@ def test_batch_opens_processes_sharing_one_gpu(world, n, slot_bytes):
     in three chunk steps), against the checker's field arithmetic"""
     import czk_amd
     res = _spawn(_open_worker, world, os.urandom(16), czk_amd.CZK_NET_SHM, True, n, slot_bytes)
+    assert res == [(r, True, []) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,slot_bytes", [(2, 3000, 16 << 20), (3, 70001, 1 << 20)])
+def test_batch_opens_over_device_mailboxes(world, n, slot_bytes):
+    """the same opens through the IPC transport: the staging slots are device memory (one mailbox per rank, mapped into the peers with hipIpc),
+    so with the parties on one GPU nothing of an exchange leaves HBM"""
+    import czk_amd
+    res = _spawn(_open_worker, world, os.urandom(16), czk_amd.CZK_NET_IPC, True, n, slot_bytes)
     assert res == [(r, True, []) for r in range(world)]
 
 
@@ -343,7 +365,8 @@ def _json_tail(proc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size,extra", [(2, ["--log-n", "12"], []), (3, ["--log-n", "10"], ["--commit-opens"]), (2, ["--constraints", "1000"], ["--no-tables", "--exchange", "p2p"])])
+@pytest.mark.parametrize("world,size,extra", [(2, ["--log-n", "12"], []), (3, ["--log-n", "10"], ["--commit-opens"]), (2, ["--constraints", "1000"], ["--no-tables", "--exchange", "p2p"]),
+                                              (3, ["--log-n", "11"], ["--transport", "ipc"])])
 def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, extra):
     """One process per MPC party, each a C++ host over include/czk.hpp whose opens run through czk::Net (SHM transport: the processes
     share this box's GPU): the proof's group elements (digest over all parties' affine results, bench.py's order) must equal
@@ -355,6 +378,7 @@ def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, e
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
     tables = [] if "--no-tables" not in extra else ["--no-tables"]
+
     cpp_party = _json_tail(__import__("util").run_ranks([exe, "party-launch", "--world", str(world), "--steps", "2", "--warmup", "1"] + size + extra,
                                           capture_output=True, text=True, timeout=600, env=env))
     assert cpp_party["layout"] == "party" and cpp_party["parties"] == world and cpp_party["share_lanes_per_process"] == 2

@@ -52,6 +52,9 @@ static int dump_lift(const Context& ctx) {
     return 0;
 }
 
+// --transport rccl | shm | ipc (include/czk.h czk_net_transport)
+static int transport_of(const char* s) { return !strcmp(s, "rccl") ? CZK_NET_RCCL : !strcmp(s, "ipc") ? CZK_NET_IPC : CZK_NET_SHM; }
+static const char* transport_name(int t) { return t == CZK_NET_RCCL ? "rccl" : t == CZK_NET_IPC ? "ipc" : "shm"; }
 static std::string hex(const uint8_t* p, size_t n) {
     static const char* d = "0123456789abcdef";
     std::string s;
@@ -209,7 +212,7 @@ static int party(int argc, char** argv) {
         else if (!strcmp(argv[i], "--world")) world = atoi(val());
         else if (!strcmp(argv[i], "--device")) device = atoi(val());
         else if (!strcmp(argv[i], "--id")) id = unhex(val());
-        else if (!strcmp(argv[i], "--transport")) transport = !strcmp(val(), "rccl") ? CZK_NET_RCCL : CZK_NET_SHM;
+        else if (!strcmp(argv[i], "--transport")) transport = transport_of(val());
         else if (!strcmp(argv[i], "--exchange")) exchange = !strcmp(val(), "p2p") ? 1 : 0;
         else if (!strcmp(argv[i], "--no-tables")) no_tables = true;
         else if (!strcmp(argv[i], "--commit-opens")) commit = true;
@@ -254,7 +257,7 @@ static int party(int argc, char** argv) {
            "\"warmup\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, \"window_tables\": %s, \"commit_opens\": %s, \"pipelined_proofs_equal\": true, "
            "\"king_net_stats\": {\"bytes_sent\": %llu, \"bytes_recv\": %llu, \"broadcasts\": %llu, \"to_king\": %llu, \"from_king\": %llu}, "
            "\"results_sha256\": \"%s\"}\n",
-           transport == CZK_NET_RCCL ? "rccl" : "shm", exchange ? "p2p" : "ring", prover.N, world, L, steps, warmup, dt / steps * 1e3, steps / dt,
+           transport_name(transport), exchange ? "p2p" : "ring", prover.N, world, L, steps, warmup, dt / steps * 1e3, steps / dt,
            no_tables ? "false" : "true", commit ? "true" : "false", (unsigned long long)st.bytes_sent, (unsigned long long)st.bytes_recv,
            (unsigned long long)st.broadcasts, (unsigned long long)st.to_king, (unsigned long long)st.from_king, hex(digest, 32).c_str());
     return 0;
@@ -264,7 +267,7 @@ static int party_launch(int argc, char** argv) {
     int world = 0, transport = CZK_NET_SHM;
     for (int i = 2; i + 1 < argc; i++) {
         if (!strcmp(argv[i], "--world")) world = atoi(argv[i + 1]);
-        if (!strcmp(argv[i], "--transport") && !strcmp(argv[i + 1], "rccl")) transport = CZK_NET_RCCL;
+        if (!strcmp(argv[i], "--transport")) transport = transport_of(argv[i + 1]);
     }
     if (world < 2) { printf("party-launch: need --world >= 2\n"); return 2; }
     const std::string id = [&] {
@@ -331,7 +334,7 @@ static int polyiop(const char* workload, int argc, char** argv) {
         else if (!strcmp(argv[i], "--world")) world = atoi(val());
         else if (!strcmp(argv[i], "--id")) id = unhex(val());
         else if (!strcmp(argv[i], "--device")) device = atoi(val());
-        else if (!strcmp(argv[i], "--transport")) transport = !strcmp(val(), "rccl") ? CZK_NET_RCCL : CZK_NET_SHM;
+        else if (!strcmp(argv[i], "--transport")) transport = transport_of(val());
         else if (!strcmp(argv[i], "--constraints")) n = (size_t)atoll(val());
         else if (!strcmp(argv[i], "--parties")) parties = (size_t)atoi(val());
         else if (!strcmp(argv[i], "--steps")) steps = (size_t)atoi(val());
@@ -470,10 +473,11 @@ static int polyiop(const char* workload, int argc, char** argv) {
     size_t msms = 0, ntts = 0;
     for (auto& p : provers) msms += p.B->msm_count, ntts += p.B->ntt_count;
     printf("{\"harness\": \"tools/host_demo.cpp %s (C++ over include/czk.h: tools/polyvm_host.hpp; no torch, no Python)\", \"workload\": \"%s\", \"constraints\": %zu, "
-           "\"parties\": %zu, \"layout\": \"%s\", \"share_lanes\": %zu, \"steps\": %zu, \"warmup\": %zu, \"proofs_in_flight\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, "
+           "\"parties\": %zu, \"layout\": \"%s\", \"transport\": \"%s\", \"share_lanes\": %zu, \"steps\": %zu, \"warmup\": %zu, \"proofs_in_flight\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, "
            "\"latency_ms_single_proof\": %.3f, \"first_proof_ms\": %.3f, \"setup_s\": %.3f, \"msms_per_proof\": %.1f, \"ntt_lanes_per_proof\": %.1f, "
            "\"arena_peak_gb\": %.2f, \"in_flight_provers_equal\": true, \"output_sha256\": \"%s\"}\n",
-           workload, workload, n, parties, party ? "party (one process per party, evaluations opened through czk_net)" : "one process", lanes, steps, warmup,
+           workload, workload, n, parties, party ? "party (one process per party, evaluations opened through czk_net)" : "one process",
+           party ? transport_name(transport) : "none", lanes, steps, warmup,
            inflight, dt / steps * 1e3, steps / dt, alone_ms, first_ms, setup_s, (double)msms / steps,
            (double)ntts / steps, provers[0].B->arena_peak_bytes() / 1e9, hex(digest, 32).c_str());
     if (net) {
