@@ -706,6 +706,10 @@ pub mod net {
         pub fn init_shm(party_id: usize, n_parties: usize, id: &[u8]) -> Net {
             Net::create(sys::CZK_NET_SHM, party_id, n_parties, id)
         }
+        /// the same with device mailboxes mapped between the processes (hipIpc): an exchange never leaves device memory
+        pub fn init_ipc(party_id: usize, n_parties: usize, id: &[u8]) -> Net {
+            Net::create(sys::CZK_NET_IPC, party_id, n_parties, id)
+        }
         fn create(transport: c_int, party_id: usize, n_parties: usize, id: &[u8]) -> Net {
             let ctx = CTX.lock().unwrap();
             let mut raw: *mut sys::czk_net = std::ptr::null_mut();
