@@ -89,7 +89,7 @@ def _shm_host_worker(rank, world, q, idb, slot_bytes):
     q.put((rank, bool(ok)))
 
 
-@pytest.mark.parametrize("world,slot_bytes", [(2, 64), (3, 4096), (4, 1 << 20)])
+@pytest.mark.parametrize("world,slot_bytes", [(2, 64), (3, 4096), (4, 1 << 20), (8, 1 << 16)])
 def test_shm_transport_host_buffers(world, slot_bytes):
     """mpc-net's three primitives between `world` processes through the shared-memory transport, no GPU involved"""
     res = _spawn(_shm_host_worker, world, os.urandom(16), slot_bytes)
@@ -401,3 +401,23 @@ def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, e
     all_digests = (cpp_party["results_sha256"], cpp_one["results_sha256"], py_one["config"]["results_sha256"], py_party["config"]["results_sha256"],
                    py_party_czk["config"]["results_sha256"])
     assert len(set(all_digests)) == 1, all_digests
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["ipc", "shm"])
+def test_cpp_party_layout_with_eight_parties(transport):
+    """BASELINE configs[4]'s party count (8 parties, mpc-net/src/multi.rs:15-23 with eight hosts): eight C++ party processes sharing this
+    box's GPU, opens through czk::Net, against the same host with all sixteen share lanes in one process -- one digest."""
+    import subprocess
+    from test_abi import _build_host_demo
+    exe = _build_host_demo()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    size = ["--log-n", "10", "--steps", "2", "--warmup", "1"]
+    party = _json_tail(__import__("util").run_ranks([exe, "party-launch", "--world", "8", "--transport", transport] + size,
+                                                    capture_output=True, text=True, timeout=600, env=env))
+    assert party["parties"] == 8 and party["share_lanes_per_process"] == 2 and party["transport"] == transport
+    assert party["king_net_stats"]["broadcasts"] == 2 * 2 * 2
+    one = _json_tail(subprocess.run([exe, "bench", "--parties", "8"] + size, capture_output=True, text=True, timeout=600, env=env))
+    assert one["share_lanes"] == 16 and one["mac_check_failures"] == 0
+    assert party["results_sha256"] == one["results_sha256"]
