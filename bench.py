@@ -221,12 +221,14 @@ def multi_gpu_plan(n: int) -> list:
     # ring before p2p; then the one-GPU reference runs that the digests are compared with (a party digest that equals the other party digests of
     # its config is already strong evidence); then the split layout.
     plan = []
+
+    def party(key, argv, net, exch):
+        return (f"{key}/party/{net}/{exch}", ["--gpus", str(n), "--layout", "party", "--exchange", exch, "--net", net] + argv, key + "/one_gpu")
     for net, exch in (("czk", "ring"), ("torch", "ring"), ("czk", "p2p"), ("torch", "p2p")):
-        for key, argv in cfgs:
-            if key.endswith("_no_tables") and exch == "p2p":
-                continue
-            plan.append((f"{key}/party/{net}/{exch}", ["--gpus", str(n), "--layout", "party", "--exchange", exch, "--net", net] + argv, key + "/one_gpu"))
+        plan += [party(key, argv, net, exch) for key, argv in cfgs if not key.endswith("_no_tables")]
     plan.append(("groth16_spdz2_2e20/split", ["--gpus", str(n), "--layout", "split", "--parties", "2"] + g16_20, "headline"))
+    for net in ("czk", "torch"):   # with vs without window tables: after the transport / pattern questions
+        plan += [party(key, argv, net, "ring") for key, argv in cfgs if key.endswith("_no_tables")]
     for key, argv in cfgs:
         one_gpu = argv + (["--no-tables"] if "--log-n" in argv and argv[argv.index("--log-n") + 1] == "22" and "--no-tables" not in argv else [])
         plan.append((key + "/one_gpu", ["--gpus", "1", "--inflight", "1"] + one_gpu, None))   # all parties' lanes on ONE GPU: the digest every party layout must reproduce
