@@ -227,6 +227,8 @@ def multi_gpu_plan(n: int) -> list:
     for net, exch in (("czk", "ring"), ("torch", "ring"), ("czk", "p2p"), ("torch", "p2p")):
         plan += [party(key, argv, net, exch) for key, argv in cfgs if not key.endswith("_no_tables")]
     plan.append(("groth16_spdz2_2e20/split", ["--gpus", str(n), "--layout", "split", "--parties", "2"] + g16_20, "headline"))
+    # the library's third transport between GPUs: device mailboxes mapped into the peers with hipIpc (peer access over xGMI), no RCCL involved
+    plan += [party(key, argv, "czk-ipc", "ring") for key, argv in cfgs if not key.endswith("_no_tables")]
     for net in ("czk", "torch"):   # with vs without window tables: after the transport / pattern questions
         plan += [party(key, argv, net, "ring") for key, argv in cfgs if key.endswith("_no_tables")]
     for key, argv in cfgs:

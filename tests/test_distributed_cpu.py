@@ -108,7 +108,7 @@ def test_multi_gpu_report_shape(gpus):
     assert d["n_gpus"] == gpus and d["ranks_seen_by_backend"] == gpus
     baseline_cfg = {2: "marlin_spdz2_2e20", 3: "plonk_gsz3_2e18"}[gpus]
     party = {k: v for k, v in rep.items() if "/party/" in k}
-    assert {k.split("/", 2)[2] for k in party if k.startswith(baseline_cfg)} == {"torch/ring", "torch/p2p", "czk/ring", "czk/p2p"}
+    assert {k.split("/", 2)[2] for k in party if k.startswith(baseline_cfg)} == {"torch/ring", "torch/p2p", "czk/ring", "czk/p2p", "czk-ipc/ring"}
     for k, v in party.items():
         assert v["reference"] == k.split("/")[0] + "/one_gpu" and v["reference"] in rep, k
         assert f"--gpus {gpus} --layout party" in v["command"] and f"--parties {gpus}" in v["command"]
