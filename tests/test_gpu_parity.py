@@ -984,23 +984,16 @@ def test_many_share_lanes(ctx, czk, orc):
             b.release()
 
 
-@pytest.mark.parametrize("case", range(14))
-def test_msm_randomised_shapes_both_table_forms(ctx, czk, orc, case):
-    """Seeded fuzz over the shapes the fixed cases do not hit: sizes around the window-width switches (16 383 / 16 384 points,
-    where narrow top windows stop being allowed), odd lane counts, random infinity patterns, scalar mixes with many zeros, ones,
-    small values, r - small values and repeated bases -- table form and CZK_MEM_NO_TABLES against the checker's Pippenger."""
-    rng = np.random.default_rng(0x5EED + case)
-    g = 1 if case % 4 else 2
-    n = int([1, 2, 3, 17, 255, 1023, 1025, 4097, 16383, 16384, 16385, 40000, 65537, 9][case])
-    if g == 2:
-        n = min(n, 1500)
+def _msm_random_case(ctx, czk, orc, rng, g, n, seed, tag):
+    """One randomised MSM comparison: odd lane counts, random infinity patterns, repeated bases, scalar mixes with many zeros, ones, small
+    values and r - small values; table form and CZK_MEM_NO_TABLES against the checker's Pippenger."""
     lanes = int(rng.integers(1, 6))
-    _, bases = _bases(ctx, g, n, 12000 + case)
+    _, bases = _bases(ctx, g, n, seed)
     if n > 8:                                               # repeated and opposite bases
         idx = rng.integers(0, n, size=max(2, n // 50))
         bases[idx[1:]] = bases[idx[0]]
     inf = (rng.random(n) < 0.1).astype(np.uint8)
-    sc = rand_fr_canonical(13000 + case, lanes * n).reshape(lanes, n, 4)
+    sc = rand_fr_canonical(seed + 1000, lanes * n).reshape(lanes, n, 4)
     kind = rng.integers(0, 6, size=(lanes, n))
     small = ints_to_limbs([int(v) for v in rng.integers(0, 1 << 20, size=64)], 4)
     for ln in range(lanes):
@@ -1015,30 +1008,41 @@ def test_msm_randomised_shapes_both_table_forms(ctx, czk, orc, case):
         b = ctx.register_bases(g, bases, inf, mem=czk.CZK_MEM_HOST | flag)
         got = ctx.msm(b, sc, lanes=lanes)
         for ln in range(lanes):
-            assert _same_point(ctx, orc, g, got[ln], want[ln]), (case, g, n, lanes, ln, flag)
+            assert _same_point(ctx, orc, g, got[ln], want[ln]), (tag, g, n, lanes, ln, flag)
         b.release()
 
 
-@pytest.mark.parametrize("case", range(16))
-def test_ntt_randomised_shapes(ctx, czk, orc, case):
-    """Seeded fuzz: domain sizes 2^0 .. 2^18 and 3 * 2^k, any prefix length (0 .. D) with a garbage tail, 1 .. 5 lanes, all four
-    kinds, host and device memory -- every limb against the checker."""
+@pytest.mark.parametrize("case", range(14))
+def test_msm_randomised_shapes_both_table_forms(ctx, czk, orc, case):
+    """Seeded fuzz over the shapes the fixed cases do not hit: sizes around the window-width switches (16 383 / 16 384 points,
+    where narrow top windows stop being allowed), odd lane counts, random infinity patterns, scalar mixes with many zeros, ones,
+    small values, r - small values and repeated bases -- table form and CZK_MEM_NO_TABLES against the checker's Pippenger."""
+    rng = np.random.default_rng(0x5EED + case)
+    g = 1 if case % 4 else 2
+    n = int([1, 2, 3, 17, 255, 1023, 1025, 4097, 16383, 16384, 16385, 40000, 65537, 9][case])
+    if g == 2:
+        n = min(n, 1500)
+    _msm_random_case(ctx, czk, orc, rng, g, n, 12000 + case, case)
+
+
+def _ntt_random_case(ctx, czk, orc, rng, mixed, device, seed, tag, max_log=18):
+    """One randomised NTT comparison: any prefix length (0 .. D) with a garbage tail, 1 .. 5 lanes, all four kinds -- every limb
+    against the checker."""
     import torch
-    rng = np.random.default_rng(0xF17 + case)
-    mixed = case % 4 == 3
     if mixed:
-        k = int(rng.integers(0, 15))
+        k = int(rng.integers(0, max_log - 3))
         size = 3 << k
+        log_d = None
     else:
-        log_d = int(rng.integers(0, 19))
+        log_d = int(rng.integers(0, max_log + 1))
         size = 1 << log_d
     lanes = int(rng.integers(1, 6))
     in_len = int(rng.integers(0, size + 1))
-    x = orc.fr_from_repr(rand_fr_canonical(15000 + case, lanes * max(in_len, 1))).reshape(lanes, max(in_len, 1), 4)[:, :in_len]
+    x = orc.fr_from_repr(rand_fr_canonical(seed, lanes * max(in_len, 1))).reshape(lanes, max(in_len, 1), 4)[:, :in_len]
     for kind in (czk.CZK_FFT, czk.CZK_IFFT, czk.CZK_COSET_FFT, czk.CZK_COSET_IFFT):
         buf = np.full((lanes, size, 4), 0xDEADBEEFDEADBEEF, dtype=np.uint64)
         buf[:, :in_len] = x
-        if case % 2:
+        if device:
             t = torch.from_numpy(buf.view(np.int64)).cuda()
             torch.cuda.synchronize()
             if mixed:
@@ -1055,7 +1059,66 @@ def test_ntt_randomised_shapes(ctx, czk, orc, case):
             got = buf
         for ln in range(lanes):
             want = orc.ntt_fr_mixed(x[ln], size, kind, in_len) if mixed else orc.ntt_fr(x[ln], log_d, kind, in_len)
-            assert np.array_equal(got[ln], want), (case, size, in_len, lanes, kind, ln)
+            assert np.array_equal(got[ln], want), (tag, size, in_len, lanes, kind, ln)
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_ntt_randomised_shapes(ctx, czk, orc, case):
+    """Seeded fuzz: domain sizes 2^0 .. 2^18 and 3 * 2^k, any prefix length (0 .. D) with a garbage tail, 1 .. 5 lanes, all four
+    kinds, host and device memory -- every limb against the checker."""
+    rng = np.random.default_rng(0xF17 + case)
+    _ntt_random_case(ctx, czk, orc, rng, case % 4 == 3, bool(case % 2), 15000 + case, case)
+
+
+def _poly_random_case(ctx, czk, orc, rng, seed, tag):
+    """One randomised comparison of the polynomial / scan entry points (division by X - z, evaluation, running products, batch inversion with
+    zeros sprinkled in, the constraint mat-vec) at a size nobody picked."""
+    n = int(2 ** rng.uniform(0, 17.5)) - 1
+    lanes = int(rng.integers(1, 4))
+    p = orc.fr_from_repr(rand_fr_canonical(seed, lanes * max(n, 1)))[: lanes * n].reshape(lanes, n, 4)
+    z = orc.fr_from_repr(rand_fr_canonical(seed + 1, 1))[0]
+    q, r = ctx.poly_div_linear(p, z, lanes=lanes)
+    v = ctx.poly_evaluate(p, z, lanes=lanes)
+    for ln in range(lanes):
+        qw, rw = orc.poly_div_linear(p[ln], z)
+        assert np.array_equal(q[ln], qw) and np.array_equal(r[ln], rw), (tag, n, ln)
+        assert np.array_equal(v[ln], orc.fr_horner(p[ln], z) if n else np.zeros(4, dtype=np.uint64)), (tag, n, ln)
+    x = p[0].copy()
+    assert np.array_equal(ctx.fr_prefix_product(x), orc.fr_prefix_product(x)), (tag, n)
+    if n:
+        x[rng.random(n) < 0.02] = 0
+    assert np.array_equal(ctx.fr_batch_inverse(x, z), orc.fr_batch_inverse(x, z)), (tag, n)
+    m, n_vars = int(2 ** rng.uniform(0, 14)), int(2 ** rng.uniform(0, 13))
+    row_ptr, col, coeff = _random_csr_limbs(orc, seed + 2, m, n_vars)
+    zz = orc.fr_from_repr(rand_fr_canonical(seed + 3, lanes * n_vars)).reshape(lanes, n_vars, 4)
+    mat = ctx.r1cs_matrix_register(row_ptr, col, coeff, n_vars)
+    got = ctx.r1cs_matvec(mat, zz, lanes=lanes)
+    for ln in range(lanes):
+        assert np.array_equal(got[ln], orc.r1cs_matvec(row_ptr, col, coeff, zz[ln])), (tag, m, n_vars, ln)
+    mat.release()
+
+
+def test_soak_with_a_fresh_seed(ctx, czk, orc):
+    """The fuzzers above on a seed nobody has seen (printed, and named in any failure: CZK_SOAK_SEED reproduces it).  A few cases per
+    session by default; CZK_SOAK_SECONDS=600 turns it into a soak run (tools/soak.sh keeps the log under profiles/)."""
+    import os
+    import time
+    seed = int(os.environ.get("CZK_SOAK_SEED", "0"), 0) or int.from_bytes(os.urandom(4), "little")
+    budget = float(os.environ.get("CZK_SOAK_SECONDS", "0"))
+    rng = np.random.default_rng(seed)
+    t0, cases = time.time(), 0
+    print(f"soak seed {seed:#x}")
+    while True:
+        tag = (hex(seed), cases)
+        g = 2 if rng.random() < 0.25 else 1
+        n = int(2 ** rng.uniform(0, 11 if g == 2 else 16.5))
+        _msm_random_case(ctx, czk, orc, rng, g, n, int(rng.integers(1, 1 << 40)), tag)
+        _ntt_random_case(ctx, czk, orc, rng, rng.random() < 0.25, rng.random() < 0.5, int(rng.integers(1, 1 << 40)), tag, max_log=17)
+        _poly_random_case(ctx, czk, orc, rng, int(rng.integers(1, 1 << 40)), tag)
+        cases += 1
+        if time.time() - t0 >= budget and cases >= 3:
+            break
+    print(f"soak seed {seed:#x}: {cases} MSM + {cases} NTT + {cases} polynomial / mat-vec cases in {time.time() - t0:.0f} s, no mismatch")
 
 
 def test_msm_without_window_tables_empty_and_all_zero(ctx, czk, orc):
