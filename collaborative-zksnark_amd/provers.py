@@ -75,12 +75,16 @@ class Groth16Local:
     circuit (squaring chain, mpc-snarks/src/proof.rs:304-344), SPDZ shares of `parties` parties."""
 
     def __init__(self, czk, ctx, n_constraints: int, parties: int, seed: int = 0xC0FFEE, local_parties=None, exchange=None, no_tables: bool = False,
-                 mac_msm_from_sh: bool = False, scheme: str = "spdz", base_split=None):
+                 mac_msm_from_sh: bool = False, scheme: str = "spdz", base_split=None, key_scalars=None):
         """local_parties: the MPC parties whose share lanes live on this GPU (default: all of them -- BASELINE
         configs[1]); with one party per rank the two opens of the witness map run the reference's two broadcast rounds
         over torch.distributed (parallel.spdz_batch_open).  `exchange` is kept for callers that pass it; unused.  no_tables:
-        register the proving key with CZK_MEM_NO_TABLES (what a prover that runs once should do)."""
+        register the proving key with CZK_MEM_NO_TABLES (what a prover that runs once should do).  key_scalars: discrete logs of a proving key to use
+        in place of the synthetic one -- {"h": (D - 1, 4), "l": (N, 4), "a" / "b_g1" / "b_g2": (N + 1, 4) [the queries from index 1 on], "pk_g1": (4, 4)
+        [alpha, beta, delta, a_query[0]], "pk_g2": (2, 4) [beta, delta]}, canonical uint64 limbs: how tests/test_verify.py hands over a key generated
+        from known toxic waste (groth16/src/generator.rs:60-230), so that the proof can be checked against the verification equation."""
         self.czk, self.ctx = czk, ctx
+        ks = key_scalars or {}
         # base_split = (k, K): the intra-party split for latency when GPUs outnumber parties (SURVEY.md section 8e: "MSM by base range -> one extra
         # point-add").  This rank registers and sums only bases [n k / K, n (k + 1) / K) of every query -- 1 / K of the window tables and of the
         # accumulation -- and runs the (cheap: 9 % of a proof) witness map in full, so no exchange is needed inside a proof; the K partial results of
@@ -121,7 +125,9 @@ class Groth16Local:
         # ---- synthetic proving key: P_i = [k_i] G ----------------------------------------------------------
         def mk_bases(group, n, sd, inf_first=False):
             lo, hi = self.base_range(n)
-            k = torch.from_numpy(rand_fr_canonical(BASE_SEED + sd, n)[lo:hi].copy().view(np.int64)).to(dev)   # the same bases in every layout
+            name = QUERIES[sd - 1][0]
+            kk = np.ascontiguousarray(ks[name], dtype=np.uint64).reshape(n, 4) if name in ks else rand_fr_canonical(BASE_SEED + sd, n)
+            k = torch.from_numpy(kk[lo:hi].copy().view(np.int64)).to(dev)   # the same bases in every layout
             n = hi - lo
             aw = 12 if group == czk.CZK_G1 else 24
             pts = torch.empty((n, aw), dtype=torch.int64, device=dev)
@@ -146,8 +152,8 @@ class Groth16Local:
         # the rest of the proving key (groth16/src/data_structures.rs:132-149): vk.alpha_g1, beta_g1, delta_g1, a_query[0] in G1 and
         # vk.beta_g2, vk.delta_g2 in G2, synthetic like the queries; b_g1_query[0] / b_g2_query[0] are infinity in the real key (the constant-one
         # variable has no B entry).  Host values: create_proof uses them in O(1) group steps.
-        g1x = ctx.fixed_base_points(czk.CZK_G1, rand_fr_canonical(BASE_SEED + 6, 4))
-        g2x = ctx.fixed_base_points(czk.CZK_G2, rand_fr_canonical(BASE_SEED + 7, 2))
+        g1x = ctx.fixed_base_points(czk.CZK_G1, np.ascontiguousarray(ks["pk_g1"], dtype=np.uint64).reshape(4, 4) if "pk_g1" in ks else rand_fr_canonical(BASE_SEED + 6, 4))
+        g2x = ctx.fixed_base_points(czk.CZK_G2, np.ascontiguousarray(ks["pk_g2"], dtype=np.uint64).reshape(2, 4) if "pk_g2" in ks else rand_fr_canonical(BASE_SEED + 7, 2))
         self.pk = {"alpha_g1": g1x[0], "beta_g1": g1x[1], "delta_g1": g1x[2], "a_query0": g1x[3], "beta_g2": g2x[0], "delta_g2": g2x[1]}
         self.setup_key_s = time.time() - t0
         # czk_ctx_reserve: NTT tables of the witness-map domain and the MSM workspaces for this key's call shapes, built here (like the window
