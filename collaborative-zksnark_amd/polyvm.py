@@ -136,7 +136,13 @@ class Backend:
         return self.upload(np.tile(mont(k), (n, 1)))
 
     def add_const(self, a, k: int):
+        """k added to every element: for arrays of EVALUATIONS (`&evals + &F`, element-wise)"""
         return self.plus(a, self.const(k, self.length(a)))
+
+    def poly_add_const(self, a, k: int):
+        """`&DensePolynomial + &F` (algebra/poly/src/polynomial/univariate/dense.rs:301-315): a polynomial in COEFFICIENT form takes a constant on
+        its coefficient 0 only."""
+        return self.plus(a, self.resized(self.const(k, 1), self.length(a)))
 
     def poly_mul(self, a, b):
         """`&DensePolynomial * &DensePolynomial` (algebra/poly/src/polynomial/univariate/dense.rs): both operands are
@@ -624,7 +630,7 @@ def plonk_prove(B: Backend, inp: dict) -> dict:
     # prove_gates (:295-340): d = s (p + pw) + (1 - s)(p pw) - pww, q = d / v_gates
     pw = B.shift(p, w)
     pww = B.shift(p, w * w % R_MOD)
-    one_minus_s = B.add_const(B.scale(s_pub, R_MOD - 1), 1)                    # public
+    one_minus_s = B.poly_add_const(B.scale(s_pub, R_MOD - 1), 1)               # public: `&(&circ.s * &-F::one()) + &F::one()` (:307-308)
     d = B.sub(_padded_add(B, B.poly_mul(s_pub, B.add(p, pw)), B.poly_mul(one_minus_s, B.poly_mul(p, pw))), B.resized(pww, G + 2 * W - 2))
     q_gates, _r = B.div_vanishing(d, G)
     commit("gates_q", q_gates)

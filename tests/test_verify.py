@@ -77,3 +77,76 @@ def test_groth16_proof_verifies_under_a_real_key(orc, n_constraints, parties, sc
 def test_groth16_full_size_proof_verifies(orc):
     """BASELINE configs[1] itself -- 2^20 constraints, SPDZ, two parties, four share lanes on one GPU -- under a real key: the proof verifies."""
     prove_and_verify(orc, 1 << 20, 2, "spdz")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Plonk: a SATISFIED circuit, the reference's verifier (mpc-plonk/src/lib.rs:451-590)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def satisfied_plonk_inputs(B, polyvm, n_gates: int, seed: int):
+    """A circuit layout (mpc-plonk/src/relations/flat.rs) that IS satisfied, unlike the benchmark's random polynomials: a chain of n_gates gates alternating
+    v -> v * v (s = 0) and v -> v + v (s = 1); gate i's wires sit at w^(3i), w^(3i+1), w^(3i+2) of the wire domain (left, right, out), so that
+    s (p + p(wX)) + (1 - s) p p(wX) - p(w^2 X) vanishes on the gate domain <w^3>; the copy constraints out_{i-1} = left_i = right_i are the cycles of the
+    wiring permutation, given as the polynomial w(X) with w(w^j) = w^sigma(j).  Returns (inputs for plonk_prove, the wire values, the generator w)."""
+    G, W = n_gates, 3 * n_gates
+    w = B.root_of_unity(W)
+    assert pow(w, W, R_MOD) == 1 and pow(w, 3 * (G // 2), R_MOD) != 1
+    v = limbs_to_ints(rand_fr_canonical(seed, 1))[0]
+    e, s_ev = [], []
+    for i in range(G):
+        out = v * v % R_MOD if i % 2 == 0 else 2 * v % R_MOD
+        e += [v, v, out]
+        s_ev.append(i % 2)
+        v = out
+    sigma = list(range(W))
+    sigma[0], sigma[1] = 1, 0
+    for i in range(1, G):
+        a, b, c = 3 * (i - 1) + 2, 3 * i, 3 * i + 1
+        sigma[a], sigma[b], sigma[c] = b, c, a
+    assert all(e[j] == e[sigma[j]] for j in range(W))
+    pub = lambda vals: B.upload(np.stack([polyvm.mont(x) for x in vals])[None])   # noqa: E731  (1, n, 4) public array
+    p_pub = B.ntt(pub(e), W, polyvm.IFFT)
+    inp = {"n_gates": G, "p": polyvm.shared_copy(B, p_pub), "s": B.ntt(pub(s_ev), G, polyvm.IFFT), "w": B.ntt(pub([pow(w, sg, R_MOD) for sg in sigma]), W, polyvm.IFFT)}
+    return inp, e, w
+
+
+@pytest.mark.parametrize("n_gates,parties", [(8, 3), (256, 3), (2048, 2)])
+def test_plonk_proof_of_a_satisfied_circuit_verifies(n_gates, parties):
+    """mpc-plonk's Prover::prove on the GPU path for a satisfied circuit, then the reference's Verifier::verify (lib.rs:511-590) on what it returns: every
+    KZG opening against its commitment (with the synthetic SRS's known tau: C - [v] G == [tau - x] W, bench.verify_openings) and the four identities on the
+    opened values -- public wire, gates, unit product (partial products and t(w^(k-1)) = 1), wiring."""
+    import czk_amd
+    from czk_amd import polyvm
+    import bench
+    ctx = polyvm.shared_stream_context(czk_amd)
+    B = polyvm.GpuBackend(czk_amd, ctx, parties, polyvm.plonk_max_degree(n_gates))
+    inp, e, w = satisfied_plonk_inputs(B, polyvm, n_gates, 0x51A7 + n_gates)
+    G, W = n_gates, 3 * n_gates
+    vk = {"s_cmt": B.commit(inp["s"]), "w_cmt": B.commit(inp["w"])}            # the index polynomials' commitments (the verifying key)
+    out = polyvm.plonk_prove(B, inp)
+    out.update(polyvm.resolved(vk))
+    out["gates_s_open"]["of"], out["w_x_open"]["of"] = "s", "w"
+    n_open = sum(1 for o in out.values() if isinstance(o, dict) and o.get("of"))
+    chk = bench.verify_openings(czk_amd, ctx, B, out)
+    assert chk["results_checked"] and chk["results_checked_points"] == parties * (n_open - 2) + 2
+
+    def val(label):                                                            # the revealed evaluation: the king_share stand-in puts the value on every lane
+        vs = [polyvm.unmont(x) for x in out[label]["value"]]
+        assert all(x == vs[0] for x in vs), label
+        return vs[0]
+    ch = polyvm.challenge
+    # verify_public (:526-540): one public wire at w^1 with value e[1]
+    x = ch("plonk.public.x")
+    assert (val("pub_p_open") - e[1]) % R_MOD == val("pub_q_open") * (x - w) % R_MOD
+    # verify_gates (:542-560)
+    x = ch("plonk.gates.x")
+    s, q, p, pw, pww = (val(k) for k in ("gates_s_open", "gates_q_open", "gates_p_open", "gates_p_w_open", "gates_p_w2_open"))
+    assert (s * (p + pw) + (1 - s) * p * pw - pww) % R_MOD == q * polyvm.vanishing(G, x) % R_MOD
+    # verify_unit_product (:451-474)
+    r = ch("plonk.product.r")
+    assert (val("t_wr_open") - val("t_r_open") * val("f_wr_open")) % R_MOD == polyvm.vanishing(W, r) * val("q_r_open") % R_MOD
+    assert val("t_wk_open") == 1
+    # verify_wiring (:561-582)
+    y, z, x = ch("plonk.wiring.y"), ch("plonk.wiring.z"), ch("plonk.wiring.x")
+    p_x, l1_x, w_x, l2 = val("p_x_open"), val("l1_x_open"), val("w_x_open"), val("l2_q_x_open")
+    assert ((p_x + y * x + z) * l1_x - (p_x + y * w_x + z)) % R_MOD == l2 * polyvm.vanishing(W, x) % R_MOD
+    ctx.close()

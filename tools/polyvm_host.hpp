@@ -357,7 +357,9 @@ class Machine {
         ctx.check(czk_fr_powers(ctx.raw(), one.l, k.l, n, o.p(), CZK_MEM_DEVICE));
         return o;
     }
-    Arr add_const(const Arr& a, const Fr& k) { return plus(a, constant(k, a.n)); }
+    Arr add_const(const Arr& a, const Fr& k) { return plus(a, constant(k, a.n)); }   // k on every element: arrays of EVALUATIONS
+    // `&DensePolynomial + &F` (algebra/poly/src/polynomial/univariate/dense.rs:301-315): a polynomial in COEFFICIENT form takes a constant on coefficient 0 only
+    Arr poly_add_const(const Arr& a, const Fr& k) { return plus(a, resized(constant(k, 1), a.n)); }
     Arr ntt(const Arr& a, size_t size, int kind) {
         const size_t m = std::min(a.n, size);
         Arr o = alloc(a.lanes, size);
@@ -600,7 +602,7 @@ inline Output plonk_prove(Machine& B, const PlonkInputs& inp) {
     open_("pub_p_open", p, x, "p");
     // prove_gates (:295-340): d = s (p + pw) + (1 - s)(p pw) - pww, q = d / v_gates
     Arr pw = B.shift(p, w), pww = B.shift(p, ww);
-    Arr one_minus_s = B.add_const(B.scale(s_pub, fr_neg(fr_one())), fr_one());   // public
+    Arr one_minus_s = B.poly_add_const(B.scale(s_pub, fr_neg(fr_one())), fr_one());   // public: `&(&circ.s * &-F::one()) + &F::one()` (:307-308)
     Arr d = B.sub(B.padded_add(B.poly_mul(s_pub, B.add(p, pw)), B.poly_mul(one_minus_s, B.poly_mul(p, pw))), B.resized(pww, G + 2 * W - 2));
     Arr q_gates = B.div_vanishing(d, G).first;
     commit("gates_q", q_gates);
