@@ -15,7 +15,7 @@ Python; nothing here comes from the library except the proof."""
 import numpy as np
 import pytest
 
-from groth16_real_key import R_INV, expected_exponents, key_scalars, real_key
+from groth16_real_key import R_INV, expected_exponents, key_scalars, limbs, real_key
 from util import R_MOD, dot_mod_r, ints_to_limbs, limbs_to_ints, rand_fr_canonical
 
 pytestmark = pytest.mark.gpu
@@ -103,13 +103,18 @@ def satisfied_plonk_inputs(B, polyvm, n_gates: int, seed: int):
         a, b, c = 3 * (i - 1) + 2, 3 * i, 3 * i + 1
         sigma[a], sigma[b], sigma[c] = b, c, a
     assert all(e[j] == e[sigma[j]] for j in range(W))
-    pub = lambda vals: B.upload(np.stack([polyvm.mont(x) for x in vals])[None])   # noqa: E731  (1, n, 4) public array
+    rr = (1 << 256) % R_MOD
+    pub = lambda vals: B.upload(limbs([x * rr % R_MOD for x in vals])[None])   # noqa: E731  (1, n, 4) public array, Montgomery form
     p_pub = B.ntt(pub(e), W, polyvm.IFFT)
-    inp = {"n_gates": G, "p": polyvm.shared_copy(B, p_pub), "s": B.ntt(pub(s_ev), G, polyvm.IFFT), "w": B.ntt(pub([pow(w, sg, R_MOD) for sg in sigma]), W, polyvm.IFFT)}
+    wp, acc = [], 1
+    for _ in range(W):
+        wp.append(acc)
+        acc = acc * w % R_MOD
+    inp = {"n_gates": G, "p": polyvm.shared_copy(B, p_pub), "s": B.ntt(pub(s_ev), G, polyvm.IFFT), "w": B.ntt(pub([wp[sg] for sg in sigma]), W, polyvm.IFFT)}
     return inp, e, w
 
 
-@pytest.mark.parametrize("n_gates,parties", [(8, 3), (256, 3), (2048, 2)])
+@pytest.mark.parametrize("n_gates,parties", [(8, 3), (256, 3), (2048, 2), (1 << 18, 3)])   # the last: BASELINE configs[2]'s size
 def test_plonk_proof_of_a_satisfied_circuit_verifies(n_gates, parties):
     """mpc-plonk's Prover::prove on the GPU path for a satisfied circuit, then the reference's Verifier::verify (lib.rs:511-590) on what it returns: every
     KZG opening against its commitment (with the synthetic SRS's known tau: C - [v] G == [tau - x] W, bench.verify_openings) and the four identities on the
