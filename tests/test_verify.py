@@ -21,7 +21,7 @@ from util import R_MOD, dot_mod_r, ints_to_limbs, limbs_to_ints, rand_fr_canonic
 pytestmark = pytest.mark.gpu
 
 
-def prove_and_verify(orc, N, parties, scheme):
+def prove_and_verify(orc, N, parties, scheme, **prover_kw):
     import torch
     import czk_amd as czk
     from czk_amd.provers import Groth16Local
@@ -36,10 +36,10 @@ def prove_and_verify(orc, N, parties, scheme):
     ts = torch.cuda.Stream()
     with torch.cuda.stream(ts):
         ctx = czk.Context(0, ts.cuda_stream)
-        p = Groth16Local(czk, ctx, N, parties, scheme=scheme, key_scalars=ks)
+        p = Groth16Local(czk, ctx, N, parties, scheme=scheme, key_scalars=ks, **prover_kw)
         p.step()
         torch.cuda.synchronize()
-        proof = p.create_proof({k: v.copy() for k, v in p.results.items()}, rs[0], rs[1])
+        proof = p.create_proof({k: v.copy() for k, v in p.results.items()}, rs[0], rs[1])      # (expands one-MSM-per-party results to the lanes)
         lpp = p.lpp
         opened = {}                                                # open: the parties' sh lanes added up
         for k, g in (("a", 1), ("b", 2), ("c", 1)):
@@ -72,6 +72,13 @@ def prove_and_verify(orc, N, parties, scheme):
 @pytest.mark.parametrize("n_constraints,parties,scheme", [(10, 2, "spdz"), (1000, 2, "spdz"), (1000, 3, "gsz"), (333, 1, "hbc"), (4094, 2, "hbc")])
 def test_groth16_proof_verifies_under_a_real_key(orc, n_constraints, parties, scheme):
     prove_and_verify(orc, n_constraints, parties, scheme)
+
+
+@pytest.mark.parametrize("kw", [{"no_tables": True}, {"mac_msm_from_sh": True}])
+def test_groth16_proof_verifies_in_the_other_msm_forms(orc, kw):
+    """the key registered without window tables (CZK_MEM_NO_TABLES: one bucket set per window), and the reference-shaped SPDZ form (one MSM per party over its sh
+    lane, the result used for the sh and the mac group share: spdz.rs:440-446)"""
+    prove_and_verify(orc, 3000, 2, "spdz", **kw)
 
 
 def test_groth16_full_size_proof_verifies(orc):
