@@ -123,6 +123,8 @@ class Backend:
     def jac_to_affine(self, jac): raise NotImplementedError          # (k, 18) -> ((k, 12), (k,))
     def random(self, seed: int, n: int): raise NotImplementedError   # public (1, n, 4): rand_fr_canonical(seed, n) in Montgomery form
     def root_of_unity(self, size: int) -> int: raise NotImplementedError   # get_root_of_unity(size), canonical integer
+    def matrix(self, row_ptr, col, coeff, n_cols: int): raise NotImplementedError   # a public sparse matrix (CSR, Montgomery coefficients) for matvec
+    def matvec(self, mat, v): raise NotImplementedError               # M v for a public (1, n_cols, 4) vector -> (1, rows, 4)
 
     # --- derived (shared by every backend) ----------------------------------------------------------------------
     def plus(self, a, b):
@@ -524,6 +526,18 @@ class GpuBackend(Backend):
     def jac_to_affine(self, jac):
         return self.ctx.jac_to_affine(self.czk.CZK_G1, jac)
 
+    def matrix(self, row_ptr, col, coeff, n_cols):
+        return self.ctx.r1cs_matrix_register(np.ascontiguousarray(row_ptr, dtype=np.uint64), np.ascontiguousarray(col, dtype=np.uint32),
+                                             np.ascontiguousarray(coeff, dtype=np.uint64), n_cols), len(row_ptr) - 1, n_cols
+
+    def matvec(self, mat, v):
+        handle, rows, n_cols = mat
+        v = v.contiguous()
+        assert v.shape[0] == 1 and v.shape[1] == n_cols
+        out = self._new(1, rows)
+        self.ctx.r1cs_matvec(handle, v.data_ptr(), lanes=1, out=out.data_ptr(), z_stride=n_cols, out_stride=rows, mem=self.M)
+        return out
+
     def commit(self, a, key="g"):
         """Enqueues the MSM (czk_msm_async: the sort / accumulate / reduce stages of consecutive commitments overlap on the
         library's streams, and with the NTTs enqueued after them) and returns a Pending; transcript_point() settles it."""
@@ -773,7 +787,16 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     hpow = B.powers(B.root_of_unity(H), H)
     r_alpha_evals = B.scale(B.inverse(B.add_const(B.scale(hpow, R_MOD - 1), alpha)), vanishing(H, alpha))
     r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT)
-    t_poly = B.ntt(B.mul(inp["t_rows"], r_alpha_evals), H, IFFT)          # calculate_t (:400-416): matrix-weighted r_alpha on H
+    if inp.get("matrices_T") is not None:
+        # calculate_t (:400-416) on a real index: t_evals[reindex(c)] += eta_M M[r][c] r_alpha[r] -- (sum_M eta_M M~)^T r_alpha with the column positions
+        # re-indexed by the input sub-domain; `matrices_T` holds the transposed, re-indexed matrices
+        t_evals = None
+        for m, eta in (("a", eta_a), ("b", eta_b), ("c", eta_c)):
+            term = B.scale(B.matvec(inp["matrices_T"][m], r_alpha_evals), eta)
+            t_evals = term if t_evals is None else B.add(t_evals, term)
+        t_poly = B.ntt(t_evals, H, IFFT)
+    else:
+        t_poly = B.ntt(B.mul(inp["t_rows"], r_alpha_evals), H, IFFT)      # the benchmark's index: one weight per row (same work: one pass over |H| elements and a transform)
     x_poly = B.ntt(inp["x"], X, IFFT)                                              # interpolated again in the second round (:503-507)
     z_poly = _padded_add(B, _mul_by_vanishing(B, w_poly, X), x_poly)              # w v_X + x (:512-517)
     n_rhs = max(B.length(r_alpha_poly) + B.length(summed), B.length(t_poly) + B.length(z_poly)) - 1
@@ -811,9 +834,10 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     for m, o1, o2 in (("a", "b", "c"), ("b", "a", "c"), ("c", "a", "b")):
         term = B.scale(B.mul(val_b[m], B.mul(den_b[o1], den_b[o2])), etas[m])      # (:664-673)
         a_on_b = term if a_on_b is None else B.add(a_on_b, term)
-    # in a real index a and b have degree < 3 |K| - 3 (that is why domain_b has that size, :636): keep that many coefficients
-    a_poly = B.resized(B.ntt(B.scale(a_on_b, vh), b_size, IFFT), 3 * K - 3)
-    b_poly = B.resized(B.ntt(B.mul(den_b["a"], B.mul(den_b["b"], den_b["c"])), b_size, IFFT), 3 * K - 3)
+    # in a real index row, col, val and row_col have degree |K| - 1, so a and b have degree 3 |K| - 3: 3 |K| - 2 coefficients (domain_b is asked for 3 |K| - 3
+    # points, :636, and holds them because it rounds up to a power of two); keep that many of the stand-in data's
+    a_poly = B.resized(B.ntt(B.scale(a_on_b, vh), b_size, IFFT), 3 * K - 2)
+    b_poly = B.resized(B.ntt(B.mul(den_b["a"], B.mul(den_b["b"], den_b["c"])), b_size, IFFT), 3 * K - 2)
     bf = B.poly_mul(b_poly, f)
     h_2, _ = B.div_vanishing(B.sub(B.resized(a_poly, B.length(bf)), bf), K)        # (a - b f) / v_K (:693-696)
     for label, a in (("g_2", g_2), ("h_2", h_2)):
@@ -838,6 +862,29 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
            "inner_sumcheck": [(challenge("marlin.lc." + m + "_val"), m + "_val") for m in "abc"] + [(challenge("marlin.lc.h_2"), "h_2")]}
     for m in "abc":
         lcs[m + "_denom"] = [(R_MOD - alpha, m + "_row"), (R_MOD - beta, m + "_col"), (1, m + "_row_col")]
+    if inp.get("real_lcs"):
+        # the coefficients AHPForR1CS::construct_linear_combinations (ahp/mod.rs:115-260) really uses: products of challenges and of evaluations the prover
+        # publicizes first (:155-157, :228-231).  Blocking reads of lane 0 (every lane is the plain prover when the caller lifts public data onto all of them);
+        # the LCTerm::One constants go to out["lc_consts"]: they do not enter the opened polynomials, the verifier moves them to the evaluation side.
+        ev = lambda a, x: unmont(B.div_linear(a, x)[1][0])     # noqa: E731
+        inv = lambda v: pow(v % R_MOD, -1, R_MOD)                # noqa: E731
+        r_ab = (vanishing(H, alpha) - vanishing(H, beta)) * inv(alpha - beta) % R_MOD          # eval_unnormalized_bivariate_lagrange_poly
+        vh_a, vh_b, vx_b = vanishing(H, alpha), vanishing(H, beta), vanishing(X, beta)
+        z_b_beta, t_beta, g_1_beta, x_beta = ev(z_b, beta), ev(t_poly, beta), ev(g_1, beta), ev(x_poly, beta)
+        lcs["outer_sumcheck"] = [(1, "mask_poly"), (r_ab * (eta_a + eta_c * z_b_beta) % R_MOD, "z_a"), (-t_beta * vx_b % R_MOD, "w"), (-vh_b % R_MOD, "h_1")]
+        consts = {"outer_sumcheck": (r_ab * eta_b % R_MOD * z_b_beta - t_beta * x_beta - beta * g_1_beta) % R_MOD}
+        den = {m: (beta * alpha - alpha * ev(row[m], gamma) - beta * ev(col[m], gamma) + ev(row_col[m], gamma)) % R_MOD for m in "abc"}
+        g_2_gamma = ev(g_2, gamma)
+        k_inv = inv(K)
+        lcs["inner_sumcheck"] = [(eta_a * den["b"] % R_MOD * den["c"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "a_val"),
+                                 (eta_b * den["a"] % R_MOD * den["c"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "b_val"),
+                                 (eta_c * den["b"] % R_MOD * den["a"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "c_val"),
+                                 (-vanishing(K, gamma) % R_MOD, "h_2")]
+        consts["inner_sumcheck"] = -(den["a"] * den["b"] % R_MOD * den["c"] % R_MOD) * (gamma * g_2_gamma + t_beta * k_inv) % R_MOD
+        for m in "abc":
+            consts[m + "_denom"] = beta * alpha % R_MOD
+        out["lc_consts"] = consts
+        out["lcs"] = {k: list(v) for k, v in lcs.items()}
     point = {"beta": beta, "gamma": gamma}
     query = {"beta": ["g_1", "outer_sumcheck", "t", "z_b"], "gamma": ["a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"]}   # verifier_query_set (ahp/verifier.rs:143-146, 207-211), labels in BTreeSet order
 
@@ -920,9 +967,9 @@ def _mul_by_vanishing(B, a, n):
 def marlin_commit_sizes(n_constraints: int):
     """lengths of the polynomials marlin_prove commits (for GpuBackend.prepare)"""
     H = K = next_pow2(n_constraints)
-    return [H - 1, H + 1, 3 * H, H, H - 1, 2 * H, K - 1, 3 * K - 4, 3 * H - 1, H - 2, 3 * K - 5, K - 2, K]
+    return [H - 1, H + 1, 3 * H, H, H - 1, 2 * H, K - 1, 3 * K - 3, 3 * H - 1, H - 2, 3 * K - 4, K - 2, K]
 
 
 def marlin_max_degree(n_constraints: int) -> int:
-    """Longest committed polynomial: mask_poly (3 |H| coefficients) or h_2 = (a - b f) / v_K (3 |K| - 4)."""
+    """Longest committed polynomial: mask_poly (3 |H| coefficients) or h_2 = (a - b f) / v_K (3 |K| - 3)."""
     return 3 * next_pow2(n_constraints) + 8

@@ -162,3 +162,132 @@ def test_plonk_proof_of_a_satisfied_circuit_verifies(n_gates, parties):
     p_x, l1_x, w_x, l2 = val("p_x_open"), val("l1_x_open"), val("w_x_open"), val("l2_q_x_open")
     assert ((p_x + y * x + z) * l1_x - (p_x + y * w_x + z)) % R_MOD == l2 * polyvm.vanishing(W, x) % R_MOD
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Marlin: a real index of a satisfied R1CS instance, the AHP verifier's decision (marlin/src/ahp/mod.rs:115-260, marlin/src/lib.rs:320-450)
+# ---------------------------------------------------------------------------------------------------------------------------------------
+def marlin_real_inputs(B, polyvm, H: int, seed: int):
+    """The benchmark's Marlin inputs are work-shaped stand-ins (random index data, random z_a / z_b); this builds the real thing for a satisfied instance:
+    |H| constraints and variables -- formatted input [1, out], a squaring chain w_{i+1} = w_i^2 ending in `out`, and two rows that use the input columns
+    (1 * out = out, 3 * 1 = 3) -- arithmetised as the indexer does (ahp/constraint_systems.rs:152-260: row / col / val of M* over K with val divided by
+    u_H(col, col), variables placed on H by reindex_by_subdomain), with z_a = A z, z_b = B z, a mask polynomial that sums to zero over H (prover.rs:376-380)
+    and the transposed matrices calculate_t walks (prover.rs:400-416)."""
+    X, K = 2, H
+    ratio = H // X
+    b_size = polyvm.next_pow2(3 * K - 3)
+    h = B.root_of_unity(H)
+    elems, acc = [], 1
+    for _ in range(H):
+        elems.append(acc)
+        acc = acc * h % R_MOD
+    reindex = lambda i: i * ratio if i < X else (i - X) + (i - X) // (ratio - 1) + 1   # noqa: E731  (domain/mod.rs:196-218)
+    nw = H - X
+    w = [limbs_to_ints(rand_fr_canonical(seed, 1))[0]]
+    for _ in range(nw - 1):
+        w.append(w[-1] * w[-1] % R_MOD)
+    out_v = w[-1] * w[-1] % R_MOD
+    z = [1, out_v] + w                                           # variable i: inputs first, then the witness
+    var_w = lambda i: X + i                                      # noqa: E731
+    rows = {"a": [], "b": [], "c": []}
+    for i in range(nw):
+        rows["a"].append([(1, var_w(i))])
+        rows["b"].append([(1, var_w(i))])
+        rows["c"].append([(1, var_w(i + 1) if i + 1 < nw else 1)])
+    rows["a"] += [[(1, 0)], [(3, 0)]]
+    rows["b"] += [[(1, 1)], [(1, 0)]]
+    rows["c"] += [[(1, 1)], [(3, 0)]]
+    mz = {m: [sum(cf * z[i] for cf, i in row) % R_MOD for row in rows[m]] for m in "abc"}
+    assert all(a * b % R_MOD == c for a, b, c in zip(mz["a"], mz["b"], mz["c"])) and len(rows["a"]) == H
+    rr = (1 << 256) % R_MOD
+    pub = lambda vals: B.upload(limbs([x * rr % R_MOD for x in vals])[None])   # noqa: E731
+    h_inv = pow(H, -1, R_MOD)                                                    # 1 / u_H(e, e) = 1 / (|H| e^(|H| - 1)) = e / |H| on H
+    inp = {"H": H, "K": K, "X": X, "b_size": b_size, "star": {}, "matrices_T": {}, "real_lcs": True, "t_rows": None}
+    index_polys = []
+    for m in "abc":
+        row_v, col_v, val_v, trans = [], [], [], [[] for _ in range(H)]
+        for r, row in enumerate(rows[m]):
+            for cf, i in sorted(row, key=lambda t: t[1]):
+                cv = elems[reindex(i)]
+                row_v.append(cv)                                 # "we are dealing with the transpose of M" (:191-194)
+                col_v.append(elems[r])
+                val_v.append(cf * cv % R_MOD * h_inv % R_MOD)
+                trans[reindex(i)].append((r, cf))
+        pad = K - len(row_v)
+        row_v += [elems[0]] * pad
+        col_v += [elems[0]] * pad
+        val_v += [0] * pad
+        rc_v = [a * b % R_MOD for a, b in zip(row_v, col_v)]
+        on_k = [pub(v) for v in (row_v, col_v, val_v)]
+        polys = [B.ntt(pub(v), K, polyvm.IFFT) for v in (row_v, col_v, val_v, rc_v)]           # row, col, val, row_col
+        on_b = [B.ntt(polys[j], b_size, polyvm.FFT) for j in (0, 1, 3, 2)]                     # row, col, row_col, val on B
+        inp["star"][m] = {"on_K": on_k, "on_B": on_b}
+        index_polys += polys
+        rp, cols, cfs = [0], [], []
+        for p in range(H):
+            for r, cf in trans[p]:
+                cols.append(r)
+                cfs.append(cf * rr % R_MOD)
+            rp.append(len(cols))
+        inp["matrices_T"][m] = B.matrix(np.array(rp, dtype=np.uint64), np.array(cols, dtype=np.uint32), limbs(cfs), H)
+    inp["index_polys"] = index_polys
+    cm = [B.commit(a) for a in index_polys]
+    B.transcript_point()
+    inp["index_cmts"] = polyvm.resolved(cm)
+    inp["x"] = pub([1, out_v])
+    w_full = [z[k // ratio] if k % ratio == 0 else w[k - k // ratio - 1] for k in range(H)]
+    assert all(w_full[reindex(i)] == z[i] for i in range(H))
+    inp["w"] = polyvm.shared_copy(B, pub(w_full))
+    inp["z_a"] = polyvm.shared_copy(B, pub(mz["a"]))
+    inp["z_b"] = polyvm.shared_copy(B, pub(mz["b"]))
+    mask = limbs_to_ints(rand_fr_canonical(seed + 5, 3 * H))
+    mask[0] = (mask[0] - sum(mask[j] for j in range(0, 3 * H, H))) % R_MOD     # the remainder mod v_H has constant term 0: the mask sums to zero over H
+    inp["mask_poly"] = polyvm.shared_copy(B, pub(mask))
+    return inp
+
+
+@pytest.mark.parametrize("H", [8, 64, 1024, 1 << 16])
+def test_marlin_proof_of_a_satisfied_instance_verifies(H):
+    """Marlin's AHP prover rounds, commitments and batched openings on the GPU path for a REAL index and a satisfied instance (the opt-in paths of
+    polyvm.marlin_prove: calculate_t over the transposed matrices, the linear combinations' real coefficients), then the verifier: every KZG opening -- the
+    two batched ones against the folded commitments, the degree-bound witnesses -- with the known tau (bench.verify_openings), and the AHP decision: the outer
+    sumcheck combination evaluates to zero at beta and the inner one at gamma (ahp/mod.rs:168-183, 233-250), constants included."""
+    import czk_amd
+    from czk_amd import polyvm
+    import bench
+    ctx = polyvm.shared_stream_context(czk_amd)
+    lanes = 2
+    B = polyvm.GpuBackend(czk_amd, ctx, lanes, polyvm.marlin_max_degree(H), lift=(1,) * lanes)    # public data on every lane: each lane is the plain prover
+    inp = marlin_real_inputs(B, polyvm, H, 0x3A21 + H)
+    out = polyvm.marlin_prove(B, inp)
+    chk = bench.verify_openings(czk_amd, ctx, B, out)
+    assert chk["results_checked"] and chk["results_checked_points"] == 2 * lanes + 2      # beta: share lanes; gamma: index polynomials, public
+    # the evaluations the prover publicized, by (polynomial, point): replay of marlin_prove's lc_eval order
+    lcs, consts = out["lcs"], out["lc_consts"]
+    query_beta = ("g_1", "outer_sumcheck", "t", "z_b")
+    it = {"beta": iter(out["evals_beta"]), "gamma": iter(out["evals_gamma"])}
+    ev = {}
+
+    def take(label, tag):
+        for _, name in lcs[label]:
+            v = [polyvm.unmont(x) for x in next(it[tag])]
+            assert all(x == v[0] for x in v), (label, name)
+            assert ev.setdefault((name, tag), v[0]) == v[0]
+    for label, tag in (("z_b", "beta"), ("t", "beta"), ("g_1", "beta"), ("a_denom", "gamma"), ("b_denom", "gamma"), ("c_denom", "gamma"), ("g_2", "gamma")):
+        take(label, tag)
+    for label in sorted(lcs):
+        take(label, "beta" if label in query_beta else "gamma")
+    assert next(it["beta"], None) is None and next(it["gamma"], None) is None
+    lc_at = lambda label, tag: (sum(cf * ev[(name, tag)] for cf, name in lcs[label]) + consts.get(label, 0)) % R_MOD   # noqa: E731
+    assert lc_at("outer_sumcheck", "beta") == 0, "outer sumcheck"
+    assert lc_at("inner_sumcheck", "gamma") == 0, "inner sumcheck"
+    # the batched openings opened what the verifier folds: sum_j ch^j (LC_j without its constant), a degree-bounded polynomial taking two challenges
+    ch = polyvm.challenge("marlin.opening_challenge")
+    for tag, labels in (("beta", query_beta), ("gamma", ("a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"))):
+        want, c = 0, 1
+        for label in labels:
+            want = (want + c * (lc_at(label, tag) - consts.get(label, 0))) % R_MOD
+            c = c * ch % R_MOD * (ch if label in ("g_1", "g_2") else 1) % R_MOD
+        got = [polyvm.unmont(x) for x in out["open_" + tag]["value"]]
+        assert all(g == want for g in got), tag
+    ctx.close()

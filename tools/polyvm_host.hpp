@@ -670,7 +670,7 @@ struct MarlinInputs {
 inline size_t marlin_max_degree(size_t n) { return 3 * next_pow2(n) + 8; }
 inline std::vector<size_t> marlin_commit_sizes(size_t n) {
     const size_t H = next_pow2(n), K = H;
-    return {H - 1, H + 1, 3 * H, H, H - 1, 2 * H, K - 1, 3 * K - 4, 3 * H - 1, H - 2, 3 * K - 5, K - 2, K};
+    return {H - 1, H + 1, 3 * H, H, H - 1, 2 * H, K - 1, 3 * K - 3, 3 * H - 1, H - 2, 3 * K - 4, K - 2, K};
 }
 inline MarlinInputs marlin_inputs(Machine& B, size_t n_constraints, uint64_t seed = 0x3A21) {
     MarlinInputs inp;
@@ -782,8 +782,8 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
         Arr term = B.scale(B.mul(val_b[m], B.mul(den_b[others[m][0]], den_b[others[m][1]])), etas[m]);   // (:664-673)
         a_on_b = a_on_b ? B.add(a_on_b, term) : term;
     }
-    Arr a_poly = B.resized(B.ntt(B.scale(a_on_b, vh), b_size, IFFT), 3 * K - 3);
-    Arr b_poly = B.resized(B.ntt(B.mul(den_b[0], B.mul(den_b[1], den_b[2])), b_size, IFFT), 3 * K - 3);
+    Arr a_poly = B.resized(B.ntt(B.scale(a_on_b, vh), b_size, IFFT), 3 * K - 2);   // degree 3 |K| - 3 in a real index: 3 |K| - 2 coefficients
+    Arr b_poly = B.resized(B.ntt(B.mul(den_b[0], B.mul(den_b[1], den_b[2])), b_size, IFFT), 3 * K - 2);
     Arr bf = B.poly_mul(b_poly, f);
     Arr h_2 = B.div_vanishing(B.sub(B.resized(a_poly, bf.n), bf), K).first;   // (a - b f) / v_K (:693-696)
     commit("g_2", g_2, false);
