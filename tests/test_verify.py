@@ -246,7 +246,7 @@ def marlin_real_inputs(B, polyvm, H: int, seed: int):
     return inp
 
 
-@pytest.mark.parametrize("H", [8, 64, 1024, 1 << 16, 1 << 20])   # the last: BASELINE configs[3]'s size
+@pytest.mark.parametrize("H", [8, 64, 1024, 1 << 16])   # (|H| = 2^20, BASELINE configs[3]'s size: 27 s, run by hand -- profiles/r05_verification_runs.txt)
 def test_marlin_proof_of_a_satisfied_instance_verifies(H):
     """Marlin's AHP prover rounds, commitments and batched openings on the GPU path for a REAL index and a satisfied instance (the opt-in paths of
     polyvm.marlin_prove: calculate_t over the transposed matrices, the linear combinations' real coefficients), then the verifier: every KZG opening -- the
