@@ -206,8 +206,9 @@ static void combine_windows_impl(const u64* src, unsigned W, unsigned c, size_t 
     for (size_t l = 0; l < lanes; l++) {
         Jac<F> acc;
         load_jac<F>(src + (l * W + (W - 1)) * JW, acc);
+        const unsigned W_hi = msm_full_windows(c);
         for (unsigned w = W - 1; w-- > 0;) {
-            for (unsigned k = 0; k < c; k++) acc = jac_double(acc);   // the Horner step of variable_base.rs:92-105
+            for (unsigned k = 0; k < msm_win_width(c, W_hi, w); k++) acc = jac_double(acc);   // the Horner step of variable_base.rs:92-105
             Jac<F> r;
             load_jac<F>(src + (l * W + w) * JW, r);
             acc = jac_add(acc, r);

@@ -261,7 +261,19 @@ int ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes);                    
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
                int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable);
 int msm_pipeline_init(czk_ctx* ctx);
-// sum_w 2^(c w) R[lane][w] on the host (Horner: c doublings per window); src: lanes x W Jacobian triples, out: lanes triples
+// Window layout of the signed-digit split (254 bits: 253-bit scalars + the carry).  W(c) = ceil(254 / c) windows of c bits overshoot by
+// slack = W c - 254 bits, which the plain layout leaves in the TOP window: with a narrow top window (< 10 bits) every point's top digit lands on
+// one of 2^top buckets -- n / 2^top additions in a row on each, the latency of a mid-size MSM (profiles/r04_tiny_msm.txt).  Such widths are
+// BALANCED instead: the last `slack` windows are c - 1 bits wide, so every window is full and no bucket sees more than twice the average.
+// Widths with a top window of >= 10 bits (every layout chosen for n >= 2^14 points: c = 15, 17, 20, ...) keep the plain layout.
+CZK_HD unsigned msm_num_windows(unsigned c) { return (254 + c - 1) / c; }
+CZK_HD unsigned msm_full_windows(unsigned c) {   // windows [0, W_hi) are c bits wide, windows [W_hi, W) are c - 1 bits wide
+    const unsigned W = msm_num_windows(c), top = 254 - (W - 1) * c, slack = W * c - 254;
+    return (top < 10 && slack <= W) ? W - slack : W;
+}
+CZK_HD unsigned msm_win_bit(unsigned c, unsigned W_hi, unsigned w) { return w * c - (w > W_hi ? w - W_hi : 0); }   // first bit of window w
+CZK_HD unsigned msm_win_width(unsigned c, unsigned W_hi, unsigned w) { return w < W_hi ? c : c - 1; }
+// sum_w 2^(bit(w)) R[lane][w] on the host (Horner: width(w) doublings per window); src: lanes x W Jacobian triples, out: lanes triples
 void host_combine_windows(int group, const char* src, unsigned W, unsigned c, size_t lanes, uint64_t* out);
 int msm_pipeline_sync(czk_ctx* ctx);
 void msm_pipeline_destroy(czk_ctx* ctx);

@@ -153,19 +153,20 @@ __global__ void k_digits(const u64* scalars, size_t n_scalars, size_t size, int 
     Fr s = fp_load<FrParams>(scalars + 4 * ((size_t)lane * n_scalars + i));
     if (montgomery) s = fp_into_repr(s);   // ec/src/lib.rs:305-307
     u32 carry = 0;
-    const u32 half = 1u << (c - 1);
+    const unsigned W_hi = msm_full_windows(c);
     for (unsigned w = 0; w < W; w++) {
-        unsigned bit = w * c;
+        const unsigned bit = msm_win_bit(c, W_hi, w), cw = msm_win_width(c, W_hi, w);
+        const u32 half = 1u << (cw - 1);
         u32 v = 0;
         if (bit < 256) {
             unsigned limb = bit >> 5, off = bit & 31;
             u64 two = (u64)s.l[limb] | ((limb + 1 < 8) ? ((u64)s.l[limb + 1] << 32) : 0);
-            v = (u32)(two >> off) & ((1u << c) - 1u);
+            v = (u32)(two >> off) & ((1u << cw) - 1u);
         }
         v += carry;
         u32 code;
         if (v > half) {
-            code = ((1u << c) - v) | 0x80000000u;
+            code = ((1u << cw) - v) | 0x80000000u;
             carry = 1;
         } else {
             code = v;
@@ -293,19 +294,20 @@ __global__ __launch_bounds__(256) void k_digits_part(const u64* scalars, size_t 
         Fr s = fp_load<FrParams>(scalars + 4 * ((size_t)lane * n_scalars + i));
         if (montgomery) s = fp_into_repr(s);   // ec/src/lib.rs:305-307
         u32 carry = 0;
-        const u32 half = 1u << (c - 1);
+        const unsigned W_hi = msm_full_windows(c);
         for (unsigned w = 0; w < W; w++) {
-            unsigned bit = w * c;
+            const unsigned bit = msm_win_bit(c, W_hi, w), cw = msm_win_width(c, W_hi, w);
+            const u32 half = 1u << (cw - 1);
             u32 v = 0;
             if (bit < 256) {
                 unsigned limb = bit >> 5, off = bit & 31;
                 u64 two = (u64)s.l[limb] | ((limb + 1 < 8) ? ((u64)s.l[limb + 1] << 32) : 0);
-                v = (u32)(two >> off) & ((1u << c) - 1u);
+                v = (u32)(two >> off) & ((1u << cw) - 1u);
             }
             v += carry;
             u32 code;
             if (v > half) {
-                code = ((1u << c) - v) | 0x80000000u;
+                code = ((1u << cw) - v) | 0x80000000u;
                 carry = 1;
             } else {
                 code = v;
@@ -557,7 +559,7 @@ struct Bump {
     }
 };
 
-static unsigned num_windows(unsigned c) { return (254 + c - 1) / c; }
+static unsigned num_windows(unsigned c) { return msm_num_windows(c); }
 
 // window width for n bases: minimise W(c) * n mixed additions + ~3 * 2^(c-1) reduction additions.  (In instruction terms
 // a bucket costs ~6 mixed additions to reduce, but weighting it so -- c = 17 at n = 2^20 -- lengthens the accumulate kernels,
@@ -724,7 +726,7 @@ static int register_impl(czk_ctx* ctx, czk_bases* b, const u64* pts_dev, const u
         unsigned g1 = (unsigned)((n + 127) / 128), g2 = (unsigned)(((n + CH - 1) / CH + 127) / 128);
         for (unsigned w = 1; w < W; w++) {
             hipLaunchKernelGGL(k_dbl_c<F>, dim3(g1), dim3(128), 0, ctx->stream, b->pts + (size_t)(w - 1) * n * AW, b->inf + (size_t)(w - 1) * n,
-                               n, b->c, jac);
+                               n, msm_win_width(b->c, msm_full_windows(b->c), w - 1), jac);   // 2^(width of window w - 1) times the previous table
             hipLaunchKernelGGL(k_batch_to_affine<F>, dim3(g2), dim3(128), 0, ctx->stream, jac, n, CH, scr, b->pts + (size_t)w * n * AW,
                                b->inf + (size_t)w * n);
         }
@@ -817,7 +819,7 @@ static int build_secondary(czk_ctx* ctx, const czk_bases* b, unsigned c, size_t 
         const unsigned CH = 32;
         unsigned g1 = (unsigned)((cover + 127) / 128), g2 = (unsigned)(((cover + CH - 1) / CH + 127) / 128);
         for (unsigned w = 1; w < W; w++) {
-            hipLaunchKernelGGL(k_dbl_c<F>, dim3(g1), dim3(128), 0, ctx->stream, t.pts + (size_t)(w - 1) * cover * AW, t.inf + (size_t)(w - 1) * cover, cover, c, jac);
+            hipLaunchKernelGGL(k_dbl_c<F>, dim3(g1), dim3(128), 0, ctx->stream, t.pts + (size_t)(w - 1) * cover * AW, t.inf + (size_t)(w - 1) * cover, cover, msm_win_width(c, msm_full_windows(c), w - 1), jac);
             hipLaunchKernelGGL(k_batch_to_affine<F>, dim3(g2), dim3(128), 0, ctx->stream, jac, cover, CH, scr, t.pts + (size_t)w * cover * AW,
                                t.inf + (size_t)w * cover);
         }

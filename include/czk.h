@@ -378,7 +378,9 @@ int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases, const uin
 void czk_bases_release(czk_bases* b);
 size_t czk_bases_len(const czk_bases* b);
 /* Pippenger layout chosen at registration (reporting only): *c = signed-digit window width, *windows = ceil(254 / c) =
- * mixed additions per (point, lane) of an MSM over this array. */
+ * mixed additions per (point, lane) of an MSM over this array.  Where c * windows overshoots the 254 bits by `slack` bits and the top window
+ * would be narrower than 10 bits (widths chosen for fewer than 2^14 points), the last `slack` windows are c - 1 bits wide instead, so that
+ * no window is narrow and no bucket collects more than twice the average (csrc/czk_internal.h: msm_full_windows). */
 int czk_bases_layout(const czk_bases* b, unsigned* c, unsigned* windows);
 /* Window width per CALL.  The reference derives c from the size of each MSM (variable_base.rs:21-25); a precomputed table fixes
  * it per key, so a short MSM under a long key (KZG10::commit of a low-degree polynomial under `powers_of_g`,
