@@ -8,8 +8,8 @@ R=${1:-r03}
 OUT=$PWD/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-seam-report --no-other-workloads"
-PMC="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam-report --no-other-workloads --no-result-check"
+BENCH="python $PWD/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-seam-report --no-other-workloads --no-verify-report"
+PMC="python $PWD/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-seam-report --no-other-workloads --no-result-check --no-verify-report"
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES"; do
