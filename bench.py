@@ -279,7 +279,7 @@ def multi_gpu_report(n: int, headline: dict, dry_run: bool, budget_s: float) -> 
         if left < 30:
             out[key] = {"skipped": f"report budget of {budget_s:.0f} s used up"}
             continue
-        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-workloads", "--no-multi-gpu-report"] + argv + (["--dry-run"] if dry_run else [])
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-workloads", "--no-multi-gpu-report", "--no-verify-report"] + argv + (["--dry-run"] if dry_run else [])
         t0 = time.time()
         try:
             rc, c_out, c_err = _run_child(cmd, env, min(420.0, left))
