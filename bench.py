@@ -228,6 +228,11 @@ def multi_gpu_plan(n: int) -> list:
         return (f"{key}/party/{net}/{exch}", ["--gpus", str(n), "--layout", "party", "--exchange", exch, "--net", net] + argv, key + "/one_gpu")
     for net, exch in (("czk", "ring"), ("torch", "ring"), ("czk", "p2p"), ("torch", "p2p")):
         plan += [party(key, argv, net, exch) for key, argv in cfgs if not key.endswith("_no_tables")]
+        if (net, exch) == ("czk", "ring"):
+            # ... and, right after the first party runs, the Groth16 party layout under a REAL key: the parties' proof shares are gathered and the opened proof
+            # goes through the verification equation (`proof_verifies`) -- the reference's own acceptance test, over its own layout and over RCCL
+            plan += [(f"{key}/verify/czk/ring", ["--gpus", str(n), "--layout", "party", "--exchange", "ring", "--net", "czk", "--real-key"] + argv, None)
+                     for key, argv in cfgs if key.startswith("groth16") and not key.endswith("_no_tables")]
     plan.append(("groth16_spdz2_2e20/split", ["--gpus", str(n), "--layout", "split", "--parties", "2"] + g16_20, "headline"))
     # the library's third transport between GPUs: device mailboxes mapped into the peers with hipIpc (peer access over xGMI), no RCCL involved
     plan += [party(key, argv, "czk-ipc", "ring") for key, argv in cfgs if not key.endswith("_no_tables")]
@@ -298,6 +303,7 @@ def multi_gpu_report(n: int, headline: dict, dry_run: bool, budget_s: float) -> 
                         "n_gpus": j["n_gpus"], "ranks_seen_by_backend": j.get("ranks_seen_by_backend"), "backend": j.get("backend"), "net": j.get("net"),
                         "layout": j["config"].get("layout"), "exchange": argv[argv.index("--exchange") + 1] if "--exchange" in argv else None,
                         "per_rank": j.get("per_rank"), "results_checked": bool(j.get("results_checked")), "results_sha256": dg,
+                        **({"proof_verifies": j["proof_verifies"]} if j.get("proof_verifies") is not None else {}),
                         "reference": ref, "wall_s": time.time() - t0, "command": "python bench.py " + " ".join(argv)}
         except Exception as e:      # noqa: BLE001 -- the report must not take the replica line down with it
             out[key] = {"error": repr(e)[-400:], "command": "python bench.py " + " ".join(argv)}
@@ -412,44 +418,46 @@ def check_results(czk, ctx, prover, results) -> dict:
     return {"results_checked": True, "results_checked_points": checked, "results_check_s": round(time.perf_counter() - t0, 2)}
 
 
-def verify_report(czk, torch, device, tstream, n_constraints: int, parties: int, scheme: str) -> dict:
-    """One proof of THIS configuration under a REAL proving key, checked against the Groth16 verification equation -- the reference's own acceptance
-    criterion (mpc-snarks/src/proof.rs:140-143 asserts verify_proof).  The timed runs use a synthetic key (random points), whose proofs cannot verify;
-    here the key's discrete logs are generated from known toxic waste (tests/groth16_real_key.py: groth16/src/generator.rs restated on integers, the
-    domain generator from the reference's constants), the GPU builds the points and proves -- constraint evaluation, witness map with both opens, the five
-    MSMs on every share lane, create_proof's group steps -- and the opened proof must (1) equal [a] G1, [b] G2, [c] G1 for the exponents the prover
-    equations give from the plain witness and the quotient h, and (2) satisfy a b = alpha beta + (sum x_i gamma_abc_i) gamma + c delta (mod r): e(A, B) =
-    e(alpha, beta) e(IC, gamma) e(C, delta) in the exponent.  Host side: big-integer Python only (no library arithmetic, no checker code)."""
-    from groth16_real_key import R_INV, expected_exponents, key_scalars, real_key
-    from czk_amd.provers import Groth16Local, rand_fr_canonical
-    t0 = time.perf_counter()
-    ints = lambda a: [sum(int(v[j]) << (64 * j) for j in range(a.shape[-1])) for v in np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, a.shape[-1])]   # noqa: E731
-    key = real_key(n_constraints, ints(rand_fr_canonical(0x7A11 + n_constraints, 5)))
-    ks = key_scalars(key)
-    t_key = time.perf_counter() - t0
+def _ints(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    return [sum(int(v[j]) << (64 * j) for j in range(a.shape[-1])) for v in a.reshape(-1, a.shape[-1])]
+
+
+def real_key_for(n_constraints: int):
+    """(key, key scalars for Groth16Local, (r, s) limbs, r, s): a REAL Groth16 key of the benchmark circuit from known toxic waste (tests/groth16_real_key.py)"""
+    from groth16_real_key import key_scalars, real_key
+    from czk_amd.provers import rand_fr_canonical
+    key = real_key(n_constraints, _ints(rand_fr_canonical(0x7A11 + n_constraints, 5)))
     rs = rand_fr_canonical(0xC0FFEE + 77 + n_constraints, 2)
-    r, s = ints(rs)
-    ninv = pow(parties, -1, R_MOD) if scheme == "gsz" else 1
-    ctx = czk.Context(device, tstream.cuda_stream)
-    p = Groth16Local(czk, ctx, n_constraints, parties, scheme=scheme, key_scalars=ks)
-    p.step()
-    proof = p.create_proof({k: v.copy() for k, v in p.results.items()}, rs[0], rs[1])
+    r, s = _ints(rs)
+    return key, key_scalars(key), rs, r, s
+
+
+def open_proof_shares(czk, ctx, shares, scheme: str, parties: int):
+    """reveal: the parties' sh-lane shares of Proof{a, b, c} (Jacobian limbs, one per party) added up (x 1 / n for Shamir shares on the n-th roots of unity)"""
     G = {"a": czk.CZK_G1, "b": czk.CZK_G2, "c": czk.CZK_G1}
+    ninv = pow(parties, -1, R_MOD) if scheme == "gsz" else 1
     opened = {}
-    for k, g in G.items():                                  # reveal: the parties' sh lanes added up (x 1 / n for Shamir shares)
-        acc = proof[k][0]
-        for j in range(1, parties):
-            acc = ctx.jac_add(g, acc, proof[k][p.lpp * j])
+    for k, g in G.items():
+        acc = shares[k][0]
+        for sh in shares[k][1:]:
+            acc = ctx.jac_add(g, acc, sh)
         if scheme == "gsz":
             acc = ctx.jac_scalar_mul(g, acc, np.array([(ninv >> (64 * i)) & ((1 << 64) - 1) for i in range(4)], dtype=np.uint64))
         opened[k] = ctx.jac_to_affine(g, acc)
-    h_lanes = p.ab.cpu().numpy().view(np.uint64)
-    D = key["D"]
-    h_acc = sum(_dot_mod_r(h_lanes[p.lpp * j][:D - 1], ks["h"]) for j in range(parties)) * R_INV % R_MOD * ninv % R_MOD
-    w0 = ints(rand_fr_canonical(0xC0FFEE, 1))[0]
+    return opened, ninv
+
+
+def verify_opened_proof(czk, ctx, key, r: int, s: int, opened, h_acc: int) -> dict:
+    """The opened proof against (1) [a] G1, [b] G2, [c] G1 for the exponents the prover equations give (plain witness, r, s, h_acc = the h MSM in the exponent) and
+    (2) the verification equation in the exponent, e(A, B) = e(alpha, beta) e(IC, gamma) e(C, delta); big-integer Python only."""
+    from groth16_real_key import expected_exponents
+    from czk_amd.provers import rand_fr_canonical
+    G = {"a": czk.CZK_G1, "b": czk.CZK_G2, "c": czk.CZK_G1}
+    w0 = _ints(rand_fr_canonical(0xC0FFEE, 1))[0]
     a_exp, b_exp, c_exp, verifies, qap = expected_exponents(key, w0, r, s, h_acc)
     q_rinv = pow(1 << 384, -1, Q_MOD)
-    fq_ints = lambda limbs: [v * q_rinv % Q_MOD for v in ints(np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 6))]   # noqa: E731
+    fq_ints = lambda limbs: [v * q_rinv % Q_MOD for v in _ints(np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 6))]   # noqa: E731
     one = np.array([[1, 0, 0, 0]], dtype=np.uint64)
     g1, g2 = fq_ints(ctx.fixed_base_points(czk.CZK_G1, one)), fq_ints(ctx.fixed_base_points(czk.CZK_G2, one))
     gens = {czk.CZK_G1: (g1[0], g1[1]), czk.CZK_G2: ((g2[0], g2[1]), (g2[2], g2[3]))}
@@ -461,12 +469,37 @@ def verify_report(czk, torch, device, tstream, n_constraints: int, parties: int,
         got = fq_ints(aff[0])
         got = (got[0], got[1]) if g == czk.CZK_G1 else ((got[0], got[1]), (got[2], got[3]))
         points_ok = points_ok and want is not None and not inf[0] and got == want
+    return {"proof_verifies": bool(points_ok and verifies and qap), "proof_elements_match_prover_equations": bool(points_ok), "verification_equation_holds": bool(verifies),
+            "qap_identity_holds": bool(qap)}
+
+
+def verify_report(czk, torch, device, tstream, n_constraints: int, parties: int, scheme: str) -> dict:
+    """One proof of THIS configuration under a REAL proving key, checked against the Groth16 verification equation -- the reference's own acceptance
+    criterion (mpc-snarks/src/proof.rs:140-143 asserts verify_proof).  The timed runs use a synthetic key (random points), whose proofs cannot verify;
+    here the key's discrete logs are generated from known toxic waste (tests/groth16_real_key.py: groth16/src/generator.rs restated on integers, the
+    domain generator from the reference's constants), the GPU builds the points and proves -- constraint evaluation, witness map with both opens, the five
+    MSMs on every share lane, create_proof's group steps -- and the opened proof must (1) equal [a] G1, [b] G2, [c] G1 for the exponents the prover
+    equations give from the plain witness and the quotient h, and (2) satisfy a b = alpha beta + (sum x_i gamma_abc_i) gamma + c delta (mod r): e(A, B) =
+    e(alpha, beta) e(IC, gamma) e(C, delta) in the exponent.  Host side: big-integer Python only (no library arithmetic, no checker code)."""
+    from groth16_real_key import R_INV
+    from czk_amd.provers import Groth16Local
+    t0 = time.perf_counter()
+    key, ks, rs, r, s = real_key_for(n_constraints)
+    t_key = time.perf_counter() - t0
+    ctx = czk.Context(device, tstream.cuda_stream)
+    p = Groth16Local(czk, ctx, n_constraints, parties, scheme=scheme, key_scalars=ks)
+    p.step()
+    proof = p.create_proof({k: v.copy() for k, v in p.results.items()}, rs[0], rs[1])
+    opened, ninv = open_proof_shares(czk, ctx, {k: [proof[k][p.lpp * j] for j in range(parties)] for k in "abc"}, scheme, parties)
+    h_lanes = p.ab.cpu().numpy().view(np.uint64)
+    D = key["D"]
+    h_acc = sum(_dot_mod_r(h_lanes[p.lpp * j][:D - 1], ks["h"]) for j in range(parties)) * R_INV % R_MOD * ninv % R_MOD
+    res = verify_opened_proof(czk, ctx, key, r, s, opened, h_acc)
     del p
     ctx.close()
     torch.cuda.empty_cache()
-    assert points_ok, "proof elements differ from the prover equations' exponents"
-    assert verifies and qap, "the proof does not satisfy the verification equation"
-    return {"proof_verifies": True, "proof_elements_match_prover_equations": True, "qap_identity_holds": True, "constraints": n_constraints, "parties": parties,
+    assert res["proof_verifies"], res
+    return {**res, "constraints": n_constraints, "parties": parties,
             "scheme": scheme, "key": "real: discrete logs from known toxic waste (tests/groth16_real_key.py), points built by czk_fixed_base_points",
             "key_generation_s": round(t_key, 2), "seconds": round(time.perf_counter() - t0, 2),
             "note": "e(A, B) = e(alpha, beta) e(sum x_i gamma_abc_i, gamma) e(C, delta) checked in the exponent (all discrete logs known): the proof of this configuration "
@@ -922,6 +955,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-result-check", action="store_true")
     ap.add_argument("--no-seam-report", action="store_true")
+    ap.add_argument("--real-key", action="store_true", help="groth16, any layout: prove under a REAL key (discrete logs from known toxic waste, tests/groth16_real_key.py) and put the "
+                                                           "opened proof through the verification equation (`proof_verifies`; in the party layout the parties' shares are gathered on rank 0) "
+                                                           "instead of the discrete-log check of the synthetic key")
     ap.add_argument("--no-verify-report", action="store_true", help="skip `proof_verifies`: one proof of this configuration under a real key against the Groth16 verification equation")
     ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
                     help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "
@@ -1015,12 +1051,15 @@ def main():
         parallel.use_net(parallel.make_net(ctx, args.net_transport, device=torch.device("cuda", device) if args.backend == "nccl" else None))
     if args.workload != "groth16":
         return run_polyiop(args, czk, parallel, ctx, rank, world, n_constraints, size_txt)
+    rk = real_key_for(n_constraints) if args.real_key else None      # (key, key scalars, (r, s) limbs, r, s)
+    if rk is not None:
+        args.no_result_check = True       # the discrete-log check knows the synthetic key's logs; a real key's proof goes through the verification equation below
     if party_layout:
-        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables, scheme=args.scheme)
+        prover = Groth16Local(czk, ctx, n_constraints, args.parties, local_parties=[rank], no_tables=args.no_tables, scheme=args.scheme, key_scalars=rk and rk[1])
         prover.commit_opens = args.commit_opens
     else:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme,
-                              base_split=(rank, world) if split_layout else None)
+                              base_split=(rank, world) if split_layout else None, key_scalars=rk and rk[1])
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)
@@ -1087,6 +1126,30 @@ def main():
         torch.distributed.all_gather_object(gathered, per_key)
         mine = b"".join(g[k] for k in ("h", "l", "a", "b_g1", "b_g2") for g in gathered)
     digest = hashlib.sha256(mine).hexdigest()
+    real_key_report = None
+    if rk is not None:
+        # the last proof of the timed region, opened and verified: every rank contributes its local parties' sh-lane shares of Proof{a, b, c} and its lanes'
+        # part of the h MSM's exponent; rank 0 adds them up (party layout: gathered over the process group; split layout: rank 0 holds the combined sums)
+        from groth16_real_key import R_INV
+        key, ks, rs_l, r_int, s_int = rk
+        t_v = time.perf_counter()
+        have_results = rank == 0 or not split_layout
+        shares, h_part = None, 0
+        if have_results:
+            proof = prover.create_proof({k: v.copy() for k, v in prover.all_results[-1].items()}, rs_l[0], rs_l[1])
+            shares = {k: [proof[k][prover.lpp * j] for j in range(len(prover.local))] for k in "abc"}
+            h_l = prover.ab.cpu().numpy().view(np.uint64)
+            h_part = sum(_dot_mod_r(h_l[prover.lpp * j][:prover.D - 1], ks["h"]) for j in range(len(prover.local))) % R_MOD
+        if party_layout:
+            got = [None] * world
+            torch.distributed.all_gather_object(got, (shares, h_part))
+            shares = {k: [sh for g in got for sh in g[0][k]] for k in "abc"}
+            h_part = sum(g[1] for g in got) % R_MOD
+        if rank == 0:
+            opened, ninv = open_proof_shares(czk, ctx, shares, args.scheme, args.parties)
+            real_key_report = {**verify_opened_proof(czk, ctx, key, r_int, s_int, opened, h_part * R_INV % R_MOD * ninv % R_MOD),
+                               "key": "real: discrete logs from known toxic waste (tests/groth16_real_key.py)", "layout": args.layout,
+                               "shares_gathered_from_ranks": world if party_layout else 1, "seconds": round(time.perf_counter() - t_v, 2)}
 
     acc_ms, acc_n = ctx.profile_read("msm_accumulate_g1")
     acc2_ms, acc2_n = ctx.profile_read("msm_accumulate_g2")
@@ -1225,6 +1288,9 @@ def main():
         "stream_elapsed_ms_per_step": {**breakdown, "note": STREAM_ELAPSED_NOTE},
         "setup_key_s": prover.setup_key_s,
     }
+    if real_key_report is not None:
+        out["proof_verifies"] = real_key_report
+        out["data"] = "synthetic circuit, REAL proving key (known toxic waste)"
     if rank == 0 and world == 1 and not args.no_seam_report and args.scheme == "spdz":
         t = prover.seam_calls_host_memory()
         out["seam_host_memory"] = {"ms_per_proof": t * 1e3, "proofs_per_s": 1.0 / t,
@@ -1253,7 +1319,7 @@ def main():
                                              "what a prove-once caller should use"}
         if r1 is not None and not args.no_result_check:
             out["one_shot_no_tables"]["results_checked"] = bool(check_results(czk, ctx1, p1, r1)["results_checked"])
-    if rank == 0 and world == 1 and not args.no_result_check and not args.no_verify_report and not party_layout and not split_layout and not os.environ.get("CZK_BENCH_CHILD"):
+    if rank == 0 and world == 1 and not args.no_result_check and not args.no_verify_report and not party_layout and not split_layout and not os.environ.get("CZK_BENCH_CHILD") and rk is None:
         try:
             del prover
         except NameError:

@@ -94,7 +94,7 @@ def test_bench_launcher_starts_one_rank_per_gpu(gpus, layout):
 def test_multi_gpu_report_shape(gpus):
     """`bench.py --gpus N` on N > 1 GPUs (the driver's SCALE run) follows its replica line with the party / split layout children
     (bench.multi_gpu_report); --dry-run produces the report's shape on CPU: one launch per kind of child (one-GPU reference, party layout
-    over N ranks, split layout over N ranks), the rest as planned commands.  Every party child names the one-GPU run whose digest it must
+    over N ranks, the Groth16 party layout under a real key with `proof_verifies`, split layout over N ranks), the rest as planned commands.  Every party child names the one-GPU run whose digest it must
     reproduce, covers both exchange patterns and both transports, and the config is the BASELINE one whose party count is N."""
     import json
     import subprocess
@@ -113,7 +113,9 @@ def test_multi_gpu_report_shape(gpus):
         assert v["reference"] == k.split("/")[0] + "/one_gpu" and v["reference"] in rep, k
         assert f"--gpus {gpus} --layout party" in v["command"] and f"--parties {gpus}" in v["command"]
     launched = {k: v for k, v in rep.items() if v.get("dry_run") is True}
-    assert {k.split("/")[1] for k in launched} == {"one_gpu", "party", "split"}
+    assert {k.split("/")[1] for k in launched} == {"one_gpu", "party", "split", "verify"}
+    verify = {k: v for k, v in rep.items() if "/verify/" in k}
+    assert verify and all(k.startswith("groth16") and "--real-key" in v["command"] and f"--gpus {gpus} --layout party" in v["command"] for k, v in verify.items())
     for k, v in launched.items():
         want = 1 if k.endswith("/one_gpu") else gpus
         assert v["n_gpus"] == want and v["ranks_seen_by_backend"] == want, (k, v)

@@ -119,3 +119,32 @@ def test_marlin_proof_of_a_satisfied_instance_verifies(H):
     B = polyvm.GpuBackend(czk_amd, ctx, lanes, polyvm.marlin_max_degree(H), lift=(1,) * lanes)    # public data on every lane: each lane is the plain prover
     marlin_prove_and_verify(polyvm, B, lambda out: bench.verify_openings(czk_amd, ctx, B, out), H)
     ctx.close()
+
+
+@pytest.mark.parametrize("argv", [
+    ["--log-n", "12", "--parties", "2"],                                                                              # all lanes on one GPU
+    ["--gpus", "2", "--layout", "party", "--backend", "gloo", "--device", "0", "--log-n", "12", "--parties", "2"],     # one process per party, opens over torch.distributed
+    ["--gpus", "3", "--layout", "party", "--backend", "gloo", "--device", "0", "--net", "czk", "--constraints", "1000", "--parties", "3"],            # ... over czk_net (shared memory)
+    ["--gpus", "3", "--layout", "party", "--backend", "gloo", "--device", "0", "--net", "czk-ipc", "--scheme", "gsz", "--constraints", "1000", "--parties", "3"],   # GSZ, device mailboxes
+    ["--gpus", "2", "--layout", "split", "--backend", "gloo", "--device", "0", "--constraints", "1000", "--parties", "2"],                            # one proof split by base range
+])
+def test_bench_real_key_proof_verifies_in_every_layout(argv):
+    """bench.py --real-key: the timed proofs run under a real key and the last one is opened -- in the party layout from shares gathered over the process group,
+    i.e. through the reference's own one-process-per-party layout and its network opens -- and put through the verification equation (`proof_verifies`)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py")] + argv + ["--real-key", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-seam-report", "--no-other-workloads"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    run = util.run_ranks if "--gpus" in argv else subprocess.run
+    r = run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert r.returncode == 0, util.child_errors(r.stderr)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    pv = d["proof_verifies"]
+    assert pv["proof_verifies"] and pv["proof_elements_match_prover_equations"] and pv["verification_equation_holds"] and pv["qap_identity_holds"], pv
+    if "party" in argv:
+        assert pv["shares_gathered_from_ranks"] == d["n_gpus"] > 1
