@@ -1,17 +1,20 @@
-"""The reference's own acceptance criterion for the whole path: the revealed proof VERIFIES (mpc-snarks/test.zsh runs groth16 / plonk / marlin and
-asserts `verify_proof`, mpc-snarks/src/proof.rs:140-143).  The benchmark's proving key is synthetic (random points with known discrete logs), so its
-proofs cannot verify; here the key is a REAL one -- generated, as groth16/src/generator.rs:60-230 does, from toxic waste (tau, alpha, beta, gamma, delta)
-that the test knows -- handed to the prover as discrete logs (Groth16Local(key_scalars=...): the GPU builds the points).  The proof the hot path returns
-(constraint evaluation, witness map with both opens, five MSMs on every share lane, create_proof's group steps; parties' shares added up) is then checked
+"""The reference's own acceptance criterion for the whole path: the revealed proof VERIFIES (mpc-snarks/test.zsh runs groth16 / plonk / marlin and asserts
+`verify_proof`, mpc-snarks/src/proof.rs:140-143).  The benchmark inputs cannot: its Groth16 key is synthetic (random points with known discrete logs), its Plonk
+and Marlin inputs are work-shaped stand-ins.  Here the inputs are REAL and every check is plain big-integer Python on what the GPU path returns:
 
-  (1) element by element against [a] G1, [b] G2, [c] G1 for the exponents a, b, c that the Groth16 prover equations give (groth16/src/prover.rs:110-178)
-      from the plain witness, r, s and the quotient h -- points made by the CPU checker's double-and-add, compared in affine; and
-  (2) against the verification equation e(A, B) = e(alpha, beta) e(sum_i x_i gamma_abc_i, gamma) e(C, delta) (groth16/src/verifier.rs:40-62), which with
-      every discrete log known is a b = alpha beta + sum_i x_i (beta u_i + alpha v_i + w_i) + c delta in Fr -- no pairing needed.
+  Groth16  a key generated, as groth16/src/generator.rs:60-230 does, from toxic waste (tau, alpha, beta, gamma, delta) that the test knows (tests/groth16_real_key.py),
+           handed to the prover as discrete logs (Groth16Local(key_scalars=...): the GPU builds the points).  The opened proof -- constraint evaluation, witness map
+           with both opens, five MSMs on every share lane, create_proof's group steps; the parties' shares added up -- must (1) equal [a] G1, [b] G2, [c] G1 for
+           the exponents the prover equations give (groth16/src/prover.rs:110-178) from the plain witness, r, s and the quotient h (points by the CPU checker's
+           double-and-add, compared in affine), and (2) satisfy e(A, B) = e(alpha, beta) e(sum_i x_i gamma_abc_i, gamma) e(C, delta) (groth16/src/verifier.rs:40-62),
+           which with every discrete log known is a b = alpha beta + sum_i x_i (beta u_i + alpha v_i + w_i) + c delta in Fr -- no pairing needed.  (2) holds only
+           if h is the true quotient (A B - C) / Z over the reference's domain: a wrong root of unity, coset, 1/D or vanishing-polynomial factor anywhere in the witness
+           map breaks it, whatever the checker's restatement says.  Also through bench.py --real-key in every layout (one process per party, split by base range).
+  Plonk    a satisfied circuit (tests/polyiop_real.py), the reference's Verifier::verify (mpc-plonk/src/lib.rs:451-590): every KZG opening and the four identities.
+  Marlin   a real index of a satisfied instance, the AHP verifier's decision (marlin/src/ahp/mod.rs:115-260): both sumcheck combinations, every KZG opening.
 
-(2) holds only if h is the true quotient (A B - C) / Z of the QAP over the reference's domain (omega = LARGE^3 squared down, fields/mod.rs:360-367): a wrong
-root of unity, coset, 1/D or vanishing-polynomial factor anywhere in the witness map breaks it, whatever the checker's restatement says.  Plain big-integer
-Python; nothing here comes from the library except the proof."""
+The prover sequences of provers.py / polyvm.py are shared by the checker-backed and the GPU-backed runs of the parity tests, so a slip in them is invisible there;
+these tests found two (1 - s(X) with the constant on every coefficient; a and b of Marlin's third round one coefficient short)."""
 import numpy as np
 import pytest
 
