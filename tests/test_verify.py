@@ -151,3 +151,45 @@ def test_bench_real_key_proof_verifies_in_every_layout(argv):
     assert pv["proof_verifies"] and pv["proof_elements_match_prover_equations"] and pv["verification_equation_holds"] and pv["qap_identity_holds"], pv
     if "party" in argv:
         assert pv["shares_gathered_from_ranks"] == d["n_gpus"] > 1
+
+
+@pytest.mark.parametrize("n_constraints,parties", [(10, 2), (1000, 3), (1 << 16, 2)])
+def test_compiled_host_proof_verifies_under_a_real_key(orc, tmp_path, n_constraints, parties):
+    """The torch-free, Python-free C++ host (tools/host_demo.cpp bench over tools/groth16_host.hpp: what the Rust shim's resident path does, compiled) given a
+    REAL key as discrete logs (--key-file): its per-lane shares of Proof{a, b, c} for the public r, s it uses are added up and verified as above."""
+    import subprocess
+    import czk_amd as czk
+    from test_device_handles import _host_demo, _read_dump
+    N = n_constraints
+    key = real_key(N, limbs_to_ints(rand_fr_canonical(0x7A11 + N, 5)))
+    ks = key_scalars(key)
+    kf, dump = str(tmp_path / "key.bin"), str(tmp_path / "g16.bin")
+    with open(kf, "wb") as f:
+        f.write(np.array([N, key["D"]], dtype=np.uint64).tobytes())
+        for name in ("h", "l", "a", "b_g1", "pk_g1", "pk_g2"):
+            f.write(np.ascontiguousarray(ks[name], dtype=np.uint64).tobytes())
+    out = subprocess.run([_host_demo(), "bench", "--constraints", str(N), "--parties", str(parties), "--steps", "2", "--warmup", "1", "--key-file", kf, "--dump", dump],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and '"pipelined_proofs_equal": true' in out.stdout and '"mac_check_failures": 0' in out.stdout, out.stdout + out.stderr
+    N2, D, L, h_lanes, pts = _read_dump(dump)
+    assert (N2, D, L) == (N, key["D"], 2 * parties)
+    rs = rand_fr_canonical(0xC0FFEE + 99, 2)                       # the r, s host_demo's --dump proves with
+    r, s = limbs_to_ints(rs)
+    ctx = czk.Context(0)
+    opened = {}
+    for k, g in (("a", 1), ("b", 2), ("c", 1)):
+        jw = 18 if g == 1 else 36
+        acc = np.zeros(jw, dtype=np.uint64)                         # the identity (z == 0)
+        for j in range(parties):                                   # the parties' sh lanes: lane 2 j
+            aff, inf = pts["proofs"][2 * j][k]
+            acc = ctx.jac_add_mixed(g, acc, aff, bool(inf))
+        opened[k] = ctx.jac_to_affine(g, acc)
+    ctx.close()
+    h_acc = sum(dot_mod_r(h_lanes[2 * j][:D - 1], ks["h"]) for j in range(parties)) * R_INV % R_MOD
+    w0 = limbs_to_ints(rand_fr_canonical(0xC0FFEE, 1))[0]
+    a_exp, b_exp, c_exp, verifies, qap = expected_exponents(key, w0, r, s, h_acc)
+    for k, g, e in (("a", 1, a_exp), ("b", 2, b_exp), ("c", 1, c_exp)):
+        want, winf = orc.jac_to_affine(g, orc.scalar_mul(g, orc.generator_affine(g), 0, ints_to_limbs([e], 4)[0]))
+        got, ginf = opened[k]
+        assert not ginf[0] and not winf and np.array_equal(np.ravel(got[0]), np.ravel(want)), (k, N, parties)
+    assert verifies and qap

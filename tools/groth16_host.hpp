@@ -154,6 +154,13 @@ struct ProofShare {   // one share lane's part of Proof{a, b, c} (groth16/src/da
     czk::G1Projective c;
 };
 
+// Discrete logs of a proving key to use in place of the synthetic one (canonical limbs): the queries from index 1 on (h: D - 1, l: N, a / b: N + 1; b serves
+// b_g1 and b_g2), [alpha, beta, delta, a_query[0]] in G1 and [beta, delta] in G2 -- how tests/test_verify.py hands the compiled host a REAL key generated from known
+// toxic waste (groth16/src/generator.rs:60-230), so that its proof can be put through the verification equation.
+struct KeyScalars {
+    std::vector<Fr> h, l, a, b, pk_g1, pk_g2;
+};
+
 class Groth16Host {
   public:
     static constexpr uint64_t BASE_SEED = 0xBA5E5;
@@ -166,7 +173,7 @@ class Groth16Host {
     // party and a czk::Net this is the reference's own layout -- one process per party (mpc-net/src/multi.rs:15-23) -- and the two opens
     // of the witness map run SpdzFieldShare::batch_open's two broadcast rounds through the communicator, on lanes that stay in HBM.
     Groth16Host(const czk::Context& c, size_t n_constraints, size_t parties, uint64_t seed = 0xC0FFEE, bool no_tables = false,
-                std::vector<size_t> local_parties = {}, const czk::Net* net = nullptr, bool commit_opens = false)
+                std::vector<size_t> local_parties = {}, const czk::Net* net = nullptr, bool commit_opens = false, const KeyScalars* key = nullptr)
         : ctx(c), N(n_constraints), P(parties), net_(net), commit_opens_(commit_opens) {
         auto t0 = std::chrono::steady_clock::now();
         if (local_parties.empty())
@@ -180,15 +187,16 @@ class Groth16Host {
         D = (size_t)1 << log_d;
         domain_.emplace(*czk::Radix2EvaluationDomain::create(ctx, N + 2));
         // ---- synthetic proving key: P_i = [k_i] G; b_query[1] has no B entry -> infinity (groth16/src/generator.rs:156-163) ----
-        h_query_ = mk_bases<CZK_G1>(D - 1, 1, false, no_tables);
-        l_query_ = mk_bases<CZK_G1>(N, 2, false, no_tables);
-        a_query_ = mk_bases<CZK_G1>(N + 1, 3, false, no_tables);
-        b_g1_query_ = mk_bases<CZK_G1>(N + 1, 4, true, no_tables);
-        b_g2_query_ = mk_bases<CZK_G2>(N + 1, 5, true, no_tables);
+        h_query_ = mk_bases<CZK_G1>(D - 1, 1, false, no_tables, key ? &key->h : nullptr);
+        l_query_ = mk_bases<CZK_G1>(N, 2, false, no_tables, key ? &key->l : nullptr);
+        a_query_ = mk_bases<CZK_G1>(N + 1, 3, false, no_tables, key ? &key->a : nullptr);
+        b_g1_query_ = mk_bases<CZK_G1>(N + 1, 4, true, no_tables, key ? &key->b : nullptr);
+        b_g2_query_ = mk_bases<CZK_G2>(N + 1, 5, true, no_tables, key ? &key->b : nullptr);
         // the rest of the key (groth16/src/data_structures.rs:132-149), synthetic like the queries: G1 [vk.alpha_g1, beta_g1, delta_g1, a_query[0]],
         // G2 [vk.beta_g2, vk.delta_g2]; b_g1_query[0] and b_g2_query[0] are infinity in the real key (the constant-one variable has no B entry)
         {
-            std::vector<Fr> k1 = rand_fr_canonical(BASE_SEED + 6, 4), k2 = rand_fr_canonical(BASE_SEED + 7, 2);
+            std::vector<Fr> k1 = key ? key->pk_g1 : rand_fr_canonical(BASE_SEED + 6, 4), k2 = key ? key->pk_g2 : rand_fr_canonical(BASE_SEED + 7, 2);
+            if (k1.size() != 4 || k2.size() != 2) throw czk::Panic(CZK_ERR_ARG, "key scalars: pk_g1 holds 4 and pk_g2 2 scalars");
             pk_g1_.resize(4 * 12);
             pk_g2_.resize(2 * 24);
             ctx.check(czk_fixed_base_points(ctx.raw(), CZK_G1, k1[0].l, 4, pk_g1_.data(), CZK_MEM_HOST));
@@ -335,8 +343,9 @@ class Groth16Host {
     std::unique_ptr<czk::DeviceLanes> lanes(size_t len) { return std::unique_ptr<czk::DeviceLanes>(new czk::DeviceLanes(ctx, L, len)); }
 
     template <int GROUP>
-    std::unique_ptr<czk::Bases<GROUP>> mk_bases(size_t n, uint64_t sd, bool inf_first, bool no_tables) {
-        std::vector<Fr> k = rand_fr_canonical(BASE_SEED + sd, n);
+    std::unique_ptr<czk::Bases<GROUP>> mk_bases(size_t n, uint64_t sd, bool inf_first, bool no_tables, const std::vector<Fr>* given = nullptr) {
+        if (given && given->size() != n) throw czk::Panic(CZK_ERR_ARG, "key scalars: a query has the wrong length");
+        std::vector<Fr> k = given ? *given : rand_fr_canonical(BASE_SEED + sd, n);
         std::vector<uint64_t> pts((GROUP == CZK_G1 ? 12 : 24) * n);
         ctx.check(czk_fixed_base_points(ctx.raw(), GROUP, k[0].l, n, pts.data(), CZK_MEM_HOST));
         std::vector<uint8_t> inf(n, 0);

@@ -98,9 +98,11 @@ static int bench(const Context& ctx, int argc, char** argv) {
     size_t n = (size_t)1 << 20, parties = 2, steps = 20, warmup = 2;
     bool no_tables = false;
     const char* dump = nullptr;
+    const char* key_file = nullptr;
     for (int i = 2; i < argc; i++) {
         auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
-        if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
+        if (!strcmp(argv[i], "--key-file")) key_file = val();
+        else if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
         else if (!strcmp(argv[i], "--constraints")) n = (size_t)atoll(val());
         else if (!strcmp(argv[i], "--parties")) parties = (size_t)atoi(val());
         else if (!strcmp(argv[i], "--steps")) steps = (size_t)atoi(val());
@@ -112,7 +114,23 @@ static int bench(const Context& ctx, int argc, char** argv) {
     if (n < 2 || parties < 2 || steps < 1) { printf("bench: need --constraints >= 2, --parties >= 2, --steps >= 1\n"); return 2; }
     using clk = std::chrono::steady_clock;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-    g16::Groth16Host prover(ctx, n, parties, 0xC0FFEE, no_tables);
+    // --key-file: the discrete logs of a REAL proving key (tests/test_verify.py): u64 header [N, D], then h (D - 1), l (N), a (N + 1), b (N + 1), pk_g1 (4),
+    // pk_g2 (2) as canonical 4 x u64 scalars
+    g16::KeyScalars key;
+    if (key_file) {
+        FILE* f = fopen(key_file, "rb");
+        REQUIRE(f != nullptr);
+        uint64_t hdr[2];
+        REQUIRE(fread(hdr, 8, 2, f) == 2 && hdr[0] == n);
+        const size_t Dk = (size_t)hdr[1];
+        auto rd = [&](std::vector<g16::Fr>& v, size_t cnt) {
+            v.resize(cnt);
+            REQUIRE(fread(v.data(), 32, cnt, f) == cnt);
+        };
+        rd(key.h, Dk - 1), rd(key.l, n), rd(key.a, n + 1), rd(key.b, n + 1), rd(key.pk_g1, 4), rd(key.pk_g2, 2);
+        fclose(f);
+    }
+    g16::Groth16Host prover(ctx, n, parties, 0xC0FFEE, no_tables, {}, nullptr, false, key_file ? &key : nullptr);
     auto t0 = clk::now();
     prover.step();                                            // first proof: also builds the NTT tables and sizes the workspaces
     const double first_ms = secs(t0, clk::now()) * 1e3;
