@@ -706,6 +706,9 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         lift = None                                                        # public addends on every lane
         max_deg = polyvm.plonk_max_degree(n)
         make_inputs, prove = (lambda B: polyvm.plonk_inputs(B, n)), polyvm.plonk_prove
+        if getattr(args, "real_instance", False):
+            from polyiop_real import satisfied_plonk_inputs
+            make_inputs = lambda B: satisfied_plonk_inputs(B, polyvm, n, 0x51A7 + n)[0]      # noqa: E731
         scheme, what = "GSZ", f"mpc-plonk Prover::prove, {n} gates (wire domain 3 x {size_txt}, mixed radix)"
     else:
         lanes = per_party if party else 2 * args.parties
@@ -833,7 +836,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         "config": {"workload": f"{what}; {where}; synthetic circuit / index and SRS, fixed Fiat-Shamir challenges, commitments / evaluations settled at "
                                "every point where the reference's transcript draws a challenge (collaborative-zksnark_amd/polyvm.py)",
                    "constraints": n, "parties": args.parties, "share_lanes": lanes, "layout": args.layout, "results_sha256": digest,
-                   "proofs_in_flight": inflight,
+                   "proofs_in_flight": inflight, "inputs": "a satisfied circuit (tests/polyiop_real.py)" if getattr(args, "real_instance", False) else "work-shaped stand-ins",
                    "ntt_lanes_per_proof": ntt_count / max(1, args.steps), "msms_per_proof": msm_count / max(1, args.steps),
                    "msm_point_lanes_per_proof": pts},
         "roofline": {"bound": "hbm", "kernel": ("k_accumulate_te (G1 bucket accumulation, twisted Edwards extended coordinates, unsaturated limbs)" if te else
@@ -958,6 +961,8 @@ def main():
     ap.add_argument("--real-key", action="store_true", help="groth16, any layout: prove under a REAL key (discrete logs from known toxic waste, tests/groth16_real_key.py) and put the "
                                                            "opened proof through the verification equation (`proof_verifies`; in the party layout the parties' shares are gathered on rank 0) "
                                                            "instead of the discrete-log check of the synthetic key")
+    ap.add_argument("--real-instance", action="store_true", help="plonk: time the prover on a SATISFIED circuit (tests/polyiop_real.py) instead of random polynomials -- the selector and "
+                                                                "wiring polynomials are then structured, the witness polynomial is not; the timed proofs themselves go through the verifier")
     ap.add_argument("--no-verify-report", action="store_true", help="skip `proof_verifies`: one proof of this configuration under a real key against the Groth16 verification equation")
     ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
                     help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "
