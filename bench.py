@@ -716,6 +716,11 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         lift = king if party else tuple([1, 1] + [0] * (2 * args.parties - 2))
         max_deg = polyvm.marlin_max_degree(n)
         make_inputs, prove = (lambda B: polyvm.marlin_inputs(B, n)), polyvm.marlin_prove
+        if getattr(args, "real_instance", False) and not party:
+            # a real index of a satisfied instance; public data lifted onto EVERY lane, so that each lane is the plain prover and the timed proofs verify
+            from polyiop_real import marlin_real_inputs
+            lift = tuple([1] * lanes)
+            make_inputs = lambda B: marlin_real_inputs(B, polyvm, polyvm.next_pow2(n), 0x3A21 + polyvm.next_pow2(n))      # noqa: E731
         scheme, what = "SPDZ", f"Marlin AHP rounds + commitments + batched openings, {n} constraints"
     t0 = time.time()
     polyvm.GpuBackend.evaluate_by_division = bool(getattr(args, "eval_by_division", False))
@@ -800,6 +805,12 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
     per_rank = per_rank_report(parallel, dt, args.steps, dev_index)
     dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
     checked = {"results_checked": False} if args.no_result_check else verify_openings(czk, ctx, B, out)
+    if getattr(args, "real_instance", False) and not party and not args.no_result_check:
+        # the timed proofs themselves through the reference verifiers' equations (tests/polyiop_real.py)
+        from polyiop_real import marlin_verify
+        if not plonk:
+            marlin_verify(polyvm, out)
+            checked["timed_proof_verifies"] = True
     for o in outs[1:]:                                  # the other in-flight provers run the same deterministic inputs
         assert _polyiop_party_digests(o, lanes, 1, only=0) == _polyiop_party_digests(out, lanes, 1, only=0), "in-flight provers disagree"
     if party:
@@ -836,7 +847,7 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         "config": {"workload": f"{what}; {where}; synthetic circuit / index and SRS, fixed Fiat-Shamir challenges, commitments / evaluations settled at "
                                "every point where the reference's transcript draws a challenge (collaborative-zksnark_amd/polyvm.py)",
                    "constraints": n, "parties": args.parties, "share_lanes": lanes, "layout": args.layout, "results_sha256": digest,
-                   "proofs_in_flight": inflight, "inputs": "a satisfied circuit (tests/polyiop_real.py)" if getattr(args, "real_instance", False) else "work-shaped stand-ins",
+                   "proofs_in_flight": inflight, "inputs": ("a satisfied circuit" if plonk else "a real index of a satisfied instance, public data on every lane") + " (tests/polyiop_real.py)" if getattr(args, "real_instance", False) else "work-shaped stand-ins",
                    "ntt_lanes_per_proof": ntt_count / max(1, args.steps), "msms_per_proof": msm_count / max(1, args.steps),
                    "msm_point_lanes_per_proof": pts},
         "roofline": {"bound": "hbm", "kernel": ("k_accumulate_te (G1 bucket accumulation, twisted Edwards extended coordinates, unsaturated limbs)" if te else
@@ -961,8 +972,8 @@ def main():
     ap.add_argument("--real-key", action="store_true", help="groth16, any layout: prove under a REAL key (discrete logs from known toxic waste, tests/groth16_real_key.py) and put the "
                                                            "opened proof through the verification equation (`proof_verifies`; in the party layout the parties' shares are gathered on rank 0) "
                                                            "instead of the discrete-log check of the synthetic key")
-    ap.add_argument("--real-instance", action="store_true", help="plonk: time the prover on a SATISFIED circuit (tests/polyiop_real.py) instead of random polynomials -- the selector and "
-                                                                "wiring polynomials are then structured, the witness polynomial is not; the timed proofs themselves go through the verifier")
+    ap.add_argument("--real-instance", action="store_true", help="plonk / marlin: time the prover on a SATISFIED circuit / a real index of a satisfied instance (tests/polyiop_real.py) instead of "
+                                                                "the work-shaped stand-ins; marlin: the timed proofs themselves go through the AHP verifier's decision")
     ap.add_argument("--no-verify-report", action="store_true", help="skip `proof_verifies`: one proof of this configuration under a real key against the Groth16 verification equation")
     ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
                     help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "

@@ -862,29 +862,6 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
            "inner_sumcheck": [(challenge("marlin.lc." + m + "_val"), m + "_val") for m in "abc"] + [(challenge("marlin.lc.h_2"), "h_2")]}
     for m in "abc":
         lcs[m + "_denom"] = [(R_MOD - alpha, m + "_row"), (R_MOD - beta, m + "_col"), (1, m + "_row_col")]
-    if inp.get("real_lcs"):
-        # the coefficients AHPForR1CS::construct_linear_combinations (ahp/mod.rs:115-260) really uses: products of challenges and of evaluations the prover
-        # publicizes first (:155-157, :228-231).  Blocking reads of lane 0 (every lane is the plain prover when the caller lifts public data onto all of them);
-        # the LCTerm::One constants go to out["lc_consts"]: they do not enter the opened polynomials, the verifier moves them to the evaluation side.
-        ev = lambda a, x: unmont(B.div_linear(a, x)[1][0])     # noqa: E731
-        inv = lambda v: pow(v % R_MOD, -1, R_MOD)                # noqa: E731
-        r_ab = (vanishing(H, alpha) - vanishing(H, beta)) * inv(alpha - beta) % R_MOD          # eval_unnormalized_bivariate_lagrange_poly
-        vh_a, vh_b, vx_b = vanishing(H, alpha), vanishing(H, beta), vanishing(X, beta)
-        z_b_beta, t_beta, g_1_beta, x_beta = ev(z_b, beta), ev(t_poly, beta), ev(g_1, beta), ev(x_poly, beta)
-        lcs["outer_sumcheck"] = [(1, "mask_poly"), (r_ab * (eta_a + eta_c * z_b_beta) % R_MOD, "z_a"), (-t_beta * vx_b % R_MOD, "w"), (-vh_b % R_MOD, "h_1")]
-        consts = {"outer_sumcheck": (r_ab * eta_b % R_MOD * z_b_beta - t_beta * x_beta - beta * g_1_beta) % R_MOD}
-        den = {m: (beta * alpha - alpha * ev(row[m], gamma) - beta * ev(col[m], gamma) + ev(row_col[m], gamma)) % R_MOD for m in "abc"}
-        g_2_gamma = ev(g_2, gamma)
-        k_inv = inv(K)
-        lcs["inner_sumcheck"] = [(eta_a * den["b"] % R_MOD * den["c"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "a_val"),
-                                 (eta_b * den["a"] % R_MOD * den["c"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "b_val"),
-                                 (eta_c * den["b"] % R_MOD * den["a"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "c_val"),
-                                 (-vanishing(K, gamma) % R_MOD, "h_2")]
-        consts["inner_sumcheck"] = -(den["a"] * den["b"] % R_MOD * den["c"] % R_MOD) * (gamma * g_2_gamma + t_beta * k_inv) % R_MOD
-        for m in "abc":
-            consts[m + "_denom"] = beta * alpha % R_MOD
-        out["lc_consts"] = consts
-        out["lcs"] = {k: list(v) for k, v in lcs.items()}
     point = {"beta": beta, "gamma": gamma}
     query = {"beta": ["g_1", "outer_sumcheck", "t", "z_b"], "gamma": ["a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"]}   # verifier_query_set (ahp/verifier.rs:143-146, 207-211), labels in BTreeSet order
 
@@ -900,6 +877,37 @@ def marlin_prove(B: Backend, inp: dict) -> dict:
     for label in sorted(lcs):
         lc_eval(label, "beta" if label in query["beta"] else "gamma")
     B.transcript_point()                                                           # fs_rng.absorb(&evaluations) (:299)
+    if inp.get("real_lcs"):
+        # The coefficients AHPForR1CS::construct_linear_combinations (ahp/mod.rs:115-260) really uses: products of challenges and of evaluations the prover has
+        # just publicized (:155-157, :228-231) -- the first entries of the two evaluation lists, settled by the transcript point above like everything else, so
+        # the real path has the benchmark's synchronisation points and no others.  Lane 0 (every lane is the plain prover when the caller lifts public data onto
+        # all of them).  The LCTerm::One constants go to out["lc_consts"]: they do not enter the opened polynomials, the verifier moves them to the evaluation side.
+        val = lambda pend: unmont(resolved(pend)[0])            # noqa: E731
+        inv = lambda v: pow(v % R_MOD, -1, R_MOD)                # noqa: E731
+        eb, eg = out["evals_beta"], out["evals_gamma"]
+        z_b_beta, t_beta, g_1_beta = val(eb[0]), val(eb[1]), val(eb[2])
+        den = {}
+        for i, m in enumerate("abc"):                           # a_denom = beta alpha - alpha row - beta col + row_col at gamma (:196-226)
+            r_g, c_g, rc_g = (val(eg[3 * i + j]) for j in range(3))
+            den[m] = (beta * alpha - alpha * r_g - beta * c_g + rc_g) % R_MOD
+        g_2_gamma = val(eg[9])
+        wx, x_beta, acc = B.root_of_unity(X), 0, 1             # x(beta) = sum_j L_j(beta) x_j over the input domain (:158-163)
+        for xj in inp["x_ints"]:
+            x_beta = (x_beta + vanishing(X, beta) * acc % R_MOD * inv(X * (beta - acc)) % R_MOD * xj) % R_MOD
+            acc = acc * wx % R_MOD
+        r_ab = (vanishing(H, alpha) - vanishing(H, beta)) * inv(alpha - beta) % R_MOD          # eval_unnormalized_bivariate_lagrange_poly
+        vh_a, vh_b, vx_b = vanishing(H, alpha), vanishing(H, beta), vanishing(X, beta)
+        lcs["outer_sumcheck"] = [(1, "mask_poly"), (r_ab * (eta_a + eta_c * z_b_beta) % R_MOD, "z_a"), (-t_beta * vx_b % R_MOD, "w"), (-vh_b % R_MOD, "h_1")]
+        consts = {"outer_sumcheck": (r_ab * eta_b % R_MOD * z_b_beta - t_beta * x_beta - beta * g_1_beta) % R_MOD}
+        lcs["inner_sumcheck"] = [(eta_a * den["b"] % R_MOD * den["c"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "a_val"),
+                                 (eta_b * den["a"] % R_MOD * den["c"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "b_val"),
+                                 (eta_c * den["b"] % R_MOD * den["a"] % R_MOD * vh_a % R_MOD * vh_b % R_MOD, "c_val"),
+                                 (-vanishing(K, gamma) % R_MOD, "h_2")]
+        consts["inner_sumcheck"] = -(den["a"] * den["b"] % R_MOD * den["c"] % R_MOD) * (gamma * g_2_gamma + t_beta * inv(K)) % R_MOD
+        for m in "abc":
+            consts[m + "_denom"] = beta * alpha % R_MOD
+        out["lc_consts"] = consts
+        out["lcs"] = {k: list(v) for k, v in lcs.items()}
     ch = challenge("marlin.opening_challenge")
     # PC::open_combinations (poly-commit/src/marlin/mod.rs:213-300): one polynomial per combination ...
     lc_poly = {}

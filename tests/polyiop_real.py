@@ -159,6 +159,7 @@ def marlin_real_inputs(B, polyvm, H: int, seed: int):
     B.transcript_point()
     inp["index_cmts"] = polyvm.resolved(cm)
     inp["x"] = pub([1, out_v])
+    inp["x_ints"] = [1, out_v]
     w_full = [z[k // ratio] if k % ratio == 0 else w[k - k // ratio - 1] for k in range(H)]
     assert all(w_full[reindex(i)] == z[i] for i in range(H))
     inp["w"] = polyvm.shared_copy(B, pub(w_full))
