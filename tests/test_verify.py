@@ -193,3 +193,29 @@ def test_compiled_host_proof_verifies_under_a_real_key(orc, tmp_path, n_constrai
         got, ginf = opened[k]
         assert not ginf[0] and not winf and np.array_equal(np.ravel(got[0]), np.ravel(want)), (k, N, parties)
     assert verifies and qap
+
+
+def test_verifiers_reject_unsatisfied_instances():
+    """negative controls: the same verifier code on inputs that are NOT satisfied -- the benchmark's random Plonk polynomials; a Marlin instance whose z_b
+    has one wrong entry -- must fail (the identities are checks, not tautologies of the helpers)."""
+    import czk_amd
+    from czk_amd import polyvm
+    import bench
+    import polyiop_real
+    ctx = polyvm.shared_stream_context(czk_amd)
+    B = polyvm.GpuBackend(czk_amd, ctx, 2, polyvm.plonk_max_degree(16))
+    out = polyvm.plonk_prove(B, polyvm.plonk_inputs(B, 16))
+    assert bench.verify_openings(czk_amd, ctx, B, out)["results_checked"]           # the openings are honest openings of the committed polynomials ...
+    with pytest.raises(AssertionError):                                             # ... of a circuit that is not satisfied
+        polyiop_real.plonk_verify(polyvm, out, [0, polyvm.unmont(out["pub_p_open"]["value"][0])], B.root_of_unity(48), 16)
+    ctx.close()
+    ctx = polyvm.shared_stream_context(czk_amd)
+    B = polyvm.GpuBackend(czk_amd, ctx, 2, polyvm.marlin_max_degree(16), lift=(1, 1))
+    inp = polyiop_real.marlin_real_inputs(B, polyvm, 16, 0x3A21)
+    zb = B.download(inp["z_b"]).copy()
+    zb[:, 3, 0] ^= 1                                                                # B z is wrong in one row
+    inp["z_b"] = B.upload(zb)
+    out = polyvm.marlin_prove(B, inp)
+    with pytest.raises(AssertionError, match="outer sumcheck"):
+        polyiop_real.marlin_verify(polyvm, out)
+    ctx.close()
