@@ -96,6 +96,84 @@ def busy_union_ms(ctxs, names) -> float:
     return float(busy + cur1 - cur0)
 
 
+class PowerSampler:
+    """Board power of one GPU over a timed region: a thread reads the amdgpu hwmon file (microwatts; a file read, ~20 us) every 10 ms.  Both dominant
+    kernels run at the board's power limit, so proofs per joule is the axis that tells whether a change traded clock for
+    instructions.  Falls back to polling `rocm-smi --showpower` (a few samples per second) where sysfs has no power file; report() returns None
+    fields when neither works.  Reporting only: never raises."""
+
+    def __init__(self, device: int):
+        import glob
+        import threading
+        self.samples, self.source, self._stop, self._thread = [], None, threading.Event(), None
+        try:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"), key=lambda f: int(f.split("/card")[1].split("/")[0]))
+            cards = [c for c in cards if any(os.path.exists(os.path.join(c, f)) for f in ("power1_average", "power1_input"))]
+            pick = None
+            try:                                    # the card whose PCI address is this device's
+                import torch
+                pr = torch.cuda.get_device_properties(device)
+                want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+                for c in cards:
+                    if want in os.path.realpath(os.path.join(c, "..", "..")):
+                        pick = c
+            except Exception:      # noqa: BLE001
+                pick = None
+            if pick is None and cards:
+                pick = cards[min(device, len(cards) - 1)]
+            if pick is not None:
+                self._file = next(os.path.join(pick, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(pick, f)))
+                float(open(self._file).read())
+                self.source = "sysfs " + self._file
+        except Exception:      # noqa: BLE001
+            self.source = None
+        if self.source is None:
+            import shutil
+            if shutil.which("rocm-smi"):
+                self.source = "rocm-smi --showpower"
+        self._device = device
+
+    def _read(self):
+        if self.source and self.source.startswith("sysfs"):
+            return float(open(self._file).read()) / 1e6
+        import re
+        out = subprocess.run(["rocm-smi", "-d", str(self._device), "--showpower"], capture_output=True, text=True, timeout=10).stdout
+        m = re.search(r"Power \(W\): ([0-9.]+)", out)
+        return float(m.group(1)) if m else None
+
+    def _loop(self):
+        period = 0.01 if self.source.startswith("sysfs") else 0.05
+        while not self._stop.is_set():
+            try:
+                w = self._read()
+                if w is not None:
+                    self.samples.append(w)
+            except Exception:      # noqa: BLE001
+                pass
+            self._stop.wait(period)
+
+    def start(self):
+        if self.source is None:
+            return self
+        import threading
+        self._thread = threading.Thread(target=self._loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=15)
+        return self
+
+    def report(self, proofs: float, seconds: float) -> dict:
+        if not self.samples:
+            return {"power_w_avg": None, "proofs_per_kJ": None, "power_source": self.source, "power_samples": 0}
+        avg = float(sum(self.samples) / len(self.samples))
+        return {"power_w_avg": avg, "power_w_max": float(max(self.samples)), "proofs_per_kJ": proofs / (avg * seconds / 1e3) if avg > 0 and seconds > 0 else None,
+                "joules_per_proof": avg * seconds / proofs if proofs else None, "power_source": self.source, "power_samples": len(self.samples)}
+
+
 def csrc_digest() -> str:
     """SHA-256 over the product's kernel sources (csrc/*.hip, *.h, *.inc; not csrc/lab/) in name order: stored with a PMC profile
     (tools/pmc_summary.py) and recomputed here, so that a bench line can say whether the kernels it ran are the ones the counters were
@@ -109,7 +187,15 @@ def csrc_digest() -> str:
     return h.hexdigest()[:16]
 
 
-OTHER_WORKLOADS = (   # (key, bench.py arguments, HBM the run needs in GB) -- BASELINE configs[2], [3] and the configs[4] size on ONE GPU
+# configs[0] is the reference's own CPU-runnable case: `./scripts/bench.zsh groth16 spdz 10 2` = 10 squarings (mpc-snarks/scripts/bench.zsh:23,55 passes
+# --computation-size 10 -> 10 constraints, FFT domain 16: mpc-snarks/src/proof.rs:476-477), and BASELINE.json words it as 2^10: both are reported.  Their metric is the
+# reference's own -- ONE proof's wall time (the "timed section", proof.rs:130-139) -- so `latency_ms_single_proof` is the figure; the reference's published times
+# beside them are from mpc-snarks/analysis/data/mpc.csv (rows N,groth16,spdz,1,2), other hardware.
+CONFIG0_REFERENCE_S = {"groth16_spdz2_10": {"constraints_8": 0.036529, "constraints_16": 0.06793, "source": "mpc-snarks/analysis/data/mpc.csv rows 8 / 16,groth16,spdz,1,2 (N = 10 lies between)"},
+                       "groth16_spdz2_2e10": {"constraints_1024": 0.693, "source": "mpc-snarks/analysis/data/mpc.csv row 1024,groth16,spdz,1,2 (BASELINE.md section 1)"}}
+OTHER_WORKLOADS = (   # (key, bench.py arguments, HBM the run needs in GB) -- BASELINE configs[0], [2], [3] and the configs[4] size on ONE GPU
+    ("groth16_spdz2_10", ["--workload", "groth16", "--parties", "2", "--constraints", "10", "--steps", "20", "--warmup", "3", "--no-seam-report", "--verify-report"], 2),
+    ("groth16_spdz2_2e10", ["--workload", "groth16", "--parties", "2", "--log-n", "10", "--steps", "20", "--warmup", "3", "--no-seam-report", "--verify-report"], 2),
     ("plonk_gsz3_2e18", ["--workload", "plonk", "--parties", "3", "--log-n", "18", "--steps", "12", "--warmup", "4"], 20),
     ("marlin_spdz2_2e20", ["--workload", "marlin", "--parties", "2", "--log-n", "20", "--steps", "12", "--warmup", "4"], 40),
     ("groth16_spdz2_2e22", ["--workload", "groth16", "--parties", "2", "--log-n", "22", "--steps", "4", "--warmup", "2", "--no-seam-report"], 70),
@@ -139,11 +225,17 @@ def other_workloads_report(device: int) -> dict:
             out[key] = {"proofs_per_s": j["value"], "ms_per_proof": j["ms_per_step"], "results_checked": bool(j.get("results_checked")),
                         "accumulate_busy_frac": j.get("accumulate_busy_frac"), "steps": j["steps"], "metric": j["metric"],
                         "proofs_in_flight": j["config"].get("proofs_in_flight", "pipelined"), "wall_s": time.time() - t0,
+                        "power_w_avg": j.get("power_w_avg"), "proofs_per_kJ": j.get("proofs_per_kJ"),
                         # the same roofline block as the headline, for this workload's dominant kernel (HIP-event timed inside the child)
                         "roofline": {k: (j.get("roofline") or {}).get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches")},
                         "command": "python bench.py " + " ".join(argv)}
             if j.get("proof_verifies") is not None:
                 out[key]["proof_verifies"] = j["proof_verifies"]
+            if key in CONFIG0_REFERENCE_S:
+                # the reference's metric for this config: one proof's wall time, inputs resident (first_proof_ms also builds the NTT tables / sizes the workspaces)
+                out[key].update({"latency_ms_single_proof": j.get("latency_ms_single_proof"), "first_proof_ms": j.get("first_proof_ms"), "one_shot_s": j.get("one_shot_s"),
+                                 "constraints": j["config"].get("constraints"), "domain": j["config"].get("domain"), "results_sha256": j["config"].get("results_sha256"),
+                                 "reference_published_s": CONFIG0_REFERENCE_S[key]})
             if argv[1] in ("plonk", "marlin"):
                 # the same workload from the compiled host (tools/polyvm_host.hpp over include/czk.h: no torch, no Python, one device arena)
                 try:
@@ -176,7 +268,7 @@ def relaunch_under_torchrun(n: int, argv: list[str]) -> int:
     return subprocess.call(cmd, env=dict(os.environ, CZK_BENCH_CHILD="1"))
 
 
-def per_rank_report(parallel, dt_local: float, steps: int, device) -> list:
+def per_rank_report(parallel, dt_local: float, steps: int, device, power: dict | None = None) -> list:
     """[{rank, ms_per_step, sclk_mhz_by_card}] of every rank (before the max over ranks): shows a straggler GPU or a clock that power management
     holds lower on one device.  The clocks are a single sample right after the timed region (None when sysfs does not expose them)."""
     import torch
@@ -193,6 +285,8 @@ def per_rank_report(parallel, dt_local: float, steps: int, device) -> list:
     except Exception:      # noqa: BLE001 -- reporting only
         clk = None
     mine = {"rank": rank, "ms_per_step": dt_local / max(1, steps) * 1e3, "sclk_mhz_by_card": clk}
+    if power:
+        mine.update({k: power.get(k) for k in ("power_w_avg", "proofs_per_kJ")})
     if world == 1 or not torch.distributed.is_initialized():
         return [mine]
     got = [None] * world
@@ -794,15 +888,19 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         c.profile_reset()
         c.profile_enable(True)
     share = [args.steps // inflight + (1 if i < args.steps % inflight else 0) for i in range(inflight)]
+    power = PowerSampler(dev_index)
     barrier()
+    power.start()
     t0 = time.perf_counter()
     outs = run(share)
     barrier()
     dt = time.perf_counter() - t0
+    power.stop()
+    power_local = power.report(args.steps, dt)
     out = outs[0]
     for c, _, _, _ in provers:
         c.profile_enable(False)
-    per_rank = per_rank_report(parallel, dt, args.steps, dev_index)
+    per_rank = per_rank_report(parallel, dt, args.steps, dev_index, power_local)
     dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
     checked = {"results_checked": False} if args.no_result_check else verify_openings(czk, ctx, B, out)
     if getattr(args, "real_instance", False) and not party and not args.no_result_check:
@@ -841,13 +939,13 @@ def run_polyiop(args, czk, parallel, ctx, rank, world, n, size_txt):
         "metric": f"collaborative {'Plonk' if plonk else 'Marlin'} proofs/sec (BLS12-377, {size_txt} constraints, {scheme} N={args.parties})",
         "value": proofs / dt, "unit": "proofs/s", "n_gpus": world, "ranks_seen_by_backend": world, "backend": args.backend if world > 1 else None,
         "net": (("czk_net " + args.net_transport) if parallel.get_net() is not None else "torch.distributed") if party else None,
-        "steps": args.steps, "warmup": args.warmup, "per_rank": per_rank,
+        "steps": args.steps, "warmup": args.warmup, "per_rank": per_rank, **power_local,
         "ms_per_step": dt / args.steps * 1e3, "first_proof_ms": first_ms, "higher_is_better": True, "scaling": "strong" if party else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic", **checked,
         "config": {"workload": f"{what}; {where}; synthetic circuit / index and SRS, fixed Fiat-Shamir challenges, commitments / evaluations settled at "
                                "every point where the reference's transcript draws a challenge (collaborative-zksnark_amd/polyvm.py)",
                    "constraints": n, "parties": args.parties, "share_lanes": lanes, "layout": args.layout, "results_sha256": digest,
-                   "proofs_in_flight": inflight, "inputs": ("a satisfied circuit" if plonk else "a real index of a satisfied instance, public data on every lane") + " (tests/polyiop_real.py)" if getattr(args, "real_instance", False) else "work-shaped stand-ins",
+                   "commit_opens": (args.commit_opens if (party and not plonk) else None), "proofs_in_flight": inflight, "inputs": ("a satisfied circuit" if plonk else "a real index of a satisfied instance, public data on every lane") + " (tests/polyiop_real.py)" if getattr(args, "real_instance", False) else "work-shaped stand-ins",
                    "ntt_lanes_per_proof": ntt_count / max(1, args.steps), "msms_per_proof": msm_count / max(1, args.steps),
                    "msm_point_lanes_per_proof": pts},
         "roofline": {"bound": "hbm", "kernel": ("k_accumulate_te (G1 bucket accumulation, twisted Edwards extended coordinates, unsaturated limbs)" if te else
@@ -974,6 +1072,7 @@ def main():
                                                            "instead of the discrete-log check of the synthetic key")
     ap.add_argument("--real-instance", action="store_true", help="plonk / marlin: time the prover on a SATISFIED circuit / a real index of a satisfied instance (tests/polyiop_real.py) instead of "
                                                                 "the work-shaped stand-ins; marlin: the timed proofs themselves go through the AHP verifier's decision")
+    ap.add_argument("--verify-report", action="store_true", help="run the `proof_verifies` leg even as a child of another bench.py (the `other_workloads` entries of configs[0])")
     ap.add_argument("--no-verify-report", action="store_true", help="skip `proof_verifies`: one proof of this configuration under a real key against the Groth16 verification equation")
     ap.add_argument("--workload", choices=("groth16", "plonk", "marlin"), default="groth16",
                     help="groth16 (default; BASELINE metric, SPDZ lanes); plonk: mpc-plonk's prover, GSZ lanes, --log-n = log2(gates) (configs[2]: "
@@ -989,7 +1088,9 @@ def main():
     ap.add_argument("--device", type=int, default=None, help="GPU index for this rank (default LOCAL_RANK)")
     ap.add_argument("--no-tables", action="store_true", help="groth16: register the proving key with CZK_MEM_NO_TABLES (points only, one bucket set per window): "
                                                              "1/13 of the key memory -- what lets 8 party ranks of the 2^22 configuration share ONE GPU")
-    ap.add_argument("--commit-opens", action="store_true", help="party layout: dx_t goes through atomic_broadcast (SHA-256 commit-then-open, channel.rs:50-75)")
+    ap.add_argument("--commit-opens", dest="commit_opens", action="store_true", default=True,
+                    help="party layout (the default, as in the reference: share/spdz.rs:179): dx_t goes through atomic_broadcast (SHA-256 commit-then-open, channel.rs:50-75)")
+    ap.add_argument("--no-commit-opens", dest="commit_opens", action="store_false", help="party layout: skip the commit round of the SPDZ open (a weaker protocol than the reference's; reported as commit_opens: false)")
     ap.add_argument("--inflight", type=int, default=None, help="plonk / marlin, replica layout: independent proofs in flight per GPU, each on its own context "
                                                                  "(default 4 with 24 hardware queues: the transcript points of one proof drain the MSM pipeline, the other proofs fill "
                                                                  "the bubbles -- round 4: plonk 172 / 151 / 137 ms per proof with 1 / 2 / 4 in flight, marlin 226 / 198 / 184)")
@@ -1094,7 +1195,9 @@ def main():
     prover.all_results.clear()
     ctx.profile_reset()
     ctx.profile_enable(True)
+    power = PowerSampler(device)
     barrier()
+    power.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         prover.step(sync=False)     # consecutive proofs pipeline on the context's streams
@@ -1103,9 +1206,11 @@ def main():
         combined = parallel.combine_split_results(ctx, czk, prover.all_results)
     barrier()
     dt = time.perf_counter() - t0
+    power.stop()
+    power_local = power.report(args.steps, dt)      # this rank's GPU over its own timed loop
     ctx.profile_enable(False)
     assert len(prover.all_results) == args.steps and all(r["h"].any() and r["b_g2"].any() for r in prover.all_results)
-    per_rank = per_rank_report(parallel, dt, args.steps, device)
+    per_rank = per_rank_report(parallel, dt, args.steps, device, power_local)
     dt = parallel.max_over_ranks(dt, device="cuda" if args.backend == "nccl" else "cpu")
     proofs = args.steps if (party_layout or split_layout) else world * args.steps      # party / split layout: all ranks work on the same proof
     if split_layout:
@@ -1247,6 +1352,8 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3,
         "per_rank": per_rank,
+        # board power of rank 0's GPU averaged over the timed loop (amdgpu hwmon, 10 ms samples) and the proofs that GPU made per kilojoule
+        **power_local,
         "latency_ms_single_proof": latency_ms,
         # the reference's own metric is one proof's wall time (mpc-snarks/src/proof.rs:130-135): the un-pipelined rate
         "proofs_per_s_unpipelined": 1000.0 / latency_ms,
@@ -1279,7 +1386,8 @@ def main():
                                   (f"ONE proof over {world} GPUs, party p's two share lanes on rank p; each of the two opens of the witness map is the "
                                    f"reference's two broadcast rounds (sh lanes, then dx_t = mac_share * value - mac) as all-gathers over {args.backend}, "
                                    "sums and the MAC check on device"),
-                   "layout": args.layout, "results_sha256": digest, "window_tables": not args.no_tables},
+                   "layout": args.layout, "results_sha256": digest, "window_tables": not args.no_tables,
+                   "commit_opens": (bool(prover.commit_opens) if (party_layout and args.scheme == "spdz") else None)},
         "roofline": {"bound": "hbm", "kernel": ("k_accumulate_te (G1 bucket accumulation, twisted Edwards extended coordinates, unsaturated limbs)" if te else
                                                 "k_accumulate_u (G1 bucket accumulation, unsaturated limbs)"), "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_raw": traffic_raw, "traffic_note": traffic_note if traffic is not None else None,
@@ -1335,7 +1443,7 @@ def main():
                                              "what a prove-once caller should use"}
         if r1 is not None and not args.no_result_check:
             out["one_shot_no_tables"]["results_checked"] = bool(check_results(czk, ctx1, p1, r1)["results_checked"])
-    if rank == 0 and world == 1 and not args.no_result_check and not args.no_verify_report and not party_layout and not split_layout and not os.environ.get("CZK_BENCH_CHILD") and rk is None:
+    if rank == 0 and world == 1 and not args.no_result_check and not args.no_verify_report and not party_layout and not split_layout and (not os.environ.get("CZK_BENCH_CHILD") or args.verify_report) and rk is None:
         try:
             del prover
         except NameError:
@@ -1378,9 +1486,15 @@ def main():
     if world > 1:
         torch.distributed.destroy_process_group()
     if want_report and rank == 0:
-        out["multi_gpu_report"] = multi_gpu_report(world, out, False, args.report_budget_s)
+        # the replica line FIRST, complete and flushed: a report child that fails or hangs (the RCCL and hipIpc-across-devices legs have never run on
+        # hardware) can then cost the report, never the measurement.  The same line follows with the report folded in; a reader takes the last one.
+        print(json.dumps({**out, "multi_gpu_report": {"pending": "this line is repeated below with the report folded in"}}), flush=True)
+        try:
+            out["multi_gpu_report"] = multi_gpu_report(world, out, False, args.report_budget_s)
+        except BaseException as e:      # noqa: BLE001 -- incl. KeyboardInterrupt / SystemExit from a child handler: the line below must still be printed
+            out["multi_gpu_report"] = {"error": repr(e)[-400:]}
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

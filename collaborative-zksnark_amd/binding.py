@@ -155,6 +155,16 @@ class Context:
     def sync(self):
         self._ck(self._L.czk_ctx_sync(self._h))
 
+    def mark(self) -> int:
+        """czk_ctx_mark: names the work enqueued on the context so far (kernels, msm_async calls, deferred downloads)"""
+        m = C.c_uint64(0)
+        self._ck(self._L.czk_ctx_mark(self._h, C.byref(m)))
+        return m.value
+
+    def wait_mark(self, mark: int):
+        """czk_ctx_wait_mark: blocks until the work before `mark` is done and delivers its host results; later calls keep running"""
+        self._ck(self._L.czk_ctx_wait_mark(self._h, C.c_uint64(mark)))
+
     # ---- device-resident share lanes ---------------------------------------------------------------
     def lanes_alloc(self, lanes: int, length: int) -> "Lanes":
         """czk_lanes_alloc: `lanes` x `length` Fr in HBM, zero-filled; the handle a caller without a HIP allocator uses."""
@@ -588,8 +598,9 @@ class Net:
         self._ck(self._L.czk_net_atomic_broadcast(self._h, _ptr(x_ptr), C.c_size_t(n), _ptr(recv_ptr), r, C.c_int(mem)))
 
     # ---- the reference's batch opens on device lanes ---------------------------------------------------------------------------
-    def spdz_batch_open(self, sh_ptr, mac_ptr, mac_share, n: int, out_ptr, commit: bool = False) -> int:
-        """SpdzFieldShare::batch_open; returns the number of failed MAC checks (the reference asserts 0)"""
+    def spdz_batch_open(self, sh_ptr, mac_ptr, mac_share, n: int, out_ptr, commit: bool = True) -> int:
+        """SpdzFieldShare::batch_open; returns the number of failed MAC checks (the reference asserts 0).  commit=True (the default, as in the
+        reference: spdz.rs:179 -> channel.rs:50-75) sends dx_ts through the commit-then-open round; False is an explicit opt-out."""
         ms = np.ascontiguousarray(mac_share, np.uint64).reshape(4)
         bad = C.c_uint64(0)
         self._ck(self._L.czk_spdz_batch_open(self._h, _ptr(sh_ptr), _ptr(mac_ptr), _ptr(ms), C.c_size_t(n), _ptr(out_ptr),
@@ -655,6 +666,12 @@ class Lanes:
         out = np.zeros((n, 4), dtype=np.uint64)
         self.ctx._ck(self.ctx._L.czk_lanes_download(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(out if n else None), C.c_size_t(n)))
         return out
+
+    def download_deferred(self, out: np.ndarray, lane: int = 0, elem: int = 0):
+        """czk_lanes_download_deferred: `out` (n x 4 u64, kept alive by the caller) is filled when a later mark is waited for / at the next sync"""
+        assert out.dtype == np.uint64 and out.flags.c_contiguous
+        n = out.size // 4
+        self.ctx._ck(self.ctx._L.czk_lanes_download_deferred(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), _ptr(out if n else None), C.c_size_t(n)))
 
     def copy_from(self, src: "Lanes", n: int, lane: int = 0, elem: int = 0, src_lane: int = 0, src_elem: int = 0):
         self.ctx._ck(self.ctx._L.czk_lanes_copy(self.ctx._h, self._h, C.c_size_t(lane), C.c_size_t(elem), src._h, C.c_size_t(src_lane), C.c_size_t(src_elem), C.c_size_t(n)))

@@ -4,6 +4,7 @@
 #include "czk_internal.h"
 
 #include <stdlib.h>
+#include <unistd.h>
 
 namespace {
 // The MSM pipeline runs on three internal streams next to the caller's stream.  HIP multiplexes streams onto
@@ -112,16 +113,38 @@ static hipEvent_t take_event(czk_ctx* ctx) {
     (void)hipEventCreate(&e);
     return e;
 }
+#ifdef CZK_LAB
+// ---- schedule perturbation (option "chaos") -----------------------------------------------------------------------------------------
+__global__ void k_chaos_spin(unsigned long long ticks) {   // one wave that holds its stream for `ticks` of the 100 MHz wall clock
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+unsigned chaos_rand(czk_ctx* ctx) {   // xorshift64*
+    unsigned long long x = ctx->chaos;
+    x ^= x >> 12, x ^= x << 25, x ^= x >> 27;
+    ctx->chaos = x ? x : 0x9E3779B97F4A7C15ull;
+    return (unsigned)((x * 0x2545F4914F6CDD1Dull) >> 33);
+}
+void chaos_point(czk_ctx* ctx, hipStream_t st) {
+    if (!ctx->chaos) return;
+    const unsigned r = chaos_rand(ctx), how = r & 7;
+    if (how >= 3 && how != 6) hipLaunchKernelGGL(k_chaos_spin, dim3(1), dim3(64), 0, st, (unsigned long long)((r >> 3) % 40000));   // up to 400 us on the stream
+    if (how >= 6) usleep((r >> 8) % 300);                                                                                          // up to 300 us on the host
+}
+#endif
 ProfScope::ProfScope(czk_ctx* c, const char* n, hipStream_t s) : ctx(c), name(n), st(s ? s : c->stream) {
+    chaos_point(ctx, st);
     if (!ctx->profiling) return;
     e0 = take_event(ctx);
     e1 = take_event(ctx);
     (void)hipEventRecord(e0, st);
 }
 ProfScope::~ProfScope() {
-    if (!e0) return;
-    (void)hipEventRecord(e1, st);
-    ctx->prof[name].pending.emplace_back(e0, e1);
+    if (e0) {
+        (void)hipEventRecord(e1, st);
+        ctx->prof[name].pending.emplace_back(e0, e1);
+    }
+    chaos_point(ctx, st);
 }
 static void prof_resolve(czk_ctx* ctx) {
     for (auto& kv : ctx->prof) {
@@ -320,7 +343,8 @@ extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
         static const char* const ENV[][2] = {{"CZK_NTT_GEN1", "ntt_gen1"}, {"CZK_SORT_ONEPASS", "msm_sort_onepass"}, {"CZK_REDUCE_SAT", "msm_reduce_sat"},
             {"CZK_REDUCE_SAT_G2", "msm_reduce_sat_g2"}, {"CZK_G2_MODE", "msm_g2_mode"}, {"CZK_MSM_AFFINE", "msm_affine_rounds"}, {"CZK_MSM_SLOTS", "msm_slots"},
             {"CZK_STREAM_PRIO", "msm_stream_priority"}, {"CZK_MSM_SAT", "msm_sat"}, {"CZK_MSM_SAT_G2", "msm_sat_g2"}, {"CZK_MSM_NO_TE", "msm_no_te"},
-            {"CZK_MSM_FIXED_C", "msm_fixed_c"}, {"CZK_MSM_C_G1", "msm_window_g1"}, {"CZK_MSM_C_G2", "msm_window_g2"}};
+            {"CZK_MSM_FIXED_C", "msm_fixed_c"}, {"CZK_MSM_C_G1", "msm_window_g1"}, {"CZK_MSM_C_G2", "msm_window_g2"}, {"CZK_CHAOS", "chaos"},
+            {"CZK_CHAOS_DROP_WAIT", "chaos_drop_wait"}};
         for (auto& e : ENV)
             if (const char* v = getenv(e[0])) (void)czk_ctx_set_option(c, e[1], atol(v) ? atol(v) : (v[0] == '0' ? 0 : 1));
     }
@@ -385,6 +409,7 @@ const OptDesc OPTIONS[] = {
     {"msm_window_g1", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g1 = (unsigned)v; }},
     {"msm_window_g2", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g2 = (unsigned)v; }},
     {"ntt_gen1", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_gen1 = v != 0; }},
+    {"net_create_timeout_ms", 0, 3600000, false, [](czk_ctx* c, long v) { c->net_create_timeout_ms = v; }},
 #ifdef CZK_LAB
     {"msm_affine_rounds", 0, 3, false, [](czk_ctx* c, long v) { c->msm_affine_rounds = (unsigned)v; }},
     {"msm_reduce_sat", 0, 1, false, [](czk_ctx* c, long v) { c->msm_reduce_sat = v != 0; }},
@@ -393,6 +418,10 @@ const OptDesc OPTIONS[] = {
     {"msm_sat", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sat = v != 0; }},
     {"msm_sat_g2", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sat_g2 = v != 0; }},
     {"msm_no_te", 0, 1, false, [](czk_ctx* c, long v) { c->msm_no_te = v != 0; }},
+    // (the seed is mixed with the process id and the context's address: the parties of a party layout and the contexts of several proofs in flight must not
+    // draw the same delays)
+    {"chaos", 0, 0x7fffffff, false, [](czk_ctx* c, long v) { c->chaos = v ? ((unsigned long long)v * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)getpid() << 32) ^ (unsigned long long)(uintptr_t)c : 0; }},
+    {"chaos_drop_wait", 0, 2, false, [](czk_ctx* c, long v) { c->chaos_drop_wait = (int)v; }},
 #endif
 };
 }  // namespace

@@ -66,15 +66,23 @@ struct MsmSlot {
     hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_fix = nullptr, ev_red = nullptr;
     bool used = false;
 };
-struct MsmPending {
+struct MsmPending {   // a host result on its way: pinned staging -> the caller's buffer at czk_ctx_sync / czk_ctx_wait_mark (MSM results, deferred downloads)
     const char* src;
     void* dst;
     size_t bytes;
+    bool on_stream = false;   // copied on the context's stream (czk_lanes_download_deferred) rather than on the reduce stream
     // split-window MSMs (bases registered without tables): `src` holds lanes x split_W per-window results that still have to
     // be combined as sum_w 2^(c w) R_w (host, a few hundred point operations) into `dst` = lanes results
     unsigned split_W = 0, c = 0;
     int group = 0;
     size_t lanes = 0;
+};
+// czk_ctx_mark: the work enqueued so far = an event on the context's stream, one on the reduce stream (results are copied there, in order) and the
+// number of host results enqueued before it
+struct CtxMark {
+    uint64_t id = 0;
+    hipEvent_t ev_stream = nullptr, ev_red = nullptr;
+    uint64_t upto = 0;   // absolute index: results [delivered, upto) belong to the mark
 };
 }  // namespace czk
 
@@ -92,8 +100,12 @@ struct czk_ctx {
     int msm_next_slot = 0;
     int msm_slots_in_use = 4;
     char* msm_pinned = nullptr;
-    size_t msm_pinned_bytes = 0, msm_pinned_used = 0;
+    size_t msm_pinned_bytes = 0, msm_pinned_used = 0;   // a ring: `used` is the tail, the oldest pending result's offset the head
     std::vector<czk::MsmPending> msm_pending;
+    uint64_t msm_delivered = 0;                         // results delivered so far (absolute index of msm_pending[0])
+    std::vector<czk::CtxMark> marks;                    // czk_ctx_mark, oldest first
+    uint64_t next_mark = 1;
+    std::vector<hipEvent_t> mark_events;                // idle events of retired marks
     // ---- czk_ctx_set_option (core.hip).  The product library knows the first group only; the second group selects kernels that exist in the
     // lab build alone (libczk_hip_lab.so, -DCZK_LAB: the measured-and-rejected variants of EXPERIMENTS.md) and is fixed at its default otherwise.
     bool msm_sort_onepass = false;   // "msm_sort_onepass": the single-pass digit sort for every call (it is the > 2048-partition fallback anyway)
@@ -106,7 +118,15 @@ struct czk_ctx {
     int msm_g2_mode = 0;             // lab "msm_g2_mode": 0 = single-lane G2 accumulate kernel (k_accumulate_u2, adopted), 1 = lane pairs <128, 2>, 2 = lane pairs <512, 3> + LDS-limited occupancy
     bool msm_sat = false, msm_sat_g2 = false;   // lab "msm_sat" / "msm_sat_g2": keys registered from now on keep saturated tables and accumulate kernels
     bool msm_no_te = false;          // lab "msm_no_te": G1 keys registered from now on keep the XYZZ kernels (what CZK_MEM_ANY_POINTS does per key)
+    long net_create_timeout_ms = 0;  // "net_create_timeout_ms": how long czk_net_create on this context waits for its peers (0 = the communicator's default, 120 s)
     unsigned long long* open_bad = nullptr;   // device counter of czk_fr_spdz_open (allocated once)
+    // lab "chaos": schedule perturbation (tests/test_chaos.py).  Non-zero = seed: every stage boundary (the profiling brackets around the sort / accumulate /
+    // reduce / NTT / polynomial stages, the result copy) first enqueues a spin kernel of random length on the stage's stream and / or sleeps on the host, and the
+    // MSM workspace ring hands out its slots in random order.  Results must not change: every ordering the library relies on has to be an event wait or stream
+    // order, never timing.  "chaos_drop_wait" removes ONE such wait on purpose (1: the accumulate stream's wait for the digit sort; 2: the reduce stream's wait
+    // for the accumulate kernel), so that the test can show it catches the class of bug it exists for.
+    unsigned long long chaos = 0;
+    int chaos_drop_wait = 0;
     bool ntt_gen1 = false;           // "ntt_gen1": first-generation NTT passes (ntt.hip, the small-domain kernels) for every size
     bool profiling = false;
     std::map<std::string, czk::ProfEntry> prof;
@@ -199,6 +219,13 @@ int stage_take(czk_ctx* ctx, size_t bytes, DeviceBuf* out);
 void stage_give(czk_ctx* ctx, const DeviceBuf& b);
 int get_domain(czk_ctx* ctx, unsigned log_d, DomainTables** out);
 
+// lab build, option "chaos": a random delay on `st` and / or on the calling thread (no-op otherwise, and in the product build)
+#ifdef CZK_LAB
+void chaos_point(czk_ctx* ctx, hipStream_t st);
+unsigned chaos_rand(czk_ctx* ctx);
+#else
+inline void chaos_point(czk_ctx*, hipStream_t) {}
+#endif
 // RAII bracket: records an event pair around the launches issued in its scope (no-op unless profiling)
 struct ProfScope {
     czk_ctx* ctx;
@@ -276,6 +303,9 @@ CZK_HD unsigned msm_win_width(unsigned c, unsigned W_hi, unsigned w) { return w 
 // sum_w 2^(bit(w)) R[lane][w] on the host (Horner: width(w) doublings per window); src: lanes x W Jacobian triples, out: lanes triples
 void host_combine_windows(int group, const char* src, unsigned W, unsigned c, size_t lanes, uint64_t* out);
 int msm_pipeline_sync(czk_ctx* ctx);
+int msm_pinned_take(czk_ctx* ctx, size_t bytes, char** out);   // staging for one host result (a ring over the pinned area; drains when full)
+int ctx_mark(czk_ctx* ctx, uint64_t* out);       // czk_ctx_mark / czk_ctx_wait_mark
+int ctx_wait_mark(czk_ctx* ctx, uint64_t id);
 void msm_pipeline_destroy(czk_ctx* ctx);
 int fixed_base_points_device(czk_ctx* ctx, int group, const u64* k_dev, size_t n, u64* out_dev);
 void launch_reduce_level_g1(hipStream_t st, const u64* P, const u64* E, size_t n_in, unsigned L, unsigned scale_dbl, u64* Po, u64* Eo, size_t n_out,

@@ -153,6 +153,21 @@ extern "C" int czk_lanes_download(czk_ctx* ctx, const czk_lanes* src, size_t lan
     return download_pageable(ctx, host, src->p + 4 * (lane * src->len + elem), n * 32);
 }
 
+extern "C" int czk_lanes_download_deferred(czk_ctx* ctx, const czk_lanes* src, size_t lane, size_t elem, uint64_t* host, size_t n) {
+    if (!ctx) return CZK_ERR_ARG;
+    if (!in_range(src, lane, elem, n) || (n && !host)) return set_err(ctx, CZK_ERR_ARG, "czk_lanes_download_deferred: range outside the lanes / null host pointer");
+    if (!n) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    // into the pinned result ring on the context's stream; delivered to `host` with the MSM results (czk_ctx_wait_mark / czk_ctx_sync)
+    char* pinned = nullptr;
+    CZK_TRY(msm_pinned_take(ctx, n * 32, &pinned));
+    CZK_HIP(ctx, hipMemcpyAsync(pinned, src->p + 4 * (lane * src->len + elem), n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    MsmPending pend{pinned, host, n * 32};
+    pend.on_stream = true;
+    ctx->msm_pending.push_back(pend);
+    return CZK_OK;
+}
+
 extern "C" int czk_lanes_copy(czk_ctx* ctx, czk_lanes* dst, size_t dst_lane, size_t dst_elem, const czk_lanes* src, size_t src_lane, size_t src_elem,
                               size_t n) {
     if (!ctx) return CZK_ERR_ARG;
@@ -203,13 +218,15 @@ extern "C" int czk_fr_copy_3d(czk_ctx* ctx, uint64_t* dst, const size_t* dst_str
     if (!total) return CZK_OK;
     if (!dst) return set_err(ctx, CZK_ERR_ARG, "czk_fr_copy_3d: null destination");
     CZK_HIP(ctx, hipSetDevice(ctx->device));
-    // contiguous cases go to the copy engine / memset path: no kernel, no CU time
-    const bool dst_dense = dst_stride[2] == 1 && dst_stride[1] == n[2] && dst_stride[0] == n[1] * n[2];
+    // contiguous cases go to the copy engine / memset path.  The stride of a dimension of extent 1 is never used, so it does not count (the provers pass
+    // stride 0 with n[0] == 1 for every two-dimensional re-layout)
+    auto dense = [&](const size_t* st) { return (n[2] == 1 || st[2] == 1) && (n[1] == 1 || st[1] == n[2]) && (n[0] == 1 || st[0] == n[1] * n[2]); };
+    const bool dst_dense = dense(dst_stride);
     if (dst_dense && !src) {
         CZK_HIP(ctx, hipMemsetAsync(dst, 0, total * 32, ctx->stream));
         return CZK_OK;
     }
-    if (dst_dense && src_stride[2] == 1 && src_stride[1] == n[2] && src_stride[0] == n[1] * n[2]) {
+    if (dst_dense && dense(src_stride)) {
         CZK_HIP(ctx, hipMemcpyAsync(dst, src, total * 32, hipMemcpyDeviceToDevice, ctx->stream));
         return CZK_OK;
     }

@@ -928,6 +928,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     const unsigned L = 8, logL = 3;
     if ((size_t)W * nb >= ((size_t)1 << 31)) return set_err(ctx, CZK_ERR_SIZE, "W * n_bases exceeds the 31-bit point index");
     CZK_TRY(msm_pipeline_init(ctx));
+#ifdef CZK_LAB
+    if (ctx->chaos && !reserve_only) ctx->msm_next_slot = (int)(chaos_rand(ctx) % (unsigned)ctx->msm_slots_in_use);   // any slot is valid: its events order the reuse
+#endif
     MsmSlot& slot = ctx->msm_slots[ctx->msm_next_slot];
     if (!reserve_only) ctx->msm_next_slot = (ctx->msm_next_slot + 1) % ctx->msm_slots_in_use;
 
@@ -1030,12 +1033,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 
     // pinned staging for the result
     const size_t out_bytes = lanes * JW * 8;
-    if (ctx->msm_pinned_used + out_bytes > ctx->msm_pinned_bytes) {
-        CZK_TRY(msm_pipeline_sync(ctx));   // drains pending results first
-        if (out_bytes > ctx->msm_pinned_bytes) return set_err(ctx, CZK_ERR_SIZE, "too many MSM lanes for the result staging area");
-    }
-    char* pinned = ctx->msm_pinned + ctx->msm_pinned_used;
-    ctx->msm_pinned_used += (out_bytes + 255) & ~(size_t)255;
+    char* pinned = nullptr;
+    CZK_TRY(msm_pinned_take(ctx, out_bytes, &pinned));
 
     hipStream_t ss = ctx->s_sort, sa = ctx->s_acc, sr = ctx->s_red;
     // inputs (scalars) are produced on the caller's stream
@@ -1116,6 +1115,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipEventRecord(slot.ev_sorted, ss));
     // the caller's stream may overwrite the scalars once the digits are extracted
     if (!scalars_stable) CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
+#ifdef CZK_LAB
+    if (ctx->chaos_drop_wait != 1)   // (the deliberately broken schedule of tests/test_chaos.py)
+#endif
     CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     if (te) {
@@ -1139,6 +1141,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     }
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
+#ifdef CZK_LAB
+    if (ctx->chaos_drop_wait != 2)
+#endif
     CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
     // work items beyond the first 1024 entries of over-full buckets (none with uniformly random scalars): reduce stream
     if (te) launch_heavy_g1_te(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, heavy_hdr, heavy_items, heavy_list, heavy_partials,
@@ -1196,6 +1201,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 #endif
     }
     CZK_HIP(ctx, hipGetLastError());
+    chaos_point(ctx, sr);
     CZK_HIP(ctx, hipMemcpyAsync(pinned, result, out_bytes, hipMemcpyDeviceToHost, sr));
     CZK_HIP(ctx, hipEventRecord(slot.ev_red, sr));
     slot.used = true;
@@ -1232,24 +1238,106 @@ int msm_pipeline_init(czk_ctx* ctx) {
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_fix, hipEventDisableTiming));
         CZK_HIP(ctx, hipEventCreateWithFlags(&s.ev_red, hipEventDisableTiming));
     }
-    ctx->msm_pinned_bytes = 1 << 20;
+    ctx->msm_pinned_bytes = 4 << 20;
     CZK_HIP(ctx, hipHostMalloc((void**)&ctx->msm_pinned, ctx->msm_pinned_bytes, hipHostMallocDefault));
     return CZK_OK;
 }
 
-// wait for every enqueued MSM and deliver the results
+static void deliver(const MsmPending& p) {
+    if (p.split_W) host_combine_windows(p.group, p.src, p.split_W, p.c, p.lanes, (uint64_t*)p.dst);
+    else memcpy(p.dst, p.src, p.bytes);
+}
+static void retire_mark(czk_ctx* ctx, CtxMark& m) {
+    ctx->mark_events.push_back(m.ev_stream);
+    ctx->mark_events.push_back(m.ev_red);
+}
+
+// wait for every enqueued MSM and deliver the results (and those of deferred downloads: their copies run on the context's stream)
 int msm_pipeline_sync(czk_ctx* ctx) {
     if (!ctx->s_sort) return CZK_OK;
+    for (auto& p : ctx->msm_pending)
+        if (p.on_stream) {
+            CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            break;
+        }
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_sort));
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_acc));
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_red));
-    for (auto& p : ctx->msm_pending) {
-        if (p.split_W) host_combine_windows(p.group, p.src, p.split_W, p.c, p.lanes, (uint64_t*)p.dst);
-        else memcpy(p.dst, p.src, p.bytes);
-    }
+    for (auto& p : ctx->msm_pending) deliver(p);
+    ctx->msm_delivered += ctx->msm_pending.size();
     ctx->msm_pending.clear();
     ctx->msm_pinned_used = 0;
+    for (auto& m : ctx->marks) retire_mark(ctx, m);   // everything a mark could name is done
+    ctx->marks.clear();
     return CZK_OK;
+}
+
+// Staging for one host result: a ring over the pinned area.  Results are delivered oldest first, so the free space runs from the tail (`used`) round to
+// the oldest pending result; when a request does not fit, everything pending is drained (a full synchronisation -- 4 MiB hold > 10^4 MSM results).
+int msm_pinned_take(czk_ctx* ctx, size_t bytes, char** out) {
+    CZK_TRY(msm_pipeline_init(ctx));
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > ctx->msm_pinned_bytes) return set_err(ctx, CZK_ERR_SIZE, "host result larger than the result staging area");
+    if (ctx->msm_pending.empty()) ctx->msm_pinned_used = 0;
+    else {
+        const size_t head = (size_t)(ctx->msm_pending.front().src - ctx->msm_pinned), tail = ctx->msm_pinned_used;
+        bool fits;
+        if (tail > head) {                         // [head, tail) in use
+            fits = tail + need <= ctx->msm_pinned_bytes;
+            if (!fits && need <= head) {           // wrap: [0, head) is free
+                ctx->msm_pinned_used = 0;
+                fits = true;
+            }
+        } else fits = tail + need <= head;         // wrapped: [tail, head) is free (tail == head with results pending: full)
+        if (!fits) {
+            CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            CZK_TRY(msm_pipeline_sync(ctx));
+        }
+    }
+    *out = ctx->msm_pinned + ctx->msm_pinned_used;
+    ctx->msm_pinned_used += need;
+    return CZK_OK;
+}
+
+// ---- marks (include/czk.h: czk_ctx_mark / czk_ctx_wait_mark / czk_lanes_download_deferred) -------------------------------------------
+static hipEvent_t mark_event(czk_ctx* ctx) {
+    if (!ctx->mark_events.empty()) {
+        hipEvent_t e = ctx->mark_events.back();
+        ctx->mark_events.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    return e;
+}
+int ctx_mark(czk_ctx* ctx, uint64_t* out) {
+    CZK_TRY(msm_pipeline_init(ctx));
+    CtxMark m;
+    m.id = ctx->next_mark++;
+    m.ev_stream = mark_event(ctx);
+    m.ev_red = mark_event(ctx);
+    if (!m.ev_stream || !m.ev_red) return set_err(ctx, CZK_ERR_HIP, "czk_ctx_mark: no event");
+    CZK_HIP(ctx, hipEventRecord(m.ev_stream, ctx->stream));
+    CZK_HIP(ctx, hipEventRecord(m.ev_red, ctx->s_red));   // every MSM enqueued so far ends with its result copy on this stream, in order
+    m.upto = ctx->msm_delivered + ctx->msm_pending.size();
+    ctx->marks.push_back(m);
+    *out = m.id;
+    return CZK_OK;
+}
+int ctx_wait_mark(czk_ctx* ctx, uint64_t id) {
+    if (id == 0 || id >= ctx->next_mark) return set_err(ctx, CZK_ERR_ARG, "czk_ctx_wait_mark: not a mark of this context");
+    while (!ctx->marks.empty() && ctx->marks.front().id <= id) {   // older marks first: a mark covers the ones before it
+        CtxMark m = ctx->marks.front();
+        CZK_HIP(ctx, hipEventSynchronize(m.ev_stream));
+        CZK_HIP(ctx, hipEventSynchronize(m.ev_red));
+        size_t k = 0;
+        while (k < ctx->msm_pending.size() && ctx->msm_delivered + k < m.upto) deliver(ctx->msm_pending[k++]);
+        ctx->msm_pending.erase(ctx->msm_pending.begin(), ctx->msm_pending.begin() + k);
+        ctx->msm_delivered += k;
+        retire_mark(ctx, m);
+        ctx->marks.erase(ctx->marks.begin());
+    }
+    return CZK_OK;   // (a mark retired earlier -- by a later mark's wait or by czk_ctx_sync -- has nothing left to wait for)
 }
 
 void msm_pipeline_destroy(czk_ctx* ctx) {
@@ -1261,6 +1349,10 @@ void msm_pipeline_destroy(czk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->s_acc);
     (void)hipStreamSynchronize(ctx->s_red);
     ctx->msm_pending.clear();
+    for (auto& m : ctx->marks) retire_mark(ctx, m);
+    ctx->marks.clear();
+    for (hipEvent_t e : ctx->mark_events) (void)hipEventDestroy(e);
+    ctx->mark_events.clear();
     for (auto& s : ctx->msm_slots) {
         if (s.ws_sort.p) (void)hipFree(s.ws_sort.p);
         if (s.ws_red.p) (void)hipFree(s.ws_red.p);
@@ -1480,6 +1572,16 @@ extern "C" int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* sca
 extern "C" int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes, int scalar_form,
                              int mem, uint64_t* out_jac) {
     return msm_common(ctx, bases, scalars, n_scalars, lanes, scalar_form, mem, out_jac, false);
+}
+extern "C" int czk_ctx_mark(czk_ctx* ctx, uint64_t* out_mark) {
+    if (!ctx || !out_mark) return ctx ? set_err(ctx, CZK_ERR_ARG, "null czk_ctx_mark argument") : CZK_ERR_ARG;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    return ctx_mark(ctx, out_mark);
+}
+extern "C" int czk_ctx_wait_mark(czk_ctx* ctx, uint64_t mark) {
+    if (!ctx) return CZK_ERR_ARG;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    return ctx_wait_mark(ctx, mark);
 }
 
 static int msm_oneshot(czk_ctx* ctx, int group, const uint64_t* bases_xy, const uint8_t* inf, const uint64_t* scalars, size_t n, size_t lanes,

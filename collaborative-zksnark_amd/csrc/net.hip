@@ -152,7 +152,7 @@ Rccl* rccl() {
 struct ShmHeader {
     std::atomic<uint64_t> magic;
     std::atomic<uint32_t> world;
-    std::atomic<uint32_t> attached;
+    std::atomic<uint32_t> reserved;  // (keeps the layout of the control block)
     std::atomic<uint32_t> count;     // arrivals at the current barrier
     std::atomic<uint32_t> abort;     // a rank timed out or failed: everybody leaves with CZK_ERR_NET
     std::atomic<uint64_t> gen;       // barrier generation
@@ -223,6 +223,7 @@ int net_buf(czk_net* n, DeviceBuf& b, size_t bytes) {
 // ---- SHM transport -------------------------------------------------------------------------------------------------------------------
 int shm_barrier(czk_net* n) {
     ShmHeader* h = n->hdr;
+    if (n->ctx) chaos_point(n->ctx, n->ctx->stream);   // lab option "chaos": the parties reach every generation flip at perturbed times (no-op otherwise)
     if (h->abort.load(std::memory_order_acquire)) return net_err(n, CZK_ERR_NET, "shm: a peer aborted the communicator");
     const uint64_t gen = h->gen.load(std::memory_order_acquire);
     if (h->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)n->world) {
@@ -365,6 +366,7 @@ inline char* shm_slot(czk_net* n, int owner, uint64_t parity) {
 }
 
 int shm_put(czk_net* n, char* slot, const void* src, size_t len, int mem, bool* wrote) {
+    if (n->ctx) chaos_point(n->ctx, n->ctx->stream);
     if (n->transport == CZK_NET_IPC) {   // the slot is device memory (this rank's mailbox, or a peer's through its mapping)
         NET_HIP(n, hipMemcpyAsync(slot, src, len, mem == CZK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, n->ctx->stream));
         *wrote = true;
@@ -379,6 +381,7 @@ int shm_put(czk_net* n, char* slot, const void* src, size_t len, int mem, bool* 
     return CZK_OK;
 }
 int shm_get(czk_net* n, void* dst, const char* slot, size_t len, int mem) {
+    if (n->ctx) chaos_point(n->ctx, n->ctx->stream);
     if (n->transport == CZK_NET_IPC) {
         NET_HIP(n, hipMemcpyAsync(dst, slot, len, mem == CZK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, n->ctx->stream));
         if (mem == CZK_MEM_DEVICE) n->reads_in_flight = true;
@@ -590,6 +593,7 @@ extern "C" int czk_net_create(czk_ctx* ctx, int transport, int rank, int world, 
     if (world < 1 || rank < 0 || rank >= world || !id || !id_len) return fail(CZK_ERR_ARG, "czk_net_create: bad rank / world / id");
     czk_net* n = new czk_net;
     n->ctx = ctx, n->transport = transport, n->rank = rank, n->world = world;
+    if (ctx && ctx->net_create_timeout_ms > 0) n->timeout_ms = ctx->net_create_timeout_ms;   // czk_ctx_set_option "net_create_timeout_ms": the rendezvous itself
     int rc = CZK_ERR_ARG;
     if (transport == CZK_NET_RCCL) {
         rc = [&]() -> int {
@@ -617,12 +621,17 @@ extern "C" int czk_net_create(czk_ctx* ctx, int transport, int rank, int world, 
             } else {
                 const double t0 = now_ms();
                 while (n->hdr->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
-                    if (now_ms() - t0 > (double)n->timeout_ms) return net_err(n, CZK_ERR_NET, "shm: rank 0 never initialised the communicator");
+                    if (now_ms() - t0 > (double)n->timeout_ms) {
+                        n->hdr->abort.store(1, std::memory_order_release);
+                        return net_err(n, CZK_ERR_NET, "shm: rank 0 never initialised the communicator");
+                    }
                     usleep(100);
                 }
-                if (n->hdr->world.load(std::memory_order_relaxed) != (uint32_t)world) return net_err(n, CZK_ERR_NET, "shm: ranks disagree on the world size");
+                if (n->hdr->world.load(std::memory_order_relaxed) != (uint32_t)world) {
+                    n->hdr->abort.store(1, std::memory_order_release);   // the ranks already in the barrier leave at once instead of after timeout_ms
+                    return net_err(n, CZK_ERR_NET, "shm: ranks disagree on the world size");
+                }
             }
-            n->hdr->attached.fetch_add(1, std::memory_order_acq_rel);
             CZK_TRY(shm_barrier(n));   // collective: everybody has the control block mapped
             if (rank == 0) shm_unlink(n->shm_name.c_str());
             return CZK_OK;

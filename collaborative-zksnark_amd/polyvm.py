@@ -455,6 +455,10 @@ class GpuBackend(Backend):
         if self._vals is None:
             self._vals = self.torch.empty((4096, 4), dtype=self.torch.int64, device=self.dev)
         if self._vals_at + rows > self._vals.shape[0]:       # (a prover evaluates a few dozen values per round)
+            # pending values are slices of the current buffer and transcript_point() reads them relative to ITS base: settle them before the buffer is
+            # replaced (their values are final either way -- only the host copy happens earlier than the reference's transcript point)
+            if self._pending:
+                self.transcript_point()
             self.ctx.sync()
             self._vals = self.torch.empty((max(2 * self._vals.shape[0], rows), 4), dtype=self.torch.int64, device=self.dev)
             self._vals_at = 0

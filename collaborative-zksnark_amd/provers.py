@@ -113,7 +113,7 @@ class Groth16Local:
         self.P = parties
         self.local = list(range(parties)) if local_parties is None else list(local_parties)
         self.exchange = exchange
-        self.commit_opens = False                     # True: dx_t goes through atomic_broadcast (commit-then-open, channel.rs:50-75)
+        self.commit_opens = True                      # dx_t goes through atomic_broadcast (commit-then-open, spdz.rs:179, channel.rs:50-75); False = explicit opt-out
         # mac_share() = 1 on the king, 0 elsewhere (share/spdz.rs:30-37: the reference's stand-in MAC key is 1)
         self.mac_share = to_mont_limbs([1 if (self.local and self.local[0] == 0) else 0])[0]
         self.lanes = self.lpp * len(self.local)       # SPDZ: sh + mac per party (share/spdz.rs:50-53); HBC: the additive share alone

@@ -93,6 +93,15 @@ typedef enum { CZK_G1 = 1, CZK_G2 = 2 } czk_group;
 int czk_ctx_create(czk_ctx** out, int device, void* hip_stream);
 void czk_ctx_destroy(czk_ctx* ctx);
 int czk_ctx_sync(czk_ctx* ctx);
+/* Waiting for PART of a context's work.  The reference's polynomial provers stop at every transcript point for what the transcript absorbs there
+ * (the commitments and evaluations sent so far: mpc-plonk/src/lib.rs:430-448, marlin/src/lib.rs:176-318) -- not for everything the prover has
+ * started: work that depends on no pending challenge (the next round's transforms of public data, commitments of polynomials that are already
+ * known) can be enqueued before the wait and runs through it.  czk_ctx_mark names the work enqueued on the context so far -- kernels on its stream,
+ * czk_msm_async calls, czk_lanes_download_deferred copies; czk_ctx_wait_mark blocks until THAT work is done and delivers its host results (what
+ * czk_ctx_sync does for all work), while calls made after the mark keep running.  A mark covers the marks taken before it; waiting for a retired mark
+ * returns at once; czk_ctx_sync retires every mark. */
+int czk_ctx_mark(czk_ctx* ctx, uint64_t* out_mark);
+int czk_ctx_wait_mark(czk_ctx* ctx, uint64_t mark);
 /* The hipStream_t the context enqueues on (the one given to czk_ctx_create, or its private stream): lets a caller order its own
  * streams against the context's with events (hipStreamWaitEvent) instead of czk_ctx_sync -- e.g. an RCCL exchange between two opens. */
 void* czk_ctx_stream(const czk_ctx* ctx);
@@ -110,6 +119,8 @@ const char* czk_version(void);
  *   "msm_fixed_c" 0/1           keys registered AFTERWARDS keep their own window width for short calls (no secondary table sets)
  *   "msm_window_g1" / "msm_window_g2" 0, 8..22   primary window width of keys registered AFTERWARDS (0 = the cost model, default)
  *   "ntt_gen1" 0/1              first-generation NTT passes (the small-domain kernels) for every size
+ *   "net_create_timeout_ms" 0..3600000   how long czk_net_create on this context waits for its peers at the rendezvous (0 = the default, 120 s;
+ *                               afterwards the communicator's own "timeout_ms" option applies)
  * Any other name is CZK_ERR_ARG.  The call drains the context's enqueued work first, so an option never changes under a running proof.
  * (libczk_hip_lab.so, the -DCZK_LAB build of the same sources, additionally knows the switches of the measured-and-rejected kernel
  * variants it alone contains -- EXPERIMENTS.md; czk_build_is_lab() tells the two apart.) */
@@ -137,6 +148,10 @@ size_t czk_lanes_len(const czk_lanes* l);
 uint64_t* czk_lanes_data(const czk_lanes* l, size_t lane, size_t elem);
 int czk_lanes_upload(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t elem, const uint64_t* host, size_t n);
 int czk_lanes_download(czk_ctx* ctx, const czk_lanes* src, size_t lane, size_t elem, uint64_t* host, size_t n);
+/* czk_lanes_download without the wait: the copy is enqueued in stream order (through the library's pinned result staging, at most 4 MiB pending) and
+ * `host` is filled when a mark taken after this call is waited for (czk_ctx_wait_mark) or at the next czk_ctx_sync -- the delivery rule of
+ * czk_msm_async's results.  `host` must stay valid until then. */
+int czk_lanes_download_deferred(czk_ctx* ctx, const czk_lanes* src, size_t lane, size_t elem, uint64_t* host, size_t n);
 int czk_lanes_copy(czk_ctx* ctx, czk_lanes* dst, size_t dst_lane, size_t dst_elem, const czk_lanes* src, size_t src_lane, size_t src_elem,
                    size_t n);
 int czk_lanes_zero(czk_ctx* ctx, czk_lanes* dst, size_t lane, size_t elem, size_t n);
@@ -406,7 +421,8 @@ int czk_msm(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_
             int scalar_form, int mem, uint64_t* out_jac);
 
 /* Same, but only enqueues: consecutive calls overlap on the context's internal streams (sort / accumulate / reduce
- * stages of neighbouring MSMs run concurrently).  `out_jac` (host) is valid after the next czk_ctx_sync().  Device
+ * stages of neighbouring MSMs run concurrently).  `out_jac` (host) is valid after the next czk_ctx_sync(), or after czk_ctx_wait_mark on a
+ * mark taken after this call.  Device
  * scalars may be overwritten by later work on the context's stream (the library orders that itself). */
 int czk_msm_async(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scalars, size_t n_scalars, size_t lanes,
                   int scalar_form, int mem, uint64_t* out_jac);

@@ -68,6 +68,14 @@ class Context {
         if (rc != CZK_OK) throw Panic(rc, czk_last_error(ctx_));
     }
     void sync() const { check(czk_ctx_sync(ctx_)); }
+    // czk_ctx_mark / czk_ctx_wait_mark: wait for the work enqueued up to a point (and take delivery of its MSM results / deferred downloads) while
+    // later calls keep running -- the transcript points of the polynomial provers (tools/polyvm_host.hpp)
+    uint64_t mark() const {
+        uint64_t m = 0;
+        check(czk_ctx_mark(ctx_, &m));
+        return m;
+    }
+    void wait_mark(uint64_t m) const { check(czk_ctx_wait_mark(ctx_, m)); }
     // czk_ctx_reserve: twiddle tables of a 2^ntt_log_d domain (0: none) and the MSM workspaces for calls of `n_scalars` x `msm_lanes` on
     // `bases` (nullptr: none), at key load instead of inside the first proof
     void reserve(unsigned ntt_log_d, size_t ntt_lanes, const czk_bases* bases = nullptr, size_t n_scalars = 0, size_t msm_lanes = 0) const {
@@ -98,6 +106,10 @@ class DeviceLanes {
     void upload(size_t lane, size_t elem, const Fr* host, size_t n) { ctx_->check(czk_lanes_upload(ctx_->raw(), h_, lane, elem, n ? host->l : nullptr, n)); }
     void upload(size_t lane, const std::vector<Fr>& v) { upload(lane, 0, v.data(), v.size()); }
     void download(size_t lane, size_t elem, Fr* host, size_t n) const { ctx_->check(czk_lanes_download(ctx_->raw(), h_, lane, elem, n ? host->l : nullptr, n)); }
+    // czk_lanes_download_deferred: `host` is filled when a later mark is waited for / at the next sync
+    void download_deferred(size_t lane, size_t elem, Fr* host, size_t n) const {
+        ctx_->check(czk_lanes_download_deferred(ctx_->raw(), h_, lane, elem, n ? host->l : nullptr, n));
+    }
     std::vector<Fr> to_host(size_t lane) const {
         std::vector<Fr> v(len);
         download(lane, 0, v.data(), len);
@@ -184,8 +196,10 @@ class Net {
     }
     // The batch opens on lanes that live on the GPU.  Each opens `n` elements starting at element 0 of the given lanes and writes the
     // opened (public) vector to `out`; a failed check panics like the reference's assert.
-    //   SpdzFieldShare::batch_open (share/spdz.rs:166-185): `shares` lane `sh_lane` = sh, lane `sh_lane + 1` = mac
-    void spdz_batch_open(const DeviceLanes& shares, size_t sh_lane, const Fr& mac_share, size_t n, uint64_t* out, bool commit = false) const {
+    //   SpdzFieldShare::batch_open (share/spdz.rs:166-185): `shares` lane `sh_lane` = sh, lane `sh_lane + 1` = mac.  `commit` (the default, as in the
+    //   reference: spdz.rs:179 sends dx_ts through Net::atomic_broadcast, channel.rs:50-75) runs the commit-then-open round; false is an explicit
+    //   opt-out for measurements of the two-round form and must be reported as such
+    void spdz_batch_open(const DeviceLanes& shares, size_t sh_lane, const Fr& mac_share, size_t n, uint64_t* out, bool commit = true) const {
         uint64_t bad = 0;
         check(czk_spdz_batch_open(n_, shares.data(sh_lane), shares.data(sh_lane + 1), mac_share.l, n, out, commit ? CZK_OPEN_COMMIT : 0, &bad));
         if (bad) throw Panic(CZK_ERR_CHECK, "assertion failed: sum.is_zero() (SPDZ MAC check, share/spdz.rs:183) on " + std::to_string(bad) + " values");

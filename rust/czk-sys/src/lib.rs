@@ -60,6 +60,8 @@ extern "C" {
     pub fn czk_ctx_create(out: *mut *mut czk_ctx, device: c_int, hip_stream: *mut c_void) -> c_int;
     pub fn czk_ctx_destroy(ctx: *mut czk_ctx);
     pub fn czk_ctx_sync(ctx: *mut czk_ctx) -> c_int;
+    pub fn czk_ctx_mark(ctx: *mut czk_ctx, out_mark: *mut u64) -> c_int;
+    pub fn czk_ctx_wait_mark(ctx: *mut czk_ctx, mark: u64) -> c_int;
     pub fn czk_ctx_stream(ctx: *const czk_ctx) -> *mut c_void;
     pub fn czk_ctx_reserve(ctx: *mut czk_ctx, ntt_log_d: c_uint, ntt_lanes: usize, bases: *const czk_bases, n_scalars: usize, msm_lanes: usize) -> c_int;
     pub fn czk_last_error(ctx: *const czk_ctx) -> *const c_char;
@@ -73,6 +75,7 @@ extern "C" {
     pub fn czk_lanes_data(l: *const czk_lanes, lane: usize, elem: usize) -> *mut u64;
     pub fn czk_lanes_upload(ctx: *mut czk_ctx, dst: *mut czk_lanes, lane: usize, elem: usize, host: *const u64, n: usize) -> c_int;
     pub fn czk_lanes_download(ctx: *mut czk_ctx, src: *const czk_lanes, lane: usize, elem: usize, host: *mut u64, n: usize) -> c_int;
+    pub fn czk_lanes_download_deferred(ctx: *mut czk_ctx, src: *const czk_lanes, lane: usize, elem: usize, host: *mut u64, n: usize) -> c_int;
     pub fn czk_lanes_copy(ctx: *mut czk_ctx, dst: *mut czk_lanes, dst_lane: usize, dst_elem: usize, src: *const czk_lanes, src_lane: usize, src_elem: usize, n: usize) -> c_int;
     pub fn czk_lanes_zero(ctx: *mut czk_ctx, dst: *mut czk_lanes, lane: usize, elem: usize, n: usize) -> c_int;
     pub fn czk_fr_copy_3d(ctx: *mut czk_ctx, dst: *mut u64, dst_stride: *const usize, src: *const u64, src_stride: *const usize, n: *const usize) -> c_int;

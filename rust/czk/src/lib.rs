@@ -63,6 +63,19 @@ impl Context {
         let rc = unsafe { sys::czk_ctx_sync(self.raw) };
         self.expect(rc, "czk_ctx_sync");
     }
+    /// czk_ctx_mark: names the work enqueued so far (kernels, `msm_async` calls, deferred downloads).
+    pub fn mark(&self) -> u64 {
+        let mut m = 0u64;
+        let rc = unsafe { sys::czk_ctx_mark(self.raw, &mut m) };
+        self.expect(rc, "czk_ctx_mark");
+        m
+    }
+    /// czk_ctx_wait_mark: blocks until the work before `mark` is done and delivers its host results; calls made after the mark keep running
+    /// (a transcript point waits for what the transcript absorbs, not for the next round's challenge-independent work).
+    pub fn wait_mark(&self, mark: u64) {
+        let rc = unsafe { sys::czk_ctx_wait_mark(self.raw, mark) };
+        self.expect(rc, "czk_ctx_wait_mark");
+    }
     /// czk_ctx_reserve: the twiddle tables of a 2^`ntt_log_d` domain (0: none) and the MSM workspaces for calls of `n_scalars` x `msm_lanes`
     /// on a pinned array (null: none), built at key load instead of inside the first proof (first proof 121 -> 77 ms at 2^20 constraints).
     pub fn reserve(&self, ntt_log_d: u32, ntt_lanes: usize, bases: *const sys::czk_bases, n_scalars: usize, msm_lanes: usize) {
@@ -676,6 +689,8 @@ pub mod net {
     pub struct Net {
         raw: *mut sys::czk_net,
     }
+    // A `Net` may move to another thread: every method that reaches the shared context (its stream, its staging buffers, its error string) takes the
+    // `CTX` mutex first, exactly like the transforms and MSMs of this crate; `party_id` / `n_parties` / `stats` only read the communicator's own fields.
     unsafe impl Send for Net {}
 
     /// mpc-net/src/lib.rs `Stats`
@@ -711,10 +726,12 @@ pub mod net {
             Net::create(sys::CZK_NET_IPC, party_id, n_parties, id)
         }
         fn create(transport: c_int, party_id: usize, n_parties: usize, id: &[u8]) -> Net {
-            let ctx = CTX.lock().unwrap();
+            // The rendezvous blocks until every party has arrived (up to the communicator's timeout): the context lock is NOT held across it -- other
+            // threads keep proving.  czk_net_create itself only reads the context's device index (and writes its error string if it fails).
+            let ctx_ptr = { CTX.lock().unwrap().as_ptr() };
             let mut raw: *mut sys::czk_net = std::ptr::null_mut();
-            let rc = unsafe { sys::czk_net_create(ctx.as_ptr(), transport, party_id as c_int, n_parties as c_int, id.as_ptr(), id.len(), &mut raw) };
-            ctx.expect(rc, "czk_net_create");
+            let rc = unsafe { sys::czk_net_create(ctx_ptr, transport, party_id as c_int, n_parties as c_int, id.as_ptr(), id.len(), &mut raw) };
+            CTX.lock().unwrap().expect(rc, "czk_net_create");
             Net { raw }
         }
         fn expect(&self, rc: c_int, what: &str) {
@@ -741,6 +758,7 @@ pub mod net {
         /// `Net::broadcast_bytes` on host bytes (mpc-net/src/lib.rs:44-47)
         pub fn broadcast_bytes(&self, out: &[u8]) -> Vec<Vec<u8>> {
             let mut flat = vec![0u8; out.len() * self.n_parties()];
+            let _ctx = CTX.lock().unwrap();   // the communicator enqueues on the shared context's stream and uses its staging buffers
             let rc = unsafe { sys::czk_net_broadcast(self.raw, out.as_ptr() as *const _, out.len(), flat.as_mut_ptr() as *mut _, sys::CZK_MEM_HOST) };
             self.expect(rc, "czk_net_broadcast");
             flat.chunks(out.len().max(1)).take(self.n_parties()).map(|c| c.to_vec()).collect()
@@ -751,6 +769,7 @@ pub mod net {
             let mut ms = [0u64; 4];
             super::limbs::fr_to(mac_share, &mut ms);
             let mut bad = 0u64;
+            let _ctx = CTX.lock().unwrap();   // the communicator enqueues on the shared context's stream and uses its staging buffers
             let rc = unsafe {
                 sys::czk_spdz_batch_open(self.raw, shares.data(0, 0), shares.data(1, 0), ms.as_ptr(), n, out.data(0, 0),
                                          if commit { sys::CZK_OPEN_COMMIT } else { 0 }, &mut bad)
@@ -760,12 +779,14 @@ pub mod net {
         }
         /// `AdditiveFieldShare::batch_open` (share/add.rs:256-259)
         pub fn add_batch_open(&self, val: &DeviceLanes, n: usize, out: &mut DeviceLanes) {
+            let _ctx = CTX.lock().unwrap();   // the communicator enqueues on the shared context's stream and uses its staging buffers
             let rc = unsafe { sys::czk_add_batch_open(self.raw, val.data(0, 0), n, out.data(0, 0)) };
             self.expect(rc, "czk_add_batch_open");
         }
         /// `GszFieldShare::batch_open` (share/gsz20/mod.rs:286-300) with one degree bound
         pub fn gsz_batch_open(&self, val: &DeviceLanes, n: usize, degree: u32, out: &mut DeviceLanes) {
             let mut bad = 0u64;
+            let _ctx = CTX.lock().unwrap();   // the communicator enqueues on the shared context's stream and uses its staging buffers
             let rc = unsafe { sys::czk_gsz_batch_open(self.raw, val.data(0, 0), n, std::ptr::null(), degree, out.data(0, 0), &mut bad) };
             self.expect(rc, "czk_gsz_batch_open");
             assert!(bad == 0, "assertion failed: p.degree() <= d ({} values)", bad);
@@ -773,6 +794,7 @@ pub mod net {
         /// `gsz20::batch_king_compute(shares, new_degree, |r| r)` (share/gsz20/mod.rs:494-527): the degree reduction inside `batch_mult`
         pub fn gsz_batch_king_compute(&self, val: &DeviceLanes, n: usize, degree: u32, out: &mut DeviceLanes) {
             let mut bad = 0u64;
+            let _ctx = CTX.lock().unwrap();   // the communicator enqueues on the shared context's stream and uses its staging buffers
             let rc = unsafe { sys::czk_gsz_batch_king_compute(self.raw, val.data(0, 0), n, std::ptr::null(), degree, out.data(0, 0), &mut bad) };
             self.expect(rc, "czk_gsz_batch_king_compute");
             assert!(bad == 0, "assertion failed: p.degree() <= d on the king ({} values)", bad);

@@ -39,18 +39,20 @@ def test_no_gpu_means_loud_failure():
     assert czk_amd.lib().czk_ntt_fr(None, None, C.c_uint(3), C.c_size_t(1), 0, C.c_size_t(8), 0) == 3
 
 
-def _build_host_demo():
-    """tools/host_demo.bin, (re)compiled with -Wall when it is older than its sources or the library"""
+def _build_host_demo(lab: bool = False):
+    """tools/host_demo.bin, (re)compiled with -Wall when it is older than its sources or the library.  lab=True: tools/host_demo_lab.bin, the same
+    sources linked against libczk_hip_lab.so (the lab build reads the CZK_* environment switches: tests/test_chaos.py)"""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = os.path.join(root, "tools", "host_demo.bin")
+    out = os.path.join(root, "tools", "host_demo_lab.bin" if lab else "host_demo.bin")
     pkg = os.path.join(root, "collaborative-zksnark_amd")
+    lib = "czk_hip_lab" if lab else "czk_hip"
     deps = [os.path.join(root, "tools", f) for f in ("host_demo.cpp", "groth16_host.hpp", "polyvm_host.hpp")] + \
-           [os.path.join(root, "include", f) for f in ("czk.h", "czk.hpp")] + [os.path.join(pkg, "libczk_hip.so")]
+           [os.path.join(root, "include", f) for f in ("czk.h", "czk.hpp")] + [os.path.join(pkg, f"lib{lib}.so")]
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "host_demo.cpp"),
-                               "-I" + os.path.join(root, "tools"), "-L" + pkg, "-lczk_hip", "-lpthread", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib",
+                               "-I" + os.path.join(root, "tools"), "-L" + pkg, "-l" + lib, "-lpthread", "-Wl,-rpath," + pkg, "-Wl,-rpath,/opt/rocm/lib",
                                "-Wl,-rpath-link,/opt/rocm/lib", "-o", out])
     return out
 

@@ -365,7 +365,7 @@ def _json_tail(proc):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,size,extra", [(2, ["--log-n", "12"], []), (3, ["--log-n", "10"], ["--commit-opens"]), (2, ["--constraints", "1000"], ["--no-tables", "--exchange", "p2p"]),
+@pytest.mark.parametrize("world,size,extra", [(2, ["--log-n", "12"], []), (3, ["--log-n", "10"], ["--no-commit-opens"]), (2, ["--constraints", "1000"], ["--no-tables", "--exchange", "p2p"]),
                                               (3, ["--log-n", "11"], ["--transport", "ipc"])])
 def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, extra):
     """One process per MPC party, each a C++ host over include/czk.hpp whose opens run through czk::Net (SHM transport: the processes
@@ -383,7 +383,8 @@ def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, e
                                           capture_output=True, text=True, timeout=600, env=env))
     assert cpp_party["layout"] == "party" and cpp_party["parties"] == world and cpp_party["share_lanes_per_process"] == 2
     # 2 opens per proof, each one broadcast of the sh lane + one (atomic: two) of dx_t -- the reference's message count (spdz.rs:166-185)
-    per_open = 3 if "--commit-opens" in extra else 2
+    per_open = 2 if "--no-commit-opens" in extra else 3   # commit-then-open is the default, as in the reference (spdz.rs:179)
+    assert cpp_party["commit_opens"] == ("--no-commit-opens" not in extra)
     assert cpp_party["king_net_stats"]["broadcasts"] == 2 * 2 * per_open
     cpp_one = _json_tail(subprocess.run([exe, "bench", "--parties", str(world), "--steps", "2", "--warmup", "1"] + size + tables,
                                         capture_output=True, text=True, timeout=600, env=env))
@@ -394,7 +395,7 @@ def test_cpp_party_layout_yields_the_digest_of_every_other_layout(world, size, e
     # (d) the Python host in the party layout with the opens through the SAME communicator calls the C++ host makes (bench.py --net czk:
     # parallel.use_net; shared-memory transport, torch.distributed only carries the communicator id)
     py_party_czk = _json_tail(__import__('util').run_ranks([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--layout", "party", "--backend", "gloo", "--device", "0",
-                                              "--net", "czk"] + common + (["--commit-opens"] if "--commit-opens" in extra else []),
+                                              "--net", "czk"] + common + (["--no-commit-opens"] if "--no-commit-opens" in extra else []),
                                              capture_output=True, text=True, timeout=600, env=env, cwd=ROOT))
     assert py_one["results_checked"] and py_party["results_checked"] and py_party_czk["results_checked"]
     assert py_party["net"] == "torch.distributed" and py_party_czk["net"] == "czk_net shm"

@@ -173,7 +173,7 @@ class Groth16Host {
     // party and a czk::Net this is the reference's own layout -- one process per party (mpc-net/src/multi.rs:15-23) -- and the two opens
     // of the witness map run SpdzFieldShare::batch_open's two broadcast rounds through the communicator, on lanes that stay in HBM.
     Groth16Host(const czk::Context& c, size_t n_constraints, size_t parties, uint64_t seed = 0xC0FFEE, bool no_tables = false,
-                std::vector<size_t> local_parties = {}, const czk::Net* net = nullptr, bool commit_opens = false, const KeyScalars* key = nullptr)
+                std::vector<size_t> local_parties = {}, const czk::Net* net = nullptr, bool commit_opens = true, const KeyScalars* key = nullptr)
         : ctx(c), N(n_constraints), P(parties), net_(net), commit_opens_(commit_opens) {
         auto t0 = std::chrono::steady_clock::now();
         if (local_parties.empty())
@@ -382,7 +382,7 @@ class Groth16Host {
     }
 
     const czk::Net* net_ = nullptr;
-    bool commit_opens_ = false;
+    bool commit_opens_ = true;   // Net::atomic_broadcast(&dx_ts) as in the reference (spdz.rs:179); false = the measured opt-out
     std::vector<size_t> local_;
     Fr mac_share_{};
     std::vector<uint64_t> pk_g1_, pk_g2_;

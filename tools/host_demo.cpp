@@ -209,7 +209,7 @@ static int bench(const Context& ctx, int argc, char** argv) {
 }
 
 // `host_demo.bin party --rank R --world W --id HEX [--transport shm|rccl] [--device D] [--log-n K | --constraints N] [--steps K]
-// [--warmup W] [--no-tables] [--commit-opens] [--exchange ring|p2p]`: ONE MPC party of the reference's own layout -- one process per
+// [--warmup W] [--no-tables] [--no-commit-opens] [--exchange ring|p2p]`: ONE MPC party of the reference's own layout -- one process per
 // party (mpc-net/src/multi.rs:15-23) -- as a compiled host: party R's two share lanes on this process's GPU, the two opens of every
 // witness map as SpdzFieldShare::batch_open through czk::Net (RCCL between GPUs; shared memory when the parties share a GPU), nothing
 // leaves HBM except the proof's group elements.  Rank 0 prints one JSON line whose results_sha256 covers ALL parties' elements in
@@ -218,7 +218,7 @@ static int bench(const Context& ctx, int argc, char** argv) {
 static int party(int argc, char** argv) {
     size_t n = (size_t)1 << 20, steps = 4, warmup = 1;
     int rank = -1, world = 0, device = -1, transport = CZK_NET_SHM, exchange = 0;
-    bool no_tables = false, commit = false;
+    bool no_tables = false, commit = true;   // dx_ts through atomic_broadcast, as the reference does (spdz.rs:179); --no-commit-opens is the reported opt-out
     std::vector<uint8_t> id;
     for (int i = 2; i < argc; i++) {
         auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
@@ -234,6 +234,7 @@ static int party(int argc, char** argv) {
         else if (!strcmp(argv[i], "--exchange")) exchange = !strcmp(val(), "p2p") ? 1 : 0;
         else if (!strcmp(argv[i], "--no-tables")) no_tables = true;
         else if (!strcmp(argv[i], "--commit-opens")) commit = true;
+        else if (!strcmp(argv[i], "--no-commit-opens")) commit = false;
         else { printf("unknown argument %s\n", argv[i]); return 2; }
     }
     if (rank < 0 || world < 2 || rank >= world || id.empty() || n < 2 || steps < 1) { printf("party: need --rank, --world >= 2, --id\n"); return 2; }
@@ -344,10 +345,19 @@ static int polyiop(const char* workload, int argc, char** argv) {
     double arena_gb = 0;
     const char* dump = nullptr;
     int rank = -1, world = 0, transport = CZK_NET_SHM, device = 0;
+    bool commit_opens = true;
+    std::vector<std::pair<std::string, long>> ctx_options;
     std::vector<uint8_t> id;
     for (int i = 2; i < argc; i++) {
         auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
         if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
+        else if (!strcmp(argv[i], "--no-commit-opens")) commit_opens = false;
+        else if (!strcmp(argv[i], "--ctx-option")) {   // NAME=VALUE: czk_ctx_set_option on every context before its first MSM (repeatable)
+            const std::string kv = val();
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos) { printf("--ctx-option wants NAME=VALUE\n"); return 2; }
+            ctx_options.emplace_back(kv.substr(0, eq), atol(kv.c_str() + eq + 1));
+        }
         else if (!strcmp(argv[i], "--rank")) rank = atoi(val());
         else if (!strcmp(argv[i], "--world")) world = atoi(val());
         else if (!strcmp(argv[i], "--id")) id = unhex(val());
@@ -422,12 +432,14 @@ static int polyiop(const char* workload, int argc, char** argv) {
     std::unique_ptr<Net> net;
     for (size_t k = 0; k < inflight; k++) {
         provers[k].ctx.reset(new Context(device));
+        for (auto& o : ctx_options) provers[k].ctx->check(czk_ctx_set_option(provers[k].ctx->raw(), o.first.c_str(), o.second));
         provers[k].B.reset(new pvm::Machine(*provers[k].ctx, lanes, max_deg, lift, arena_elems, k ? provers[0].B->srs : nullptr));
         if (party) {
             net.reset(new Net(*provers[0].ctx, transport, rank, world, id));
             pvm::Machine& M = *provers[0].B;
             M.net = net.get();
             M.net_gsz = plonk;
+            M.commit_opens = commit_opens;
             M.gsz_degree = (unsigned)((parties - 1) / 2);              // t = (n - 1) / 2 (share/gsz20/mod.rs:94-96)
             M.mac_share = rank == 0 ? pvm::fr_one() : pvm::fr_zero();   // mac_share() = 1 on the king, 0 elsewhere (share/spdz.rs:30-37)
         }
@@ -493,11 +505,11 @@ static int polyiop(const char* workload, int argc, char** argv) {
     printf("{\"harness\": \"tools/host_demo.cpp %s (C++ over include/czk.h: tools/polyvm_host.hpp; no torch, no Python)\", \"workload\": \"%s\", \"constraints\": %zu, "
            "\"parties\": %zu, \"layout\": \"%s\", \"transport\": \"%s\", \"share_lanes\": %zu, \"steps\": %zu, \"warmup\": %zu, \"proofs_in_flight\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, "
            "\"latency_ms_single_proof\": %.3f, \"first_proof_ms\": %.3f, \"setup_s\": %.3f, \"msms_per_proof\": %.1f, \"ntt_lanes_per_proof\": %.1f, "
-           "\"arena_peak_gb\": %.2f, \"in_flight_provers_equal\": true, \"output_sha256\": \"%s\"}\n",
+           "\"arena_peak_gb\": %.2f, \"commit_opens\": %s, \"in_flight_provers_equal\": true, \"output_sha256\": \"%s\"}\n",
            workload, workload, n, parties, party ? "party (one process per party, evaluations opened through czk_net)" : "one process",
            party ? transport_name(transport) : "none", lanes, steps, warmup,
            inflight, dt / steps * 1e3, steps / dt, alone_ms, first_ms, setup_s, (double)msms / steps,
-           (double)ntts / steps, provers[0].B->arena_peak_bytes() / 1e9, hex(digest, 32).c_str());
+           (double)ntts / steps, provers[0].B->arena_peak_bytes() / 1e9, (party && !plonk) ? (commit_opens ? "true" : "false") : "null", hex(digest, 32).c_str());
     if (net) {
         provers[0].B->net = nullptr;
         net.reset();   // the communicator goes before its context

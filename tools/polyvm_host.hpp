@@ -18,6 +18,7 @@
 #pragma once
 #include <algorithm>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -166,6 +167,19 @@ struct Output {       // everything a prover publishes, in the reference's order
     std::vector<std::pair<std::string, std::vector<ValueP>>> evals;
 };
 
+// A transcript point in two halves (Machine::mark / Machine::settle): `mark` names what the reference's transcript has absorbed so far -- the commitments and
+// evaluations enqueued up to here; `settle` waits for exactly that (czk_ctx_wait_mark) before the next challenge is drawn.  Whatever the prover enqueues between the
+// two -- work that depends on no pending challenge -- runs through the wait.
+struct Mark {
+    uint64_t id = 0;
+    std::vector<CommitmentP> cmts;
+    std::vector<ValueP> vals;
+    std::vector<Fr> host;     // the evaluation rows [row0, row0 + host.size()) on their way down (czk_lanes_download_deferred)
+    size_t row0 = 0;
+    bool settled = false;
+};
+using MarkP = std::shared_ptr<Mark>;
+
 // ---- the polynomial machine (polyvm.GpuBackend) -----------------------------------------------------------------------------------
 struct Srs {          // powers_of_g = [tau^i] G and powers_of_gamma_g = [gamma tau^i] G for FIXED, KNOWN tau / gamma (polyvm.py GpuBackend.__init__)
     std::unique_ptr<czk::G1Bases> g, gamma;
@@ -183,6 +197,7 @@ class Machine {
     // ONE batch_open -- GszFieldShare::batch_open (lanes = 1) or SpdzFieldShare::batch_open (lanes = 2: sh, mac) -- on values that stay in HBM
     const czk::Net* net = nullptr;
     bool net_gsz = false;
+    bool commit_opens = true;                  // SPDZ: dx_ts through Net::atomic_broadcast, as the reference does (share/spdz.rs:179, channel.rs:50-75)
     unsigned gsz_degree = 0;
     Fr mac_share{};
     std::vector<std::vector<Fr>> opened;       // what the opens returned, in order (reset by the caller per proof)
@@ -460,7 +475,8 @@ class Machine {
         CommitmentP c = std::make_shared<Commitment>();
         c->jac.resize(a.lanes);
         c->keep = a;
-        ctx.check(czk_msm_async(ctx.raw(), bases.raw(), a.p(), a.n, a.lanes, CZK_SCALAR_MONTGOMERY, CZK_MEM_DEVICE, c->jac[0].x.l));
+        // CZK_MEM_STABLE: `keep` holds the scalars until the commitment is settled, so the context's stream need not wait for the digit extraction
+        ctx.check(czk_msm_async(ctx.raw(), bases.raw(), a.p(), a.n, a.lanes, CZK_SCALAR_MONTGOMERY, CZK_MEM_DEVICE | CZK_MEM_STABLE, c->jac[0].x.l));
         msm_count += a.lanes;
         msm_points += a.lanes * a.n;
         pending_cmts_.push_back(c);
@@ -471,7 +487,7 @@ class Machine {
         czk::G1Bases& bases = *srs->gamma;
         c->jac2.resize(blind.lanes);
         c->keep2 = blind;
-        ctx.check(czk_msm_async(ctx.raw(), bases.raw(), blind.p(), blind.n, blind.lanes, CZK_SCALAR_MONTGOMERY, CZK_MEM_DEVICE, c->jac2[0].x.l));
+        ctx.check(czk_msm_async(ctx.raw(), bases.raw(), blind.p(), blind.n, blind.lanes, CZK_SCALAR_MONTGOMERY, CZK_MEM_DEVICE | CZK_MEM_STABLE, c->jac2[0].x.l));
         msm_count += blind.lanes;
         msm_points += blind.lanes * blind.n;
         return c;
@@ -491,11 +507,40 @@ class Machine {
     }
     Opening open_at(const Arr& a, const Fr& x, int pub = -1) { return open_finish(open_begin(a, x, pub)); }
     // Where the reference feeds commitments / evaluations to its Fiat-Shamir transcript before drawing the next challenge: everything committed
-    // or evaluated so far must be final.
+    // or evaluated SO FAR IN THE REFERENCE'S ORDER must be final.  mark() at that place in the sequence, settle() before the challenge is used; a
+    // prover with nothing to enqueue in between calls transcript_point().
+    MarkP mark() {
+        MarkP m = std::make_shared<Mark>();
+        m->cmts.swap(pending_cmts_);
+        m->vals.swap(pending_vals_);
+        if (vals_at_ > vals_done_) {   // one copy: every slot handed out since the last mark, delivered with the mark
+            m->row0 = vals_done_;
+            m->host.resize(vals_at_ - vals_done_);
+            vals_.download_deferred(0, vals_done_, m->host.data(), m->host.size());
+            vals_done_ = vals_at_;
+        }
+        m->id = ctx.mark();
+        marks_.push_back(m);
+        if (net) settle(m);   // one party per process: the evaluations are opened over the communicator here, in the reference's batches
+        return m;
+    }
+    void settle(const MarkP& upto) {
+        while (!marks_.empty() && !upto->settled) {
+            MarkP m = marks_.front();
+            marks_.pop_front();
+            settle_one(*m);
+        }
+        if (marks_.empty() && pending_cmts_.empty() && pending_vals_.empty()) vals_at_ = vals_done_ = 0;   // nothing refers to the evaluation buffer any more
+    }
     void transcript_point() {
-        if (pending_cmts_.empty() && pending_vals_.empty()) return;
-        ctx.sync();
-        for (CommitmentP& c : pending_cmts_) {
+        if (pending_cmts_.empty() && pending_vals_.empty() && marks_.empty()) return;
+        settle(mark());
+    }
+
+  private:
+    void settle_one(Mark& m) {
+        ctx.wait_mark(m.id);
+        for (CommitmentP& c : m.cmts) {
             const size_t L = c->jac.size();
             c->aff.resize(12 * L);
             c->inf.resize(L);
@@ -515,50 +560,47 @@ class Machine {
             c->keep = c->keep2 = Arr();
             c->settled = true;
         }
-        if (vals_at_) {
-            std::vector<Fr> host(vals_at_);
-            vals_.download(0, 0, host.data(), vals_at_);   // one copy: every slot handed out since the last settle
-            std::vector<ValueP> to_open;
-            for (ValueP& v : pending_vals_) {
-                v->v.assign(host.begin() + v->slot, host.begin() + v->slot + v->lanes);
-                v->settled = true;
-                if (v->open) to_open.push_back(v);
-            }
-            if (net && !to_open.empty()) {
-                // `y.publicize()` of every evaluation made since the last challenge, as ONE batch_open over the parties: lane j of the k values
-                // gathered into k contiguous elements (k is a few dozen), the open on the communicator, the opened vector to the host
-                const size_t k = to_open.size();
-                Arr sh = alloc(1, k), mac = alloc(1, k), res = alloc(1, k);
-                const size_t one3[3] = {1, 1, 1}, st[3] = {0, 0, 1};
-                for (size_t i = 0; i < k; i++) {
-                    if (to_open[i]->lanes != lanes) throw czk::Panic(CZK_ERR_ARG, "pvm: an opened value must have one element per local lane");
-                    ctx.check(czk_fr_copy_3d(ctx.raw(), sh.p() + 4 * i, st, vals_.data(0, to_open[i]->slot), st, one3));
-                    if (!net_gsz) ctx.check(czk_fr_copy_3d(ctx.raw(), mac.p() + 4 * i, st, vals_.data(0, to_open[i]->slot + 1), st, one3));
-                }
-                if (net_gsz) net->gsz_batch_open(sh.p(), k, gsz_degree, res.p());
-                else {
-                    uint64_t bad = 0;
-                    net->check(czk_spdz_batch_open(net->raw(), sh.p(), mac.p(), mac_share.l, k, res.p(), 0, &bad));
-                    if (bad) throw czk::Panic(CZK_ERR_CHECK, "assertion failed: sum.is_zero() (SPDZ MAC check, share/spdz.rs:183)");
-                }
-                const size_t kk[3] = {1, 1, k};
-                ctx.check(czk_fr_copy_3d(ctx.raw(), down_.data(), st, res.p(), st, kk));
-                std::vector<Fr> got(k);
-                down_.download(0, 0, got.data(), k);
-                opened.push_back(got);
-            }
+        std::vector<ValueP> to_open;
+        for (ValueP& v : m.vals) {
+            const Fr* at = m.host.data() + (v->slot - m.row0);
+            v->v.assign(at, at + v->lanes);
+            v->settled = true;
+            if (v->open) to_open.push_back(v);
         }
-        pending_cmts_.clear();
-        pending_vals_.clear();
-        vals_at_ = 0;
+        if (net && !to_open.empty()) {
+            // `y.publicize()` of every evaluation made since the last challenge, as ONE batch_open over the parties: lane j of the k values
+            // gathered into k contiguous elements (k is a few dozen), the open on the communicator, the opened vector to the host
+            const size_t k = to_open.size();
+            Arr sh = alloc(1, k), mac = alloc(1, k), res = alloc(1, k);
+            const size_t one3[3] = {1, 1, 1}, st[3] = {0, 0, 1};
+            for (size_t i = 0; i < k; i++) {
+                if (to_open[i]->lanes != lanes) throw czk::Panic(CZK_ERR_ARG, "pvm: an opened value must have one element per local lane");
+                ctx.check(czk_fr_copy_3d(ctx.raw(), sh.p() + 4 * i, st, vals_.data(0, to_open[i]->slot), st, one3));
+                if (!net_gsz) ctx.check(czk_fr_copy_3d(ctx.raw(), mac.p() + 4 * i, st, vals_.data(0, to_open[i]->slot + 1), st, one3));
+            }
+            if (net_gsz) net->gsz_batch_open(sh.p(), k, gsz_degree, res.p());
+            else {
+                uint64_t bad = 0;
+                net->check(czk_spdz_batch_open(net->raw(), sh.p(), mac.p(), mac_share.l, k, res.p(), commit_opens ? CZK_OPEN_COMMIT : 0, &bad));
+                if (bad) throw czk::Panic(CZK_ERR_CHECK, "assertion failed: sum.is_zero() (SPDZ MAC check, share/spdz.rs:183)");
+            }
+            const size_t kk[3] = {1, 1, k};
+            ctx.check(czk_fr_copy_3d(ctx.raw(), down_.data(), st, res.p(), st, kk));
+            std::vector<Fr> got(k);
+            down_.download(0, 0, got.data(), k);
+            opened.push_back(got);
+        }
+        m.cmts.clear();
+        m.vals.clear();
+        m.settled = true;
     }
 
-  private:
     Arena arena_;
     czk::DeviceLanes vals_, stage_, down_;   // evaluation buffer; upload staging (16 MiB); opened values on their way to the host
-    size_t vals_at_ = 0;
+    size_t vals_at_ = 0, vals_done_ = 0;   // evaluation rows handed out / already on their way to the host
     std::vector<CommitmentP> pending_cmts_;
     std::vector<ValueP> pending_vals_;
+    std::deque<MarkP> marks_;                // taken, not yet settled (oldest first)
 };
 
 static const Fr GENERATOR = fr_u64(22);   // Fr::multiplicative_generator() (fr.rs:69-74)
@@ -592,21 +634,31 @@ inline Output plonk_prove(Machine& B, const PlonkInputs& inp) {
         if (of) o.of = of;
         out.openings.emplace_back(label, std::move(o));
     };
+    // Schedule: the statements below are the reference's, and every commitment / opening lands in `out` in the reference's order; what moves is WHEN a
+    // statement is enqueued.  A transcript point waits for what the transcript has absorbed (B.mark() at that place, B.settle() before the challenge is
+    // used); statements that depend on no pending challenge are enqueued between the two and run through the wait, so the accumulate kernels of the
+    // commitments being settled share the GPU with the next statements' transforms and the MSM queue does not run dry at the drain.
     commit("p", p);                                                    // :434-441
     // prove_public (:259-292) with one public wire: v = p(x_pub) constant, z = X - x_pub, q = (p - v) / z
     Arr q_pub = B.quotient(p, w);
     commit("pub_q", q_pub);
-    B.transcript_point();
-    Fr x = challenge("plonk.public.x");
-    open_("pub_q_open", q_pub, x, "pub_q");
-    open_("pub_p_open", p, x, "p");
-    // prove_gates (:295-340): d = s (p + pw) + (1 - s)(p pw) - pww, q = d / v_gates
+    MarkP tp = B.mark();                                               // transcript: p, pub_q
+    // prove_gates (:295-340): d = s (p + pw) + (1 - s)(p pw) - pww, q = d / v_gates -- no challenge enters: enqueued ahead of the first one
     Arr pw = B.shift(p, w), pww = B.shift(p, ww);
     Arr one_minus_s = B.poly_add_const(B.scale(s_pub, fr_neg(fr_one())), fr_one());   // public: `&(&circ.s * &-F::one()) + &F::one()` (:307-308)
     Arr d = B.sub(B.padded_add(B.poly_mul(s_pub, B.add(p, pw)), B.poly_mul(one_minus_s, B.poly_mul(p, pw))), B.resized(pww, G + 2 * W - 2));
     Arr q_gates = B.div_vanishing(d, G).first;
-    commit("gates_q", q_gates);
-    B.transcript_point();
+    pw = pww = one_minus_s = d = Arr();
+    CommitmentP gates_cmt = B.commit(q_gates);
+    B.settle(tp);
+    Fr x = challenge("plonk.public.x");
+    open_("pub_q_open", q_pub, x, "pub_q");
+    open_("pub_p_open", p, x, "p");
+    out.commitments.emplace_back("gates_q_cmt", gates_cmt);
+    tp = B.mark();                                                     // transcript: + the two openings, gates_q
+    // prove_wiring's evaluations of p and w over the wire domain (:207-211) depend on no challenge either
+    Arr p_evals = B.ntt(p, W, FFT), w_evals = B.ntt(w_pub, W, FFT);
+    B.settle(tp);
     x = challenge("plonk.gates.x");
     open_("gates_s_open", s_pub, x, nullptr);
     open_("gates_p_open", p, x, "p");
@@ -616,7 +668,6 @@ inline Output plonk_prove(Machine& B, const PlonkInputs& inp) {
     // prove_wiring (:201-257) over the wire domain
     B.transcript_point();
     const Fr y = challenge("plonk.wiring.y"), z = challenge("plonk.wiring.z");
-    Arr p_evals = B.ntt(p, W, FFT), w_evals = B.ntt(w_pub, W, FFT);
     Arr yx_z = B.ntt(B.upload({z, y}, 1, 2), W, FFT);
     Arr num_evals = B.add_const(B.plus(p_evals, B.scale(w_evals, y)), z);
     Arr den_evals = B.plus(p_evals, yx_z);
@@ -629,18 +680,20 @@ inline Output plonk_prove(Machine& B, const PlonkInputs& inp) {
     Arr f_c = B.ntt(B.shift(l1, w), W, COSET_FFT), t_c = B.ntt(t, W, COSET_FFT), tw_c = B.ntt(B.shift(t, w), W, COSET_FFT);
     Arr q_up = B.ntt(B.scale(B.sub(tw_c, B.mul(f_c, t_c)), zinv_w), W, COSET_IFFT);
     commit("q", q_up);
-    B.transcript_point();
+    tp = B.mark();                                                     // transcript: l1, t, q
+    // l2_q (:228-243) depends on y and z only: enqueued ahead of the product argument's challenge r
+    Arr num_c = B.ntt(num_evals, W, IFFT), den_c = B.ntt(den_evals, W, IFFT);   // interpolate() of both before the coset transforms (:225-226)
+    Arr l1_v = B.ntt(l1, W, COSET_FFT), num_v = B.ntt(num_c, W, COSET_FFT), den_v = B.ntt(den_c, W, COSET_FFT);
+    Arr l2_q = B.ntt(B.scale(B.sub(B.mul(l1_v, den_v), num_v), zinv_w), W, COSET_IFFT);
+    CommitmentP l2_cmt = B.commit(l2_q);
+    B.settle(tp);
     const Fr r = challenge("plonk.product.r");
     open_("t_wr_open", t, fr_mul(w, r), "t");
     open_("t_r_open", t, r, "t");
     open_("t_wk_open", t, fr_pow(w, W - 1), "t");
     open_("f_wr_open", l1, fr_mul(w, r), "l1");
     open_("q_r_open", q_up, r, "q");
-    // l2_q (:228-243)
-    Arr num_c = B.ntt(num_evals, W, IFFT), den_c = B.ntt(den_evals, W, IFFT);   // interpolate() of both before the coset transforms (:225-226)
-    Arr l1_v = B.ntt(l1, W, COSET_FFT), num_v = B.ntt(num_c, W, COSET_FFT), den_v = B.ntt(den_c, W, COSET_FFT);
-    Arr l2_q = B.ntt(B.scale(B.sub(B.mul(l1_v, den_v), num_v), zinv_w), W, COSET_IFFT);
-    commit("l2_q", l2_q);
+    out.commitments.emplace_back("l2_q_cmt", l2_cmt);
     B.transcript_point();
     x = challenge("plonk.wiring.x");
     open_("l2_q_x_open", l2_q, x, "l2_q");
@@ -708,58 +761,76 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
         return (uint64_t)0xB11D + s;
     };
     // marlin_pc::commit -> KZG10::commit (kzg10/mod.rs:141-192); a hiding bound of Some(1) samples a blinding polynomial of degree 2, commits it over
-    // powers_of_gamma_g (:181-186) and adds the two commitments (:188)
-    auto commit = [&](const std::string& label, const Arr& a, bool hiding) {
+    // powers_of_gamma_g (:181-186) and adds the two commitments (:188).  enqueue() starts the MSMs, publish() lists the commitment in the reference's order.
+    auto enqueue = [&](const std::string& label, const Arr& a, bool hiding) {
         CommitmentP c = B.commit(a);
         if (hiding) {
             blind[label] = B.shared_copy(B.random(label_seed(label), 3));
             c = B.commit_sum(c, blind[label]);
         }
-        out.commitments.emplace_back(label + "_cmt", c);
+        return c;
     };
+    auto publish = [&](const std::string& label, const CommitmentP& c) { out.commitments.emplace_back(label + "_cmt", c); };
+    auto commit = [&](const std::string& label, const Arr& a, bool hiding) { publish(label, enqueue(label, a, hiding)); };
     // a + rand v_H: the zk blinding of the first-round polynomials (prover.rs:359-374), the blinding scalar a fixed constant
     auto mask = [&](const Arr& a, const char* tag, size_t n_dom) {
         const Fr rr = challenge(std::string("marlin.blind.") + tag);
         Arr bump = B.concat({B.constant(fr_neg(rr), 1), B.zeros(1, n_dom - 1), B.constant(rr, 1)});   // rr X^n - rr
         return B.plus(B.resized(a, n_dom + 1), bump);
     };
+    // Schedule (see plonk_prove): statements and the order of `out` are the reference's; a statement is ENQUEUED as soon as the challenges it depends on are
+    // known, and a transcript point waits for what the transcript has absorbed (mark / settle).
     // ---- first round (prover.rs:300-398) --------------------------------------------------------------------------------------------
+    const Arr& mask_poly = inp.mask_poly;
+    CommitmentP mask_cmt = enqueue("mask_poly", mask_poly, false);      // an input: its MSM runs while the round's other polynomials are interpolated
     Arr x_poly = B.ntt(inp.x, X, IFFT);                                  // public input polynomial (:324-330)
     Arr x_evals = B.ntt(x_poly, H, FFT);
     Arr w_poly = B.ntt(B.minus(inp.w, x_evals), H, IFFT);               // witness minus x on H, interpolated (:343-356)
     w_poly = B.div_vanishing(mask(w_poly, "w", H), X).first;            // / v_X (:357)
-    Arr z_a = mask(B.ntt(inp.z_a, H, IFFT), "za", H), z_b = mask(B.ntt(inp.z_b, H, IFFT), "zb", H);
-    const Arr& mask_poly = inp.mask_poly;
     commit("w", w_poly, true);                                           // hiding bounds Some(1), Some(1), Some(1), None (:386-390)
+    Arr z_a = mask(B.ntt(inp.z_a, H, IFFT), "za", H);
     commit("z_a", z_a, true);
+    Arr z_b = mask(B.ntt(inp.z_b, H, IFFT), "zb", H);
     commit("z_b", z_b, true);
-    commit("mask_poly", mask_poly, false);
-    // ---- second round (:439-556) -----------------------------------------------------------------------------------------------------
-    B.transcript_point();
-    const Fr alpha = challenge("marlin.alpha"), eta_a = challenge("marlin.eta_a"), eta_b = challenge("marlin.eta_b"), eta_c = challenge("marlin.eta_c");
+    publish("mask_poly", mask_cmt);
+    MarkP tp = B.mark();                                                 // transcript: the first round's four commitments
+    // ---- second round (:439-556); what depends on no challenge comes first -------------------------------------------------------------
     Arr z_c = B.poly_mul(z_a, z_b);                                     // shared x shared (:466)
-    Arr summed = B.padded_add(B.scale(z_c, eta_c), B.add(B.scale(z_a, eta_a), B.scale(z_b, eta_b)));   // (:468-476)
-    // r(alpha, X) on H, unnormalised bivariate Lagrange: (alpha^|H| - 1) / (alpha - h^i)  (:480-482), public
     Arr hpow = B.powers(B.root_of_unity(H), H);
-    Arr r_alpha_evals = B.scale(B.inverse(B.add_const(B.scale(hpow, fr_neg(fr_one())), alpha)), vanishing(H, alpha));
-    Arr r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT);
-    Arr t_poly = B.ntt(B.mul(inp.t_rows, r_alpha_evals), H, IFFT);      // calculate_t (:400-416)
     x_poly = B.ntt(inp.x, X, IFFT);                                      // interpolated again in the second round (:503-507)
     Arr z_poly = B.padded_add(mul_by_vanishing(B, w_poly, X), x_poly);  // w v_X + x (:512-517)
-    const size_t n_rhs = std::max(r_alpha_poly.n + summed.n, t_poly.n + z_poly.n) - 1;
+    const size_t summed_n = std::max(z_c.n, std::max(z_a.n, z_b.n));
+    const size_t n_rhs = std::max(H + summed_n, H + z_poly.n) - 1;      // r_alpha_poly and t_poly have |H| coefficients
     const size_t mul_size = next_pow2(std::max(mask_poly.n, n_rhs + 1));   // GeneralEvaluationDomain::new(max(..)) (:522-531)
     auto ev = [&](const Arr& a) { return B.ntt(a, mul_size, FFT); };
-    Arr rhs = B.resized(B.ntt(B.sub(B.mul(ev(r_alpha_poly), ev(summed)), B.mul(ev(z_poly), ev(t_poly))), mul_size, IFFT), n_rhs);
+    Arr z_poly_ev = ev(z_poly);
+    B.settle(tp);
+    const Fr alpha = challenge("marlin.alpha"), eta_a = challenge("marlin.eta_a"), eta_b = challenge("marlin.eta_b"), eta_c = challenge("marlin.eta_c");
+    // r(alpha, X) on H, unnormalised bivariate Lagrange: (alpha^|H| - 1) / (alpha - h^i)  (:480-482), public
+    Arr r_alpha_evals = B.scale(B.inverse(B.add_const(B.scale(hpow, fr_neg(fr_one())), alpha)), vanishing(H, alpha));
+    Arr t_poly = B.ntt(B.mul(inp.t_rows, r_alpha_evals), H, IFFT);      // calculate_t (:400-416)
+    commit("t", t_poly, false);                                          // hiding bounds None, Some(1), None (:558-560)
+    Arr r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT);
+    Arr summed = B.padded_add(B.scale(z_c, eta_c), B.add(B.scale(z_a, eta_a), B.scale(z_b, eta_b)));   // (:468-476)
+    if (summed.n != summed_n || std::max(r_alpha_poly.n + summed.n, t_poly.n + z_poly.n) - 1 != n_rhs) throw czk::Panic(CZK_ERR_ARG, "pvm: marlin second-round sizes");
+    Arr rhs = B.resized(B.ntt(B.sub(B.mul(ev(r_alpha_poly), ev(summed)), B.mul(z_poly_ev, ev(t_poly))), mul_size, IFFT), n_rhs);
     Arr q_1 = B.padded_add(mask_poly, rhs);
     auto hx = B.div_vanishing(q_1, H);
     Arr h_1 = hx.first, g_1 = B.drop_first(hx.second, 1);
-    commit("t", t_poly, false);                                          // hiding bounds None, Some(1), None (:558-560)
+    z_c = hpow = z_poly_ev = summed = rhs = q_1 = r_alpha_evals = Arr();
     commit("g_1", g_1, true);
     commit("g_1_shifted", g_1, true);                                    // the degree bound's second commitment over the shifted powers, own blinding (marlin_pc/mod.rs:218-232)
     commit("h_1", h_1, false);
     // ---- third round (:585-704): everything public -----------------------------------------------------------------------------------
     B.transcript_point();
     const Fr beta = challenge("marlin.beta");
+    // the witness of g_1's degree-bound opening at beta and the witness of its shifted randomness (marlin_pc/mod.rs:294-299 -> kzg10/mod.rs:200-224; used by
+    // batch_open below) depend on beta alone: their MSM runs while the third round's public polynomials are computed
+    Opening sh_beta = B.open_begin(g_1, beta), sh_rand_beta;
+    const bool has_rand_beta = blind.count("g_1_shifted") != 0;
+    if (has_rand_beta) sh_rand_beta = B.open_begin(blind["g_1_shifted"], beta);
+    sh_beta = B.open_finish(std::move(sh_beta));
+    if (has_rand_beta) sh_beta.proof = B.commit_sum(sh_beta.proof, sh_rand_beta.wit);
     const Fr vh = fr_mul(vanishing(H, alpha), vanishing(H, beta));
     const Fr etas[3] = {eta_a, eta_b, eta_c};
     const Fr minus_one = fr_neg(fr_one());
@@ -776,6 +847,8 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
     }
     Arr f = B.ntt(B.scale(f_evals, vh), K, IFFT);
     Arr g_2 = B.drop_first(f, 1);
+    commit("g_2", g_2, false);
+    commit("g_2_shifted", g_2, false);                                   // degree bound |K| - 2
     Arr a_on_b;
     const int others[3][2] = {{1, 2}, {0, 2}, {0, 1}};
     for (int m = 0; m < 3; m++) {
@@ -786,12 +859,9 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
     Arr b_poly = B.resized(B.ntt(B.mul(den_b[0], B.mul(den_b[1], den_b[2])), b_size, IFFT), 3 * K - 2);
     Arr bf = B.poly_mul(b_poly, f);
     Arr h_2 = B.div_vanishing(B.sub(B.resized(a_poly, bf.n), bf), K).first;   // (a - b f) / v_K (:693-696)
-    commit("g_2", g_2, false);
-    commit("g_2_shifted", g_2, false);                                   // degree bound |K| - 2
     commit("h_2", h_2, false);
     // ---- evaluations and openings (marlin/src/lib.rs:262-318) -------------------------------------------------------------------------
-    B.transcript_point();
-    const Fr gamma = challenge("marlin.gamma");
+    tp = B.mark();                                                       // transcript: the third round's commitments
     std::map<std::string, Arr> polys = {{"w", w_poly}, {"z_a", z_a}, {"z_b", z_b}, {"mask_poly", mask_poly}, {"t", t_poly},
                                         {"g_1", g_1},  {"h_1", h_1}, {"g_2", g_2}, {"h_2", h_2}};
     const char* mats[3] = {"a", "b", "c"};
@@ -817,29 +887,49 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
         const std::string m = mats[i];
         lcs[m + "_denom"] = {{fr_neg(alpha), m + "_row"}, {fr_neg(beta), m + "_col"}, {one, m + "_row_col"}};
     }
-    std::map<std::string, Fr> point = {{"beta", beta}, {"gamma", gamma}};
+    std::map<std::string, Fr> point = {{"beta", beta}};
     // verifier_query_set (ahp/verifier.rs:143-146, 207-211), labels in BTreeSet order
     std::map<std::string, std::vector<std::string>> query = {{"beta", {"g_1", "outer_sumcheck", "t", "z_b"}},
                                                              {"gamma", {"a_denom", "b_denom", "c_denom", "g_2", "inner_sumcheck"}}};
     std::vector<ValueP> evals_beta, evals_gamma;
-    // EvaluationsProvider::get_lc_eval (ahp/mod.rs:288-312): every polynomial of the combination is evaluated at the point
-    auto lc_eval = [&](const std::string& label, const std::string& tag) {
-        for (auto& t : lcs[label]) (tag == "beta" ? evals_beta : evals_gamma).push_back(B.evaluate(polys[t.second], point[tag]));
+    // EvaluationsProvider::get_lc_eval (ahp/mod.rs:288-312): every polynomial of the combination is evaluated at the point.  construct_linear_combinations
+    // evaluates what the coefficients of the two sumcheck combinations need (:155-157, :228-231), and Marlin::prove evaluates every queried combination
+    // (lib.rs:283-292; the query set iterates in label order).  The evaluations at beta are enqueued here, ahead of gamma; those at gamma once it is drawn --
+    // each list keeps the reference's order.
+    auto evaluate_at = [&](const std::string& tag) {
+        std::vector<ValueP>& into = tag == "beta" ? evals_beta : evals_gamma;
+        auto lc_eval = [&](const std::string& label) {
+            for (auto& t : lcs[label]) into.push_back(B.evaluate(polys[t.second], point[tag]));
+        };
+        for (auto& lt : std::vector<std::pair<const char*, const char*>>{{"z_b", "beta"}, {"t", "beta"}, {"g_1", "beta"}, {"a_denom", "gamma"}, {"b_denom", "gamma"},
+                                                                         {"c_denom", "gamma"}, {"g_2", "gamma"}})
+            if (tag == lt.second) lc_eval(lt.first);
+        for (auto& kv : lcs) {   // std::map iterates in sorted label order, like Python's sorted(lcs)
+            const bool in_beta = std::find(query["beta"].begin(), query["beta"].end(), kv.first) != query["beta"].end();
+            if ((tag == "beta") == in_beta) lc_eval(kv.first);
+        }
     };
-    // construct_linear_combinations evaluates what the coefficients of the two sumcheck combinations need (:155-157, :228-231) ...
-    for (auto& lt : std::vector<std::pair<const char*, const char*>>{{"z_b", "beta"}, {"t", "beta"}, {"g_1", "beta"}, {"a_denom", "gamma"}, {"b_denom", "gamma"},
-                                                                     {"c_denom", "gamma"}, {"g_2", "gamma"}})
-        lc_eval(lt.first, lt.second);
-    // ... and Marlin::prove evaluates every queried combination (lib.rs:283-292; the query set iterates in label order)
-    for (auto& kv : lcs) {   // std::map iterates in sorted label order, like Python's sorted(lcs)
-        const bool in_beta = std::find(query["beta"].begin(), query["beta"].end(), kv.first) != query["beta"].end();
-        lc_eval(kv.first, in_beta ? "beta" : "gamma");
+    evaluate_at("beta");
+    B.settle(tp);
+    const Fr gamma = challenge("marlin.gamma");
+    point["gamma"] = gamma;
+    evaluate_at("gamma");
+    tp = B.mark();                                                       // fs_rng.absorb(&evaluations) (:299)
+    // what depends on gamma but not on the opening challenge: the witness of g_2's degree-bound opening at gamma ...
+    std::map<std::string, Opening> sh_open = {{"beta", std::move(sh_beta)}}, sh_rand_open;
+    if (has_rand_beta) sh_rand_open["beta"] = std::move(sh_rand_beta);
+    {
+        Opening sh = B.open_begin(g_2, gamma), sh_rand;
+        const bool has_rand = blind.count("g_2_shifted") != 0;
+        if (has_rand) sh_rand = B.open_begin(blind["g_2_shifted"], gamma);
+        sh = B.open_finish(std::move(sh));
+        if (has_rand) {
+            sh.proof = B.commit_sum(sh.proof, sh_rand.wit);
+            sh_rand_open["gamma"] = std::move(sh_rand);
+        }
+        sh_open["gamma"] = std::move(sh);
     }
-    B.transcript_point();                                                // fs_rng.absorb(&evaluations) (:299)
-    out.evals.emplace_back("evals_beta", evals_beta);
-    out.evals.emplace_back("evals_gamma", evals_gamma);
-    const Fr ch = challenge("marlin.opening_challenge");
-    // PC::open_combinations (poly-commit/src/marlin/mod.rs:213-300): one polynomial per combination ...
+    // ... and PC::open_combinations (poly-commit/src/marlin/mod.rs:213-300): one polynomial per combination
     std::map<std::string, Arr> lc_poly;
     // (insertion order of the Python dict: z_b, g_1, t, g_2, outer_sumcheck, inner_sumcheck, a_denom, b_denom, c_denom -- the order only decides
     // which arrays exist when; the values do not depend on it)
@@ -851,9 +941,14 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
         }
         lc_poly[kv.first] = acc;
     }
+    B.settle(tp);
+    out.evals.emplace_back("evals_beta", evals_beta);
+    out.evals.emplace_back("evals_gamma", evals_gamma);
+    const Fr ch = challenge("marlin.opening_challenge");
     // ... then batch_open (poly-commit/src/lib.rs:597-640): per query point the queried polynomials are folded with powers of the opening challenge
     // and opened once (marlin_pc/mod.rs:259-316); a degree-bounded polynomial takes two challenges and also opens its own witness polynomial over
-    // the shifted powers (:291-310, :318-330)
+    // the shifted powers (:291-310, :318-330: the witness AND the witness of its shifted randomness, marlin_pc/mod.rs:294-299 -> kzg10/mod.rs:200-224 --
+    // enqueued above, as soon as their point was known)
     for (const char* tagc : {"beta", "gamma"}) {
         const std::string tag = tagc;
         Arr folded;
@@ -871,12 +966,8 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
                 c = fr_mul(c, ch);
             }
         }
-        // the degree-bounded polynomial's witness AND the witness of its shifted randomness (marlin_pc/mod.rs:294-299 -> kzg10/mod.rs:200-224) ...
-        Opening sh = B.open_begin(polys[shifted], point[tag]);
-        const bool has_rand = blind.count(shifted + "_shifted") != 0;
-        Opening sh_rand;
-        if (has_rand) sh_rand = B.open_begin(blind[shifted + "_shifted"], point[tag]);
-        // ... then the folded polynomial with the folded randomness (`r += (challenge_j, &rand.rand)`, :288; KZG10::open :313)
+        const bool has_rand = sh_rand_open.count(tag) != 0;
+        // the folded polynomial with the folded randomness (`r += (challenge_j, &rand.rand)`, :288; KZG10::open :313)
         Arr r_fold;
         for (auto& t : terms) {
             auto it = blind.find(t.second);
@@ -895,13 +986,10 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
         }
         out.openings.emplace_back("open_" + tag, std::move(o));
         // ... and the shifted witness over the shifted powers, with the shifted randomness' witness (open_with_witness_polynomial, :318-330)
-        Opening so = B.open_finish(std::move(sh));
+        Opening so = std::move(sh_open[tag]);
         so.has_of = true;
         so.of = has_rand ? shifted + "_shifted" : shifted;
-        if (has_rand) {
-            so.random_v = sh_rand.value;
-            so.proof = B.commit_sum(so.proof, sh_rand.wit);
-        }
+        if (has_rand) so.random_v = sh_rand_open[tag].value;
         out.openings.emplace_back("open_" + tag + "_shifted", std::move(so));
     }
     B.transcript_point();
