@@ -438,6 +438,17 @@ class Context:
         self._ck(self._L.czk_poly_div_linear(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(qp), _ptr(remainder), C.c_int(mem)))
         return quotient, remainder
 
+    def poly_div_vanishing(self, coeffs, n: int, lanes: int = 1, m=None, quotient=None, remainder=None, mem=CZK_MEM_HOST):
+        """coeffs = q (X^n - 1) + r per lane (czk_poly_div_vanishing); host mode returns (q (lanes, m - n, 4), r (lanes, n, 4))."""
+        if mem == CZK_MEM_HOST:
+            coeffs = np.ascontiguousarray(coeffs, np.uint64).reshape(lanes, -1, 4)
+            m = coeffs.shape[1]
+            quotient = np.zeros((lanes, max(m - n, 0), 4), dtype=np.uint64)
+            remainder = np.zeros((lanes, n, 4), dtype=np.uint64)
+        qp = quotient if not (isinstance(quotient, np.ndarray) and quotient.size == 0) else None
+        self._ck(self._L.czk_poly_div_vanishing(self._h, _ptr(coeffs), C.c_size_t(m), C.c_size_t(lanes), C.c_size_t(n), _ptr(qp), _ptr(remainder), C.c_int(mem)))
+        return quotient, remainder
+
     def poly_evaluate(self, coeffs, z, lanes: int = 1, n=None, values=None, mem=CZK_MEM_HOST):
         """p(z) per lane (czk_poly_evaluate); host mode returns (lanes, 4)."""
         z = np.ascontiguousarray(z, np.uint64).reshape(4)
@@ -448,6 +459,26 @@ class Context:
         cp = coeffs if not (isinstance(coeffs, np.ndarray) and coeffs.size == 0) else None
         self._ck(self._L.czk_poly_evaluate(self._h, _ptr(cp), C.c_size_t(n), C.c_size_t(lanes), _ptr(z), _ptr(values), C.c_int(mem)))
         return values
+
+    def poly_evaluate_many(self, ptrs, ns, lanes, zs, value_ptrs):
+        """czk_poly_evaluate_many on DEVICE pointers: polynomial k = ns[k] coefficients x lanes[k] lanes at ptrs[k], evaluated at zs[k] (Montgomery limbs),
+        its values written to value_ptrs[k]."""
+        k = len(ptrs)
+        src = (C.c_void_p * k)(*[int(p) for p in ptrs])
+        dst = (C.c_void_p * k)(*[int(p) for p in value_ptrs])
+        n = (C.c_size_t * k)(*[int(x) for x in ns])
+        ln = (C.c_size_t * k)(*[int(x) for x in lanes])
+        z = np.ascontiguousarray(np.stack([np.asarray(x, np.uint64).reshape(4) for x in zs]) if k else np.zeros((0, 4), np.uint64))
+        self._ck(self._L.czk_poly_evaluate_many(self._h, C.c_size_t(k), src, n, ln, _ptr(z if k else None), dst))
+
+    def fr_lincomb(self, ptrs, lens, term_lanes, coeffs, lanes: int, lift_mask: int, out_ptr, out_len: int):
+        """czk_fr_lincomb on DEVICE pointers: out[l][i] = sum_k coeffs[k] * term_k[l][i]; a term with one lane is public (added on the lanes of lift_mask)."""
+        k = len(ptrs)
+        src = (C.c_void_p * k)(*[int(p) for p in ptrs])
+        n = (C.c_size_t * k)(*[int(x) for x in lens])
+        tl = (C.c_size_t * k)(*[int(x) for x in term_lanes])
+        c = np.ascontiguousarray(np.stack([np.asarray(x, np.uint64).reshape(4) for x in coeffs]) if k else np.zeros((0, 4), np.uint64))
+        self._ck(self._L.czk_fr_lincomb(self._h, C.c_size_t(k), src, n, tl, _ptr(c if k else None), C.c_size_t(lanes), C.c_uint64(lift_mask), _ptr(out_ptr), C.c_size_t(out_len)))
 
     def fr_prefix_product(self, x, out=None, n=None, mem=CZK_MEM_HOST):
         """Running products of a public Fr vector (partial_products' local loop)."""

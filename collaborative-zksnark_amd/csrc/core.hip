@@ -188,14 +188,34 @@ static void field_to_limbs(const Fq2& a, u64* p) {
 
 template <class F>
 static void host_jac_to_affine(const u64* jac, size_t n, u64* out_aff, uint8_t* out_inf) {
+    // From<Projective> for Affine (short_weierstrass_jacobian.rs:768-789) per point, with ONE field inversion for the whole array (Montgomery's trick, the
+    // reference's own batch_inversion, ff/src/fields/mod.rs:704-727): the inverse of an element is unique, so the affine coordinates are the per-point ones.
+    // A prover settles a dozen commitments at a transcript point; the Fermat inversion of this host code costs ~0.2 ms each.
     constexpr int W = FieldIO<F>::W64;
+    std::vector<Jac<F>> pts(n);
+    std::vector<F> pre(n);          // pre[i] = product of the non-zero z before point i
+    F acc = F::one();
     for (size_t i = 0; i < n; i++) {
-        Jac<F> p;
-        limbs_to_field<F>(jac + 3 * W * i, p.x);
-        limbs_to_field<F>(jac + 3 * W * i + W, p.y);
-        limbs_to_field<F>(jac + 3 * W * i + 2 * W, p.z);
+        limbs_to_field<F>(jac + 3 * W * i, pts[i].x);
+        limbs_to_field<F>(jac + 3 * W * i + W, pts[i].y);
+        limbs_to_field<F>(jac + 3 * W * i + 2 * W, pts[i].z);
+        pre[i] = acc;
+        if (!pts[i].is_zero()) acc = f_mul(acc, pts[i].z);
+    }
+    F inv = f_inv(acc);             // 1 / (z_0 z_1 ... ), infinity points left out
+    for (size_t i = n; i-- > 0;) {
         Affine<F> a;
-        bool inf = jac_to_affine(p, a);
+        const bool inf = pts[i].is_zero();
+        if (inf) {
+            a.x = F::zero();
+            a.y = F::one();
+        } else {
+            const F zi = f_mul(inv, pre[i]);
+            inv = f_mul(inv, pts[i].z);
+            const F zi2 = f_sqr(zi);
+            a.x = f_mul(pts[i].x, zi2);
+            a.y = f_mul(pts[i].y, f_mul(zi2, zi));
+        }
         field_to_limbs(a.x, out_aff + 2 * W * i);
         field_to_limbs(a.y, out_aff + 2 * W * i + W);
         if (out_inf) out_inf[i] = inf ? 1 : 0;
@@ -344,7 +364,7 @@ extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
             {"CZK_REDUCE_SAT_G2", "msm_reduce_sat_g2"}, {"CZK_G2_MODE", "msm_g2_mode"}, {"CZK_MSM_AFFINE", "msm_affine_rounds"}, {"CZK_MSM_SLOTS", "msm_slots"},
             {"CZK_STREAM_PRIO", "msm_stream_priority"}, {"CZK_MSM_SAT", "msm_sat"}, {"CZK_MSM_SAT_G2", "msm_sat_g2"}, {"CZK_MSM_NO_TE", "msm_no_te"},
             {"CZK_MSM_FIXED_C", "msm_fixed_c"}, {"CZK_MSM_C_G1", "msm_window_g1"}, {"CZK_MSM_C_G2", "msm_window_g2"}, {"CZK_CHAOS", "chaos"},
-            {"CZK_CHAOS_DROP_WAIT", "chaos_drop_wait"}};
+            {"CZK_CHAOS_DROP_WAIT", "chaos_drop_wait"}, {"CZK_NTT_SKIP_COSET_FIRST", "ntt_skip_coset_first"}, {"CZK_G1_LANE_PAIRS", "msm_g1_lane_pairs"}};
         for (auto& e : ENV)
             if (const char* v = getenv(e[0])) (void)czk_ctx_set_option(c, e[1], atol(v) ? atol(v) : (v[0] == '0' ? 0 : 1));
     }
@@ -422,6 +442,8 @@ const OptDesc OPTIONS[] = {
     // draw the same delays)
     {"chaos", 0, 0x7fffffff, false, [](czk_ctx* c, long v) { c->chaos = v ? ((unsigned long long)v * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)getpid() << 32) ^ (unsigned long long)(uintptr_t)c : 0; }},
     {"chaos_drop_wait", 0, 2, false, [](czk_ctx* c, long v) { c->chaos_drop_wait = (int)v; }},
+    {"ntt_skip_coset_first", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_skip_coset_first = v != 0; }},
+    {"msm_g1_lane_pairs", 0, 1, false, [](czk_ctx* c, long v) { c->msm_g1_lane_pairs = v != 0; }},
 #endif
 };
 }  // namespace

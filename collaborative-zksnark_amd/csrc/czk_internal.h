@@ -125,6 +125,8 @@ struct czk_ctx {
     // MSM workspace ring hands out its slots in random order.  Results must not change: every ordering the library relies on has to be an event wait or stream
     // order, never timing.  "chaos_drop_wait" removes ONE such wait on purpose (1: the accumulate stream's wait for the digit sort; 2: the reduce stream's wait
     // for the accumulate kernel), so that the test can show it catches the class of bug it exists for.
+    bool ntt_skip_coset_first = false;   // lab "ntt_skip_coset_first": timing experiment (wrong results), see ntt.hip
+    bool msm_g1_lane_pairs = false;      // lab "msm_g1_lane_pairs": k_accumulate_te_pairs -- neighbouring threads take the same bucket rank of two lanes
     unsigned long long chaos = 0;
     int chaos_drop_wait = 0;
     bool ntt_gen1 = false;           // "ntt_gen1": first-generation NTT passes (ntt.hip, the small-domain kernels) for every size

@@ -564,6 +564,30 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
 }
+#ifdef CZK_LAB
+// lab variant (option "msm_g1_lane_pairs", EXPERIMENTS.md section 14): the same work with neighbouring threads on the same bucket RANK of two lanes -- threads
+// 2k / 2k + 1 of a workgroup walk bucket perm[lane][rank] of lanes 2y / 2y + 1 -- so that the two lanes' gathers of one rank are issued by the same wave
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_te_pairs(const u64* pts, const u32* sorted, const u32* offsets,
+                                                                                                         const u32* counts, const u32* perm, size_t B, size_t sorted_stride,
+                                                                                                         u64* buckets, unsigned lanes) {
+    const size_t t = (size_t)blockIdx.x * (blockDim.x / 2) + threadIdx.x / 2;
+    const unsigned lane = 2 * blockIdx.y + (threadIdx.x & 1);
+    if (t >= B || lane >= lanes) return;
+    const size_t b = perm[(size_t)lane * B + t];
+    const u32* srt = sorted + (size_t)lane * sorted_stride;
+    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
+    if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;
+    TEU acc = teu_identity();
+    for (u32 e = 0; e < cnt; e++) {
+        const u32 code = srt[off + e];
+        FqU ym, yp, k2;
+        te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
+        if (e == 0) acc = teu_from_niels(ym, yp, k2);
+        else teu_madd(acc, ym, yp, k2);
+    }
+    teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
+}
+#endif
 // over-full buckets (see k_accumulate_heavy / k_heavy_combine above): the same work items, folded and combined with the unified law
 // (<= 128 VGPRs like k_accumulate_heavy: the normally empty launches must not wait for a drained SIMD beside the accumulate kernels)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_heavy_te(const u64* pts, const u32* sorted, const u32* offsets,

@@ -179,6 +179,11 @@ struct czk_net {
     // IPC (the SHM control block + one device mailbox per rank, mapped into every peer with hipIpc: staging never leaves device memory)
     char* mailbox = nullptr;                 // this rank's 2 x slot_bytes, device memory
     std::vector<char*> peer_mail;            // every rank's mailbox as this process sees it (own entry = mailbox)
+    // lab build, IPC transport created WITHOUT a context: a dry run of the mailbox hand-over on a box without GPUs (tests/test_net.py) -- every rank's "device
+    // mailbox" is a POSIX segment of its own, its 64-byte handle names the owner's rank and device (= rank: every peer is on another device), and the order
+    // allocate -> publish handle -> barrier -> open every peer's handle -> barrier -> exchanges by slot parity is the code the hipIpc path runs
+    bool ipc_dry = false;
+    size_t dry_mail_bytes = 0;
     bool shm_like() const { return transport == CZK_NET_SHM || transport == CZK_NET_IPC; }
     uint64_t seq = 0;             // chunk steps so far: parity of the slot in use
     bool reads_in_flight = false;
@@ -307,11 +312,30 @@ int ipc_data(czk_net* n) {
         munmap(p, hb);
         return net_err(n, CZK_ERR_HIP, msg);
     };
+    // the three steps that touch HIP, with their dry-run stand-ins (lab build, no context): allocate this rank's mailbox, make its handle, open a peer's handle
+    struct DryHandle {
+        uint64_t magic;
+        int32_t rank, device;
+    };
+    constexpr uint64_t DRY_MAGIC = 0x59524449414d5a43ull;   // "CZMAIDRY"
+    static_assert(sizeof(DryHandle) <= sizeof(hipIpcMemHandle_t), "a dry-run handle fits the slot of a real one");
+    auto mail_name = [&](int r) { return n->shm_name + ".m" + std::to_string(r); };
     void* mb = nullptr;
-    if (hipMalloc(&mb, 2 * n->slot_bytes) != hipSuccess) return fail("hipMalloc mailbox");
+    if (n->ipc_dry) {
+        n->dry_mail_bytes = 2 * n->slot_bytes;
+        if (shm_map(n, mail_name(n->rank), n->dry_mail_bytes, true, &mb) != CZK_OK) return fail("dry run: mailbox segment: " + n->err);
+        memset(&handles[n->rank], 0, sizeof(hipIpcMemHandle_t));
+        DryHandle dh{DRY_MAGIC, n->rank, n->rank};
+        memcpy(&handles[n->rank], &dh, sizeof dh);
+    } else {
+        if (hipMalloc(&mb, 2 * n->slot_bytes) != hipSuccess) return fail("hipMalloc mailbox");
+        hipError_t e = hipIpcGetMemHandle(&handles[n->rank], mb);
+        if (e != hipSuccess) {
+            (void)hipFree(mb);
+            return fail(std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e) + " (HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment?)");
+        }
+    }
     n->mailbox = (char*)mb;
-    hipError_t e = hipIpcGetMemHandle(&handles[n->rank], mb);
-    if (e != hipSuccess) return fail(std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e) + " (HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment?)");
     CZK_TRY(shm_barrier(n));   // every handle is published
     std::vector<char*> peers((size_t)n->world, nullptr);
     for (int r = 0; r < n->world; r++) {
@@ -320,11 +344,19 @@ int ipc_data(czk_net* n) {
             continue;
         }
         void* q = nullptr;
-        e = hipIpcOpenMemHandle(&q, handles[r], hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return fail(std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        if (n->ipc_dry) {
+            DryHandle dh;
+            memcpy(&dh, &handles[r], sizeof dh);
+            if (dh.magic != DRY_MAGIC || dh.rank != r || dh.device == n->rank) return fail("dry run: slot " + std::to_string(r) + " of the handle table does not hold rank " + std::to_string(r) + "'s handle");
+            if (shm_map(n, mail_name(r), n->dry_mail_bytes, false, &q) != CZK_OK) return fail("dry run: open mailbox of rank " + std::to_string(r) + ": " + n->err);
+        } else {
+            hipError_t e = hipIpcOpenMemHandle(&q, handles[r], hipIpcMemLazyEnablePeerAccess);   // (a peer on another GPU: peer access over xGMI, enabled on first use)
+            if (e != hipSuccess) return fail(std::string("hipIpcOpenMemHandle: ") + hipGetErrorString(e));
+        }
         peers[r] = (char*)q;
     }
     CZK_TRY(shm_barrier(n));   // everybody has every mailbox mapped
+    if (n->ipc_dry) shm_unlink(mail_name(n->rank).c_str());   // (mapped by every peer: the name can go)
     if (n->rank == 0) shm_unlink(name.c_str());
     munmap(p, hb);
     n->peer_mail = peers;
@@ -367,7 +399,7 @@ inline char* shm_slot(czk_net* n, int owner, uint64_t parity) {
 
 int shm_put(czk_net* n, char* slot, const void* src, size_t len, int mem, bool* wrote) {
     if (n->ctx) chaos_point(n->ctx, n->ctx->stream);
-    if (n->transport == CZK_NET_IPC) {   // the slot is device memory (this rank's mailbox, or a peer's through its mapping)
+    if (n->transport == CZK_NET_IPC && !n->ipc_dry) {   // the slot is device memory (this rank's mailbox, or a peer's through its mapping)
         NET_HIP(n, hipMemcpyAsync(slot, src, len, mem == CZK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, n->ctx->stream));
         *wrote = true;
         return CZK_OK;
@@ -382,7 +414,7 @@ int shm_put(czk_net* n, char* slot, const void* src, size_t len, int mem, bool* 
 }
 int shm_get(czk_net* n, void* dst, const char* slot, size_t len, int mem) {
     if (n->ctx) chaos_point(n->ctx, n->ctx->stream);
-    if (n->transport == CZK_NET_IPC) {
+    if (n->transport == CZK_NET_IPC && !n->ipc_dry) {
         NET_HIP(n, hipMemcpyAsync(dst, slot, len, mem == CZK_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, n->ctx->stream));
         if (mem == CZK_MEM_DEVICE) n->reads_in_flight = true;
         else NET_HIP(n, hipStreamSynchronize(n->ctx->stream));   // host destination: complete before the call returns
@@ -578,8 +610,14 @@ extern "C" void czk_net_destroy(czk_net* n) {
         munmap(n->slots, n->data_bytes);
     }
     for (size_t r = 0; r < n->peer_mail.size(); r++)
-        if ((int)r != n->rank && n->peer_mail[r]) (void)hipIpcCloseMemHandle(n->peer_mail[r]);
-    if (n->mailbox) (void)hipFree(n->mailbox);   // (a peer that still has it mapped keeps the memory alive until it closes its handle)
+        if ((int)r != n->rank && n->peer_mail[r]) {
+            if (n->ipc_dry) munmap(n->peer_mail[r], n->dry_mail_bytes);
+            else (void)hipIpcCloseMemHandle(n->peer_mail[r]);
+        }
+    if (n->mailbox) {   // (a peer that still has it mapped keeps the memory alive until it closes its handle)
+        if (n->ipc_dry) munmap(n->mailbox, n->dry_mail_bytes);
+        else (void)hipFree(n->mailbox);
+    }
     if (n->hdr) munmap(n->hdr, sizeof(ShmHeader));
     for (DeviceBuf* b : {&n->gather, &n->dx, &n->small})
         if (b->p) (void)hipFree(b->p);
@@ -609,7 +647,11 @@ extern "C" int czk_net_create(czk_ctx* ctx, int transport, int rank, int world, 
         }();
     } else if (transport == CZK_NET_SHM || transport == CZK_NET_IPC) {
         rc = [&]() -> int {
+#ifdef CZK_LAB
+            if (transport == CZK_NET_IPC && !ctx) n->ipc_dry = true;   // lab build: the dry run of the mailbox hand-over (see czk_net::ipc_dry); host buffers only
+#else
             if (transport == CZK_NET_IPC && !ctx) return net_err(n, CZK_ERR_ARG, "czk_net_create: the IPC transport needs a context");
+#endif
             if (id_len > 32) return net_err(n, CZK_ERR_ARG, "czk_net_create: an SHM id is 1..32 bytes");
             n->shm_name = shm_name_of(id, id_len, "");
             void* p = nullptr;

@@ -450,6 +450,11 @@ int ntt_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, int kind, 
             b.post_mode = !last ? 0 : (kind == CZK_IFFT ? 1 : (kind == CZK_COSET_IFFT ? 2 : 0));
             b.in = first ? src : scratch;
             b.out = last ? data : scratch;
+#ifdef CZK_LAB
+            // TIMING EXPERIMENT ONLY (wrong results): the first pass of every coset FFT is not launched -- an upper bound on what fusing it into the last pass
+            // of the inverse transform in front of it (witness_map: ifft -> coset_fft on a, b, c) could save: the fused kernel would still run its seven stages
+            if (ctx->ntt_skip_coset_first && first && !last && kind == CZK_COSET_FFT) continue;
+#endif
             ProfScope ps(ctx, "ntt_pass");
             CZK_TRY(launch_ntt2_pass(ctx, b, K, last, lanes));
         }

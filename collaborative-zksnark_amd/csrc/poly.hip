@@ -93,6 +93,27 @@ __global__ __launch_bounds__(256) void k_seg_fill(const u64* in, size_t in_strid
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Division by the vanishing polynomial X^n - 1 in coefficient form: a = q (X^n - 1) + r with
+// q_i = sum_{k >= 1} a_{i + k n} and r_i = sum_{k >= 0} a_{i + k n} (i < n): the suffix sums of the
+// n-coefficient chunks of a.  One thread per residue i < n walks its chunks from the top: every
+// coefficient is read once, every output written once, neighbouring threads touch neighbouring elements.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_div_vanishing(const u64* in, size_t m, size_t n, u64* q, u64* rem) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned lane = blockIdx.y;
+    const u64* a = in + 4 * (size_t)lane * m;
+    u64* qo = q + 4 * (size_t)lane * (m - n);
+    const size_t chunks = (m + n - 1) / n;
+    Fr acc = Fr::zero();
+    for (size_t k = chunks; k-- > 1;) {
+        if (i + k * n < m) acc = fp_add(acc, pfr_load(a, i + k * n));
+        if (i + (k - 1) * n < m - n) pfr_store(qo, i + (k - 1) * n, acc);
+    }
+    if (rem) pfr_store(rem + 4 * (size_t)lane * n, i, i < m ? fp_add(acc, pfr_load(a, i)) : acc);
+}
+
 static Fr host_pow(Fr x, unsigned e) {
     Fr r = Fr::one();
     for (; e; e >>= 1) {
@@ -146,6 +167,61 @@ static int eval_horner(czk_ctx* ctx, const u64* in, size_t in_stride, size_t n, 
     CZK_HIP(ctx, hipGetLastError());
     if (n_seg > 1) return eval_horner(ctx, H, n_seg, n_seg, lanes, host_pow(x, SEG), value, ws);
     return CZK_OK;
+}
+
+// Several polynomials in one launch per level (czk_poly_evaluate_many): the descriptors travel with the launch, blockIdx.z selects the polynomial.  A
+// prover's evaluation round is two dozen evaluations whose upper levels are a few dozen elements each -- launch-bound when issued one by one.
+constexpr unsigned EVAL_MANY = 16;
+struct EvalDesc {
+    const u64* in;
+    size_t in_stride, n, n_seg;
+    u64* out;        // lanes x n_seg segment values (the next level's input), or the lanes values when n_seg == 1
+    Fr x;
+    unsigned lanes;
+};
+struct EvalBatch {
+    EvalDesc d[EVAL_MANY];
+};
+__global__ __launch_bounds__(256) void k_seg_horner_many(EvalBatch b) {
+    const EvalDesc& d = b.d[blockIdx.z];
+    const unsigned lane = blockIdx.y;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= d.lanes || t >= d.n_seg) return;
+    const u64* p = d.in + 4 * (size_t)lane * d.in_stride;
+    const size_t a = t * SEG, e = a + SEG < d.n ? a + SEG : d.n;
+    Fr r = Fr::zero();
+    for (size_t i = e; i-- > a;) r = fp_add(fp_mul(r, d.x), pfr_load(p, i));
+    pfr_store(d.out + 4 * (size_t)lane * d.n_seg, t, r);
+}
+
+// out[l][i] = sum_k c_k a_k[l][i] over terms of different lengths (czk_fr_lincomb): one read of every operand, one write of the result, where a chain of
+// scale / resize / add calls makes a pass per call.  A term on one lane is PUBLIC: it is added on the lanes of `lift_mask` only (the reference's
+// `shift` of a shared value by a public one: the king's lanes under SPDZ, every lane under GSZ).
+constexpr unsigned LINCOMB_MAX = 12;
+struct LinTerm {
+    const u64* a;
+    size_t len, lane_stride;   // lane_stride == 0: a public term
+    Fr c;
+    unsigned unit;             // c == 1: no multiplication
+};
+struct LinBatch {
+    LinTerm t[LINCOMB_MAX];
+    unsigned count;
+    unsigned long long lift_mask;
+};
+__global__ __launch_bounds__(256) void k_lincomb(LinBatch b, u64* out, size_t out_len) {
+    const unsigned lane = blockIdx.y;
+    const bool lifts = (b.lift_mask >> (lane & 63)) & 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < out_len; i += (size_t)gridDim.x * blockDim.x) {
+        Fr acc = Fr::zero();
+        for (unsigned k = 0; k < b.count; k++) {
+            const LinTerm& t = b.t[k];
+            if (i >= t.len || (t.lane_stride == 0 && !lifts)) continue;
+            const Fr v = pfr_load(t.a + 4 * (size_t)lane * t.lane_stride, i);
+            acc = fp_add(acc, t.unit ? v : fp_mul(v, t.c));
+        }
+        pfr_store(out + 4 * (size_t)lane * out_len, i, acc);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,6 +424,28 @@ extern "C" int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t 
     return CZK_OK;
 }
 
+extern "C" int czk_poly_div_vanishing(czk_ctx* ctx, const uint64_t* coeffs, size_t m, size_t lanes, size_t n, uint64_t* quotient, uint64_t* remainder, int mem) {
+    if (!ctx || !n || (lanes && m && !coeffs) || (lanes && m > n && !quotient)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null / zero poly_div_vanishing argument") : CZK_ERR_ARG;
+    if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
+    if (!lanes) return CZK_OK;
+    if (m < n) return set_err(ctx, CZK_ERR_ARG, "czk_poly_div_vanishing: fewer than n coefficients (pad with zeros: the remainder is the polynomial itself)");
+    if (lanes > 65535) return set_err(ctx, CZK_ERR_SIZE, "too many lanes");
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    Staged sp{ctx}, sq{ctx}, sr{ctx};
+    CZK_TRY(sp.to_device(coeffs, lanes * m * 32, mem));
+    CZK_TRY(sq.to_device(mem == CZK_MEM_HOST ? nullptr : quotient, lanes * (m - n) * 32, mem));
+    CZK_TRY(sr.to_device(mem == CZK_MEM_HOST ? nullptr : remainder, lanes * n * 32, remainder ? mem : CZK_MEM_HOST));
+    {
+        ProfScope ps(ctx, "poly_div_vanishing");
+        hipLaunchKernelGGL(k_div_vanishing, dim3((unsigned)((n + 255) / 256), (unsigned)lanes), dim3(256), 0, ctx->stream, (const u64*)sp.dev, m, n, (u64*)sq.dev,
+                           remainder ? (u64*)sr.dev : nullptr);
+        CZK_HIP(ctx, hipGetLastError());
+    }
+    CZK_TRY(sq.to_host(quotient, lanes * (m - n) * 32));
+    if (remainder) CZK_TRY(sr.to_host(remainder, lanes * n * 32));
+    return CZK_OK;
+}
+
 extern "C" int czk_poly_evaluate(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* values, int mem) {
     if (!ctx || !z || (lanes && n && !coeffs) || (lanes && !values)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null poly_evaluate argument") : CZK_ERR_ARG;
     if (!valid_mem(mem)) return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE");
@@ -369,6 +467,99 @@ extern "C" int czk_poly_evaluate(czk_ctx* ctx, const uint64_t* coeffs, size_t n,
         CZK_TRY(eval_horner(ctx, (const u64*)sp.dev, n, n, lanes, x, (u64*)sv.dev, ws));
     }
     CZK_TRY(sv.to_host(values, lanes * 32));
+    return CZK_OK;
+}
+
+extern "C" int czk_poly_evaluate_many(czk_ctx* ctx, size_t count, const uint64_t* const* coeffs, const size_t* n, const size_t* lanes, const uint64_t* z,
+                                      uint64_t* const* values) {
+    if (!ctx || (count && (!coeffs || !n || !lanes || !z || !values))) return ctx ? set_err(ctx, CZK_ERR_ARG, "null poly_evaluate_many argument") : CZK_ERR_ARG;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    for (size_t at = 0; at < count; at += EVAL_MANY) {
+        const unsigned m = (unsigned)(count - at < EVAL_MANY ? count - at : EVAL_MANY);
+        // scratch: every polynomial keeps two level arrays of its own (lanes x n_seg, then 32 times smaller, ping-pong would do; the sum is n / 31 per lane)
+        size_t need = 256;
+        for (unsigned k = 0; k < m; k++) {
+            if (lanes[at + k] > 65535) return set_err(ctx, CZK_ERR_SIZE, "too many lanes");
+            if (lanes[at + k] && n[at + k] && (!coeffs[at + k] || !values[at + k])) return set_err(ctx, CZK_ERR_ARG, "null poly_evaluate_many polynomial / value pointer");
+            need += eval_horner_scratch(n[at + k], lanes[at + k]) + 64;
+        }
+        CZK_TRY(ensure_buf(ctx, ctx->poly_scratch, need));
+        char* ws = (char*)ctx->poly_scratch.p;
+        struct Cur {
+            const u64* in;
+            size_t stride, n;
+            Fr x;
+            u64* value;
+            unsigned lanes;
+            bool done;
+        } cur[EVAL_MANY];
+        for (unsigned k = 0; k < m; k++) {
+            cur[k] = Cur{(const u64*)coeffs[at + k], n[at + k], n[at + k], host_fr(z + 4 * (at + k)), (u64*)values[at + k], (unsigned)lanes[at + k], false};
+            if (!cur[k].lanes) cur[k].done = true;
+            else if (!cur[k].n) {   // the zero polynomial
+                CZK_HIP(ctx, hipMemsetAsync(cur[k].value, 0, (size_t)cur[k].lanes * 32, ctx->stream));
+                cur[k].done = true;
+            }
+        }
+        ProfScope ps(ctx, "poly_evaluate");
+        for (;;) {
+            EvalBatch b;
+            unsigned cnt = 0, max_lanes = 0;
+            size_t max_seg = 0;
+            unsigned which[EVAL_MANY];
+            for (unsigned k = 0; k < m; k++) {
+                if (cur[k].done) continue;
+                EvalDesc& d = b.d[cnt];
+                d.in = cur[k].in, d.in_stride = cur[k].stride, d.n = cur[k].n, d.n_seg = (cur[k].n + SEG - 1) / SEG, d.x = cur[k].x, d.lanes = cur[k].lanes;
+                if (d.n_seg == 1) d.out = cur[k].value;
+                else {
+                    d.out = (u64*)ws;
+                    ws += (size_t)d.lanes * d.n_seg * 32;
+                }
+                max_lanes = d.lanes > max_lanes ? d.lanes : max_lanes;
+                max_seg = d.n_seg > max_seg ? d.n_seg : max_seg;
+                which[cnt++] = k;
+            }
+            if (!cnt) break;
+            hipLaunchKernelGGL(k_seg_horner_many, dim3((unsigned)((max_seg + 255) / 256), max_lanes, cnt), dim3(256), 0, ctx->stream, b);
+            CZK_HIP(ctx, hipGetLastError());
+            for (unsigned j = 0; j < cnt; j++) {
+                Cur& c = cur[which[j]];
+                const EvalDesc& d = b.d[j];
+                if (d.n_seg == 1) c.done = true;
+                else c.in = d.out, c.stride = d.n_seg, c.n = d.n_seg, c.x = host_pow(c.x, SEG);
+            }
+        }
+    }
+    return CZK_OK;
+}
+
+extern "C" int czk_fr_lincomb(czk_ctx* ctx, size_t count, const uint64_t* const* terms, const size_t* term_len, const size_t* term_lanes, const uint64_t* coeffs,
+                              size_t lanes, uint64_t lift_mask, uint64_t* out, size_t out_len) {
+    if (!ctx || (count && (!terms || !term_len || !term_lanes || !coeffs)) || (lanes && out_len && !out)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null fr_lincomb argument") : CZK_ERR_ARG;
+    if (count > LINCOMB_MAX) return set_err(ctx, CZK_ERR_SIZE, "czk_fr_lincomb: at most 12 terms per call (chain calls: the result of one is a unit term of the next)");
+    if (lanes > 64) return set_err(ctx, CZK_ERR_SIZE, "czk_fr_lincomb: at most 64 lanes (the lift mask)");
+    if (!lanes || !out_len) return CZK_OK;
+    CZK_HIP(ctx, hipSetDevice(ctx->device));
+    LinBatch b;
+    b.count = (unsigned)count;
+    b.lift_mask = lanes == 1 ? ~0ull : lift_mask;   // a public result takes every public term
+    static const Fr ONE = Fr::one();
+    for (size_t k = 0; k < count; k++) {
+        if (term_lanes[k] != lanes && term_lanes[k] != 1) return set_err(ctx, CZK_ERR_ARG, "czk_fr_lincomb: a term has `lanes` lanes or one (public)");
+        if (term_len[k] && !terms[k]) return set_err(ctx, CZK_ERR_ARG, "czk_fr_lincomb: null term");
+        LinTerm& t = b.t[k];
+        t.a = (const u64*)terms[k];
+        t.len = term_len[k] < out_len ? term_len[k] : out_len;
+        t.lane_stride = (term_lanes[k] == 1 && lanes > 1) ? 0 : term_len[k];
+        t.c = host_fr(coeffs + 4 * k);
+        t.unit = t.c == ONE ? 1 : 0;
+    }
+    ProfScope ps(ctx, "fr_lincomb");
+    size_t blocks = (out_len + 255) / 256, cap = (size_t)ctx->num_cu * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(k_lincomb, dim3((unsigned)blocks, (unsigned)lanes), dim3(256), 0, ctx->stream, b, (u64*)out, out_len);
+    CZK_HIP(ctx, hipGetLastError());
     return CZK_OK;
 }
 

@@ -482,6 +482,19 @@ class GpuBackend(Backend):
     def quotient(self, a, x):
         return self._div_linear_dev(a, x)[0]
 
+    def div_vanishing(self, a, n: int):
+        """The suffix sums of a's n-coefficient chunks in ONE pass (czk_poly_div_vanishing) where the generic form makes a copy and an addition per chunk;
+        few residues with long chains (Marlin's v_X, |X| = 2) keep the generic route through div_linear."""
+        m = a.shape[1]
+        if m <= n or n < (m + n - 1) // n:
+            return super().div_vanishing(a, n)
+        a = a.contiguous()
+        lanes = a.shape[0]
+        q = self.torch.empty((lanes, m - n, 4), dtype=self.torch.int64, device=self.dev)
+        r = self.torch.empty((lanes, n, 4), dtype=self.torch.int64, device=self.dev)
+        self.ctx.poly_div_vanishing(a.data_ptr(), n, lanes=lanes, m=m, quotient=q.data_ptr(), remainder=r.data_ptr(), mem=self.M)
+        return q, r
+
     def _value_kind(self, a, public):
         if public is None:
             public = a.shape[0] == 1 and self.lanes > 1

@@ -369,6 +369,26 @@ int czk_poly_div_linear(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t l
  * Marlin's evaluation round).  coeffs: lanes x n Fr, low degree first; values: lanes Fr = p(z); z: one Montgomery Fr in HOST
  * memory.  Same result as czk_poly_div_linear's remainder, at half its memory traffic. */
 int czk_poly_evaluate(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lanes, const uint64_t* z, uint64_t* values, int mem);
+/* DensePolynomial::divide_by_vanishing_poly (algebra/poly/src/polynomial/univariate/dense.rs:172-179) for the radix-2 / mixed-radix vanishing polynomial
+ * X^n - 1, per lane (the divisor is public): a = q (X^n - 1) + r.  coeffs: lanes x m Fr, low degree first, m >= n; quotient: lanes x (m - n) Fr;
+ * remainder (may be NULL): lanes x n Fr.  The quotients h of mpc-plonk's gate / product arguments (mpc-plonk/src/lib.rs:190, :332) and Marlin's h_1, h_2
+ * (marlin/src/ahp/prover.rs:533, :696); one pass over the coefficients.  (For n of a few units -- Marlin's v_X with |X| = 2 -- the residue classes are long
+ * chains: divide them with czk_poly_div_linear at z = 1 instead, as tools/polyvm_host.hpp does.) */
+/* czk_poly_evaluate for `count` polynomials in one call, DEVICE memory: polynomial k = n[k] coefficients on lanes[k] lanes at coeffs[k], evaluated at
+ * z + 4 k (HOST, Montgomery), its lanes[k] values written to values[k].  One launch per 32-fold reduction level for all of them: Marlin's evaluation round
+ * (marlin/src/lib.rs:283-292 through EvaluationsProvider::get_lc_eval, marlin/src/ahp/mod.rs:288-312) evaluates two dozen polynomials at two points,
+ * and the upper levels of one evaluation are a few dozen elements -- launch-bound when issued one polynomial at a time. */
+int czk_poly_evaluate_many(czk_ctx* ctx, size_t count, const uint64_t* const* coeffs, const size_t* n, const size_t* lanes, const uint64_t* z,
+                           uint64_t* const* values);
+/* out[l][i] = sum_k coeffs[k] * terms[k][l][i], i < out_len, over `count` <= 12 DEVICE arrays of different lengths (term_len[k] elements per lane; shorter
+ * terms end early, longer ones are cut at out_len), coeffs: count x 4 u64, HOST, Montgomery.  A term has `lanes` lanes (term_lanes[k] == lanes) or is
+ * PUBLIC (term_lanes[k] == 1): a public term is added on the lanes whose bit is set in `lift_mask` only -- the rule by which the reference adds a public
+ * value to a shared one (AdditiveFieldShare::shift, mpc-algebra/src/share/add.rs:141-146: the king; GszFieldShare: every party).  One pass: the linear
+ * combinations of polynomials a prover forms -- `poly += (*coeff, cur_poly.polynomial())` per term (poly-commit/src/marlin/mod.rs:275; the batch opening's
+ * fold, marlin_pc/mod.rs:259-316; marlin/src/ahp/prover.rs:468-476) -- where a scale / resize / add chain makes a pass over memory per call. */
+int czk_fr_lincomb(czk_ctx* ctx, size_t count, const uint64_t* const* terms, const size_t* term_len, const size_t* term_lanes, const uint64_t* coeffs,
+                   size_t lanes, uint64_t lift_mask, uint64_t* out, size_t out_len);
+int czk_poly_div_vanishing(czk_ctx* ctx, const uint64_t* coeffs, size_t m, size_t lanes, size_t n, uint64_t* quotient, uint64_t* remainder, int mem);
 
 /* out[i] = x[0] * x[1] * ... * x[i] over a PUBLIC vector: the sequential loop of partial_products between its
  * batch_open and the final scale (mpc-algebra/src/share/field.rs:169-172; Plonk's grand product).  The share-side

@@ -640,6 +640,103 @@ def test_poly_div_linear_matches_oracle(ctx, czk, orc, n):
         assert np.array_equal(v[ln], orc.fr_horner(p[ln], z) if n else np.zeros(4, dtype=np.uint64)), (n, ln)
 
 
+@pytest.mark.parametrize("m,n", [(5, 5), (6, 5), (17, 4), (1000, 64), (7 * 4096 + 3, 4096), (3 * (1 << 14) - 1, 1 << 14), (2 * 768, 768), ((1 << 18) + 5, 3 << 12)])
+def test_poly_div_vanishing_matches_checker_and_definition(ctx, czk, orc, m, n):
+    """czk_poly_div_vanishing (DensePolynomial::divide_by_vanishing_poly, dense.rs:172-179, for X^n - 1): against the suffix sums of the n-coefficient chunks
+    computed with the checker's field addition, and against the definition a = q X^n - q + r, deg r < n, which determines (q, r) uniquely --
+    incl. ragged lengths (m not a multiple of n), m == n (empty quotient) and a mixed-radix size."""
+    lanes = 2
+    a = orc.fr_from_repr(rand_fr_canonical(900 + m + n, lanes * m)).reshape(lanes, m, 4)
+    q, r = ctx.poly_div_vanishing(a, n, lanes=lanes)
+    assert q.shape == (lanes, m - n, 4) and r.shape == (lanes, n, 4)
+    chunks = -(-m // n)
+    for ln in range(lanes):
+        pad = np.zeros((chunks * n, 4), dtype=np.uint64)
+        pad[:m] = a[ln]
+        suffix = np.zeros((n, 4), dtype=np.uint64)
+        want_q = np.zeros((chunks * n, 4), dtype=np.uint64)
+        for k in range(chunks - 1, 0, -1):
+            suffix = orc.fr_add(suffix, pad[k * n:(k + 1) * n])
+            want_q[(k - 1) * n:k * n] = suffix
+        assert np.array_equal(q[ln], want_q[:m - n]) and np.array_equal(r[ln], orc.fr_add(suffix, pad[:n])), (m, n, ln)
+        # the definition: a_j = q_(j - n) - q_j + r_j
+        qx = np.zeros((m + n, 4), dtype=np.uint64)
+        qx[:m - n] = q[ln]
+        shifted = np.zeros((m + n, 4), dtype=np.uint64)
+        shifted[n:m] = q[ln]
+        rr = np.zeros((m + n, 4), dtype=np.uint64)
+        rr[:n] = r[ln]
+        back = orc.fr_add(orc.fr_sub(shifted, qx), rr)
+        assert np.array_equal(back[:m], a[ln]) and not back[m:].any(), (m, n, ln)
+
+
+def test_poly_evaluate_many_matches_checker(ctx, czk, orc):
+    """czk_poly_evaluate_many: 21 polynomials of ragged lengths (around the 32-coefficient segment levels, the zero polynomial, one coefficient), 1 / 2 / 4
+    lanes, each at its own point, in one call (two batches of the kernel's 16 descriptors) -- every value against the checker's Horner evaluation, and against
+    czk_poly_evaluate."""
+    import torch
+    sizes = [0, 1, 2, 31, 32, 33, 1023, 1024, 1025, 32 * 32 * 32, 32 * 32 * 32 + 1, (1 << 16) + 5, 7, 100, 5000, 40000, 3, 64, 65, 2049, 12345]
+    lanes = [1, 2, 4, 1, 2, 4, 1, 2, 4, 1, 2, 4, 3, 3, 1, 2, 4, 1, 2, 4, 2]
+    polys, zs = [], []
+    for k, (n, ln) in enumerate(zip(sizes, lanes)):
+        polys.append(orc.fr_from_repr(rand_fr_canonical(700 + k, ln * max(n, 1)))[: ln * n].reshape(ln, n, 4))
+        zs.append(orc.fr_from_repr(rand_fr_canonical(750 + k, 1))[0])
+    dev = [torch.from_numpy(p.view(np.int64).copy()).cuda() for p in polys]
+    vals = torch.full((sum(lanes), 4), -1, dtype=torch.int64, device="cuda")
+    at, outs = 0, []
+    for ln in lanes:
+        outs.append(vals[at:at + ln])
+        at += ln
+    torch.cuda.synchronize()
+    ctx.poly_evaluate_many([d.data_ptr() for d in dev], sizes, lanes, zs, [o.data_ptr() for o in outs])
+    ctx.sync()
+    got = vals.cpu().numpy().view(np.uint64)
+    at = 0
+    for k, (n, ln) in enumerate(zip(sizes, lanes)):
+        for l in range(ln):
+            want = orc.fr_horner(polys[k][l], zs[k]) if n else np.zeros(4, dtype=np.uint64)
+            assert np.array_equal(got[at + l], want), (k, n, l)
+        if n:
+            assert np.array_equal(got[at:at + ln], ctx.poly_evaluate(polys[k], zs[k], lanes=ln)), k
+        at += ln
+
+
+def test_fr_lincomb_matches_checker(ctx, czk, orc):
+    """czk_fr_lincomb: shared (4-lane) and public (1-lane) terms of ragged lengths, a unit coefficient, a term longer than the result; public terms must land
+    on the lanes of the lift mask only (AdditiveFieldShare::shift: the king's lanes) -- against the same sum built from the checker's field operations."""
+    import torch
+    lanes, out_len, mask = 4, 5000, 0b0011
+    spec = [(4, 5000), (1, 4097), (4, 1), (1, 5000), (4, 6000), (4, 4999), (1, 0), (4, 3000)]      # (lanes, length)
+    one = orc.fr_from_repr(np.array([[1, 0, 0, 0]], dtype=np.uint64))[0]
+    terms = [orc.fr_from_repr(rand_fr_canonical(800 + k, ln * max(n, 1)))[: ln * n].reshape(ln, n, 4) for k, (ln, n) in enumerate(spec)]
+    coeffs = [orc.fr_from_repr(rand_fr_canonical(850 + k, 1))[0] for k in range(len(spec))]
+    coeffs[2] = one
+    dev = [torch.from_numpy(t.view(np.int64).copy()).cuda() for t in terms]
+    out = torch.full((lanes, out_len, 4), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.fr_lincomb([d.data_ptr() for d in dev], [n for _, n in spec], [ln for ln, _ in spec], coeffs, lanes, mask, out.data_ptr(), out_len)
+    ctx.sync()
+    got = out.cpu().numpy().view(np.uint64)
+    for l in range(lanes):
+        want = np.zeros((out_len, 4), dtype=np.uint64)
+        for (ln, n), t, c in zip(spec, terms, coeffs):
+            if ln == 1 and not (mask >> l) & 1:
+                continue
+            m = min(n, out_len)
+            if m:
+                want[:m] = orc.fr_add(want[:m], orc.fr_mul(t[l if ln > 1 else 0][:m], np.tile(c, (m, 1))))
+        assert np.array_equal(got[l], want), l
+    # a public result takes every public term whatever the mask; more than 12 terms is an error, not a truncation
+    out1 = torch.full((1, 4097, 4), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ctx.fr_lincomb([dev[1].data_ptr(), dev[3].data_ptr()], [4097, 5000], [1, 1], [coeffs[1], coeffs[3]], 1, 0, out1.data_ptr(), 4097)
+    ctx.sync()
+    want1 = orc.fr_add(orc.fr_mul(terms[1][0], np.tile(coeffs[1], (4097, 1))), orc.fr_mul(terms[3][0][:4097], np.tile(coeffs[3], (4097, 1))))
+    assert np.array_equal(out1.cpu().numpy().view(np.uint64)[0], want1)
+    with pytest.raises(czk.CzkError):
+        ctx.fr_lincomb([dev[0].data_ptr()] * 13, [5000] * 13, [4] * 13, [one] * 13, lanes, mask, out.data_ptr(), out_len)
+
+
 def test_poly_div_linear_full_size_identity(ctx, czk, orc):
     """2^21 coefficients x 2 lanes on device: remainder == p(z) (oracle Horner) and p(x) == q(x) (x - z) + r at a random x."""
     import torch

@@ -96,6 +96,39 @@ def test_shm_transport_host_buffers(world, slot_bytes):
     assert res == [(r, True) for r in range(world)]
 
 
+def _ipc_dry_worker(rank, world, q, idb, slot_bytes):
+    sys.path.insert(0, ROOT)
+    import czk_amd
+    ok = True
+    try:
+        czk_amd.Net(None, czk_amd.CZK_NET_IPC, rank, world, idb)       # the PRODUCT library has no stand-in: device mailboxes need a context
+        ok = False
+    except czk_amd.CzkError as e:
+        ok = e.code == 3
+    net = czk_amd.Net(None, czk_amd.CZK_NET_IPC, rank, world, idb, options={"slot_bytes": slot_bytes, "timeout_ms": 60000}, lab=True)
+    for nbytes in (1, slot_bytes - 1, slot_bytes, slot_bytes + 1, 5 * slot_bytes + 3, 0):      # one and several chunk steps: the slots alternate by parity
+        got = net.broadcast(_payload(rank, nbytes))
+        ok = ok and got.shape == (world, nbytes) and all(np.array_equal(got[p], _payload(p, nbytes)) for p in range(world))
+        king = net.send_to_king(_payload(rank + 7, nbytes))
+        ok = ok and ((king is None) if rank else all(np.array_equal(king[p], _payload(p + 7, nbytes)) for p in range(world)))
+        parts = np.stack([_payload(100 + p, nbytes) for p in range(world)]) if rank == 0 else None
+        ok = ok and np.array_equal(net.recv_from_king(parts, nbytes=nbytes), _payload(100 + rank, nbytes))
+    net.barrier()
+    net.close()
+    q.put((rank, bool(ok)))
+
+
+@pytest.mark.parametrize("world,slot_bytes", [(2, 64), (3, 4096), (4, 192)])
+def test_ipc_mailbox_hand_over_dry_run(world, slot_bytes):
+    """The hipIpc transport's open order with every peer on ANOTHER device, on a box without GPUs (lab library, CZK_NET_IPC without a context): each rank
+    allocates its mailbox, publishes a handle that names its rank and device (device = rank, so device != peer device for every pair), all ranks meet,
+    each opens every peer's handle from the shared table, all meet again, and the three mpc-net primitives run through the mapped mailboxes by slot
+    parity -- the code path of `czk-ipc` between GPUs with the three HIP calls (hipMalloc, hipIpcGetMemHandle, hipIpcOpenMemHandle with
+    hipIpcMemLazyEnablePeerAccess) replaced by POSIX segments.  What is left untested until a multi-GPU lease is those three calls and the peer copies."""
+    res = _spawn(_ipc_dry_worker, world, os.urandom(16), slot_bytes)
+    assert res == [(r, True) for r in range(world)]
+
+
 def _shm_timeout_worker(rank, world, q, idb):
     sys.path.insert(0, ROOT)
     import czk_amd

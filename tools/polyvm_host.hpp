@@ -439,10 +439,48 @@ class Machine {
         return {q, rem};
     }
     Arr quotient(const Arr& a, const Fr& x) { return div_linear(a, x).first; }
-    ValueP evaluate(const Arr& a, const Fr& x, int pub = -1) {   // Polynomial::evaluate per lane, without the quotient
+    // Polynomial::evaluate per lane, without the quotient.  The evaluations of a round are collected and go to the GPU together (czk_poly_evaluate_many, one
+    // launch per reduction level for all of them) when the round's transcript point is marked; the polynomial stays referenced until then.
+    ValueP evaluate(const Arr& a, const Fr& x, int pub = -1) {
         ValueP v = value_slot(a.lanes, value_is_open(a, pub));
-        ctx.check(czk_poly_evaluate(ctx.raw(), a.p(), a.n, a.lanes, x.l, vals_.data(0, v->slot), CZK_MEM_DEVICE));
+        eval_queue_.push_back(EvalReq{a, x, v->slot});
         return v;
+    }
+    void flush_evaluations() {
+        if (eval_queue_.empty()) return;
+        std::vector<const uint64_t*> src;
+        std::vector<uint64_t*> dst;
+        std::vector<size_t> n, ln;
+        std::vector<Fr> z;
+        for (const EvalReq& r : eval_queue_) {
+            src.push_back(r.a.p()), dst.push_back(vals_.data(0, r.slot)), n.push_back(r.a.n), ln.push_back(r.a.lanes), z.push_back(r.x);
+        }
+        ctx.check(czk_poly_evaluate_many(ctx.raw(), src.size(), src.data(), n.data(), ln.data(), z[0].l, dst.data()));
+        eval_queue_.clear();
+    }
+    // sum_k c_k a_k over arrays of different lengths, public terms on the lifting lanes only (`plus`): `poly += (coeff, &other)` per term, one pass
+    // (czk_fr_lincomb) instead of a scale, two resizes and an addition per term
+    Arr lincomb(const std::vector<std::pair<Fr, Arr>>& terms) {
+        size_t ln = 1, len = 0;
+        for (auto& t : terms) ln = std::max(ln, t.second.lanes), len = std::max(len, t.second.n);
+        uint64_t mask = 0;
+        for (size_t l = 0; l < lanes && l < 64; l++) mask |= (uint64_t)(lift[l] ? 1 : 0) << l;
+        Arr acc;
+        for (size_t at = 0; at < terms.size();) {
+            std::vector<const uint64_t*> src;
+            std::vector<size_t> n, tl;
+            std::vector<Fr> c;
+            if (acc) src.push_back(acc.p()), n.push_back(acc.n), tl.push_back(acc.lanes), c.push_back(fr_one());
+            for (; at < terms.size() && src.size() < 12; at++) {
+                const Arr& a = terms[at].second;
+                if (a.lanes != ln && a.lanes != 1) throw czk::Panic(CZK_ERR_ARG, "pvm: lincomb of arrays with different lane counts");
+                src.push_back(a.p()), n.push_back(a.n), tl.push_back(a.lanes), c.push_back(terms[at].first);
+            }
+            Arr o = alloc(ln, len);
+            ctx.check(czk_fr_lincomb(ctx.raw(), src.size(), src.data(), n.data(), tl.data(), c[0].l, ln, mask, o.p(), len));
+            acc = o;
+        }
+        return acc;
     }
     // `divide_by_vanishing_poly` in coefficient form: (q, r) with a = q (X^n - 1) + r
     std::pair<Arr, Arr> div_vanishing(const Arr& a, size_t n) {
@@ -458,15 +496,10 @@ class Machine {
             Arr q = strided_merge(resized(qc, L), n, a.lanes);
             return {resized(q, m - n), r};
         }
-        std::vector<Arr> chunks;
-        for (size_t lo = 0; lo < m; lo += n) chunks.push_back(resized(drop_first(a, lo), n));   // the last chunk is zero-padded
-        Arr suffix = chunks.back();
-        std::vector<Arr> q_chunks(chunks.size() - 1);
-        for (size_t j = chunks.size() - 1; j-- > 0;) {
-            q_chunks[j] = suffix;
-            suffix = add(suffix, chunks[j]);
-        }
-        return {resized(concat(q_chunks), m - n), suffix};
+        // q_i = sum_{k >= 1} a_{i + k n}, r_i = sum_{k >= 0} a_{i + k n}: the suffix sums of a's n-coefficient chunks, one pass (czk_poly_div_vanishing)
+        Arr q = alloc(a.lanes, m - n), r = alloc(a.lanes, n);
+        ctx.check(czk_poly_div_vanishing(ctx.raw(), a.p(), m, a.lanes, n, q.p(), r.p(), CZK_MEM_DEVICE));
+        return {q, r};
     }
     // ---- commitments and openings -------------------------------------------------------------------------------------------------------
     CommitmentP commit(const Arr& a, bool gamma_key = false) {   // KZG10::commit's MSM, enqueued (czk_msm_async); transcript_point() settles it
@@ -510,6 +543,7 @@ class Machine {
     // or evaluated SO FAR IN THE REFERENCE'S ORDER must be final.  mark() at that place in the sequence, settle() before the challenge is used; a
     // prover with nothing to enqueue in between calls transcript_point().
     MarkP mark() {
+        flush_evaluations();
         MarkP m = std::make_shared<Mark>();
         m->cmts.swap(pending_cmts_);
         m->vals.swap(pending_vals_);
@@ -540,23 +574,44 @@ class Machine {
   private:
     void settle_one(Mark& m) {
         ctx.wait_mark(m.id);
-        for (CommitmentP& c : m.cmts) {
-            const size_t L = c->jac.size();
-            c->aff.resize(12 * L);
-            c->inf.resize(L);
-            if (!c->jac2.empty()) {   // into_affine, then add_assign_mixed of the blinding commitment (GroupProjective::add_assign_mixed), as polyvm.group_add does
-                std::vector<uint64_t> a2(12 * L);
-                std::vector<uint8_t> i2(L);
-                ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, c->jac[0].x.l, L, c->aff.data(), c->inf.data()));
-                ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, c->jac2[0].x.l, L, a2.data(), i2.data()));
+        // into_affine of every commitment settled here in ONE call (the library shares one field inversion over the array: czk_jac_to_affine); a hiding
+        // commitment first adds its blinding commitment: into_affine of both, add_assign_mixed (GroupProjective::add_assign_mixed, kzg10/mod.rs:188), as
+        // polyvm.group_add does -- the sums then go through the same call
+        auto to_affine = [&](const std::vector<czk::G1Projective>& jac, std::vector<uint64_t>& aff, std::vector<uint8_t>& inf) {
+            aff.resize(12 * jac.size());
+            inf.resize(jac.size());
+            if (!jac.empty()) ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, jac[0].x.l, jac.size(), aff.data(), inf.data()));
+        };
+        std::vector<czk::G1Projective> blinded;
+        std::vector<uint64_t> aff;
+        std::vector<uint8_t> inf;
+        for (CommitmentP& c : m.cmts)
+            if (!c->jac2.empty()) {
+                blinded.insert(blinded.end(), c->jac.begin(), c->jac.end());
+                blinded.insert(blinded.end(), c->jac2.begin(), c->jac2.end());
+            }
+        to_affine(blinded, aff, inf);
+        size_t at = 0;
+        for (CommitmentP& c : m.cmts)
+            if (!c->jac2.empty()) {
+                const size_t L = c->jac.size();
                 for (size_t ln = 0; ln < L; ln++) {
                     czk::G1Projective acc{}, sum;
-                    ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, acc.x.l, &c->aff[12 * ln], c->inf[ln], acc.x.l));
-                    ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, acc.x.l, &a2[12 * ln], i2[ln], sum.x.l));
+                    ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, acc.x.l, &aff[12 * (at + ln)], inf[at + ln], acc.x.l));
+                    ctx.check(czk_jac_add_mixed(ctx.raw(), CZK_G1, acc.x.l, &aff[12 * (at + L + ln)], inf[at + L + ln], sum.x.l));
                     c->jac[ln] = sum;
                 }
+                at += 2 * L;
             }
-            ctx.check(czk_jac_to_affine(ctx.raw(), CZK_G1, c->jac[0].x.l, L, c->aff.data(), c->inf.data()));
+        std::vector<czk::G1Projective> all;
+        for (CommitmentP& c : m.cmts) all.insert(all.end(), c->jac.begin(), c->jac.end());
+        to_affine(all, aff, inf);
+        at = 0;
+        for (CommitmentP& c : m.cmts) {
+            const size_t L = c->jac.size();
+            c->aff.assign(aff.begin() + 12 * at, aff.begin() + 12 * (at + L));
+            c->inf.assign(inf.begin() + at, inf.begin() + at + L);
+            at += L;
             c->keep = c->keep2 = Arr();
             c->settled = true;
         }
@@ -595,6 +650,12 @@ class Machine {
         m.settled = true;
     }
 
+    struct EvalReq {
+        Arr a;
+        Fr x;
+        size_t slot;
+    };
+    std::vector<EvalReq> eval_queue_;
     Arena arena_;
     czk::DeviceLanes vals_, stage_, down_;   // evaluation buffer; upload staging (16 MiB); opened values on their way to the host
     size_t vals_at_ = 0, vals_done_ = 0;   // evaluation rows handed out / already on their way to the host
@@ -643,18 +704,20 @@ inline Output plonk_prove(Machine& B, const PlonkInputs& inp) {
     Arr q_pub = B.quotient(p, w);
     commit("pub_q", q_pub);
     MarkP tp = B.mark();                                               // transcript: p, pub_q
-    // prove_gates (:295-340): d = s (p + pw) + (1 - s)(p pw) - pww, q = d / v_gates -- no challenge enters: enqueued ahead of the first one
+    // prove_gates (:295-340): d = s (p + pw) + (1 - s)(p pw) - pww, q = d / v_gates -- no challenge enters.  Its first two products are enqueued ahead of
+    // the first challenge (they run under the accumulate kernels of p and pub_q), the rest behind the two openings at that challenge: transforms make slow
+    // progress while an accumulate kernel holds the register files, so the openings -- which feed the MSM queue -- must not queue behind all of them
     Arr pw = B.shift(p, w), pww = B.shift(p, ww);
     Arr one_minus_s = B.poly_add_const(B.scale(s_pub, fr_neg(fr_one())), fr_one());   // public: `&(&circ.s * &-F::one()) + &F::one()` (:307-308)
-    Arr d = B.sub(B.padded_add(B.poly_mul(s_pub, B.add(p, pw)), B.poly_mul(one_minus_s, B.poly_mul(p, pw))), B.resized(pww, G + 2 * W - 2));
-    Arr q_gates = B.div_vanishing(d, G).first;
-    pw = pww = one_minus_s = d = Arr();
-    CommitmentP gates_cmt = B.commit(q_gates);
+    Arr s_ppw = B.poly_mul(s_pub, B.add(p, pw)), p_pw = B.poly_mul(p, pw);
     B.settle(tp);
     Fr x = challenge("plonk.public.x");
     open_("pub_q_open", q_pub, x, "pub_q");
     open_("pub_p_open", p, x, "p");
-    out.commitments.emplace_back("gates_q_cmt", gates_cmt);
+    Arr d = B.sub(B.padded_add(s_ppw, B.poly_mul(one_minus_s, p_pw)), B.resized(pww, G + 2 * W - 2));
+    Arr q_gates = B.div_vanishing(d, G).first;
+    pw = pww = one_minus_s = d = s_ppw = p_pw = Arr();
+    commit("gates_q", q_gates);
     tp = B.mark();                                                     // transcript: + the two openings, gates_q
     // prove_wiring's evaluations of p and w over the wire domain (:207-211) depend on no challenge either
     Arr p_evals = B.ntt(p, W, FFT), w_evals = B.ntt(w_pub, W, FFT);
@@ -811,7 +874,7 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
     Arr t_poly = B.ntt(B.mul(inp.t_rows, r_alpha_evals), H, IFFT);      // calculate_t (:400-416)
     commit("t", t_poly, false);                                          // hiding bounds None, Some(1), None (:558-560)
     Arr r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT);
-    Arr summed = B.padded_add(B.scale(z_c, eta_c), B.add(B.scale(z_a, eta_a), B.scale(z_b, eta_b)));   // (:468-476)
+    Arr summed = B.lincomb({{eta_c, z_c}, {eta_a, z_a}, {eta_b, z_b}});   // (:468-476)
     if (summed.n != summed_n || std::max(r_alpha_poly.n + summed.n, t_poly.n + z_poly.n) - 1 != n_rhs) throw czk::Panic(CZK_ERR_ARG, "pvm: marlin second-round sizes");
     Arr rhs = B.resized(B.ntt(B.sub(B.mul(ev(r_alpha_poly), ev(summed)), B.mul(z_poly_ev, ev(t_poly))), mul_size, IFFT), n_rhs);
     Arr q_1 = B.padded_add(mask_poly, rhs);
@@ -929,36 +992,22 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
         }
         sh_open["gamma"] = std::move(sh);
     }
-    // ... and PC::open_combinations (poly-commit/src/marlin/mod.rs:213-300): one polynomial per combination
-    std::map<std::string, Arr> lc_poly;
-    // (insertion order of the Python dict: z_b, g_1, t, g_2, outer_sumcheck, inner_sumcheck, a_denom, b_denom, c_denom -- the order only decides
-    // which arrays exist when; the values do not depend on it)
-    for (auto& kv : lcs) {
-        Arr acc;
-        for (auto& t : kv.second) {
-            Arr term = fr_eq(t.first, one) ? polys[t.second] : B.scale(polys[t.second], t.first);
-            acc = acc ? B.padded_add(acc, term) : term;
-        }
-        lc_poly[kv.first] = acc;
-    }
     B.settle(tp);
     out.evals.emplace_back("evals_beta", evals_beta);
     out.evals.emplace_back("evals_gamma", evals_gamma);
     const Fr ch = challenge("marlin.opening_challenge");
-    // ... then batch_open (poly-commit/src/lib.rs:597-640): per query point the queried polynomials are folded with powers of the opening challenge
-    // and opened once (marlin_pc/mod.rs:259-316); a degree-bounded polynomial takes two challenges and also opens its own witness polynomial over
+    // PC::open_combinations (poly-commit/src/marlin/mod.rs:213-300) forms one polynomial per combination (`poly += (*coeff, cur_poly.polynomial())`, :275),
+    // then batch_open (poly-commit/src/lib.rs:597-640): per query point the queried polynomials are folded with powers of the opening challenge
+    // and opened once (marlin_pc/mod.rs:259-316): sum_j ch^j sum_t c_t p_t = sum over `terms` of (ch^j c_t) p_t -- ONE pass over the operands per
+    // query point (Machine::lincomb) instead of a materialised polynomial per combination; a degree-bounded polynomial takes two challenges and also opens its own witness polynomial over
     // the shifted powers (:291-310, :318-330: the witness AND the witness of its shifted randomness, marlin_pc/mod.rs:294-299 -> kzg10/mod.rs:200-224 --
     // enqueued above, as soon as their point was known)
     for (const char* tagc : {"beta", "gamma"}) {
         const std::string tag = tagc;
-        Arr folded;
         Fr c = one;
         Terms terms;
         std::string shifted;
         for (const std::string& label : query[tag]) {
-            const Arr& a = lc_poly[label];
-            Arr term = fr_eq(c, one) ? a : B.scale(a, c);
-            folded = folded ? B.padded_add(folded, term) : term;
             for (auto& t : lcs[label]) terms.emplace_back(fr_mul(c, t.first), t.second);
             c = fr_mul(c, ch);
             if (label == "g_1" || label == "g_2") {
@@ -967,14 +1016,16 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
             }
         }
         const bool has_rand = sh_rand_open.count(tag) != 0;
+        std::vector<std::pair<Fr, Arr>> fold_terms, rand_terms;
+        for (auto& t : terms) {
+            fold_terms.emplace_back(t.first, polys[t.second]);
+            auto it = blind.find(t.second);
+            if (it != blind.end()) rand_terms.emplace_back(t.first, it->second);
+        }
+        Arr folded = B.lincomb(fold_terms);
         // the folded polynomial with the folded randomness (`r += (challenge_j, &rand.rand)`, :288; KZG10::open :313)
         Arr r_fold;
-        for (auto& t : terms) {
-            auto it = blind.find(t.second);
-            if (it == blind.end()) continue;
-            Arr term = fr_eq(t.first, one) ? it->second : B.scale(it->second, t.first);
-            r_fold = r_fold ? B.add(r_fold, term) : term;
-        }
+        if (!rand_terms.empty()) r_fold = B.lincomb(rand_terms);
         Opening o = B.open_begin(folded, point[tag]);
         Opening rw;
         if (r_fold) rw = B.open_begin(r_fold, point[tag]);

@@ -7,6 +7,7 @@ The trace holds PROOFS proofs made one after another (warm-up included); their b
 all (the host's drain between two proofs).  Prints, for proof WHICH (default: the last), the alternation of stretches in which a PATTERN
 (default k_accumulate) kernel is running and the gaps between them, with the kernels that run inside every gap -- the dependency-forced
 part of a single proof's wall time sits in those gaps."""
+import os
 import sqlite3
 import sys
 
@@ -23,14 +24,14 @@ def is_dom(k):
 
 dom = [(s, e) for k, s, e in rows if is_dom(k)]
 per = len(dom) // proofs
-assert per * proofs == len(dom), f"{len(dom)} '{pat}' dispatches do not divide into {proofs} proofs"
+# (set-up work before the first proof -- the index commitments of Marlin -- may add PATTERN kernels at the head of the trace: count from the tail)
 # Every proof after the first enqueues the same kernels in the same order, and the trace ends with the last proof's last kernel: the number of kernels
 # between the first PATTERN kernel of one proof and the first of the next is a proof's kernel count K, and proof `which` is K kernels ending where
 # the following proofs' kernels begin.  (Idle stretches do not mark the boundary any more: the provers enqueue a proof's first commitment at once.)
 by_start = sorted(range(len(rows)), key=lambda i: rows[i][1])
 dom_pos = [i for i in by_start if is_dom(rows[i][0])]          # positions (in start order) of the PATTERN kernels
 order = {i: n for n, i in enumerate(by_start)}
-K = order[dom_pos[per * (proofs - 1)]] - order[dom_pos[per * (proofs - 2)]]
+K = order[dom_pos[-1]] - order[dom_pos[-1 - per]]
 hi = len(rows) - K * (proofs - 1 - which)
 sel = [rows[i] for i in by_start[hi - K:hi]]
 w0, w1 = min(s for _, s, _ in sel), max(e for _, _, e in sel)
@@ -73,3 +74,7 @@ for i, (a, b) in enumerate(edges):
     print(f"  {(a - w0) / 1e6:8.2f} .. {(b - w0) / 1e6:8.2f}  gap  {(b - a) / 1e6:7.2f} ms  idle {idle / 1e6:5.2f} | " +
           ", ".join(f"{k} x{c} {t / 1e6:.2f}" for k, (t, c) in items))
 print(f"gaps: {tot_gap / 1e6:.2f} ms")
+if os.environ.get("TIMELINE_DUMP"):   # every kernel of the proof in start order: start (ms after the window's start), duration (ms), name
+    with open(os.environ["TIMELINE_DUMP"], "w") as f:
+        for k, s, e, d in sorted(win, key=lambda r: r[1]):
+            f.write(f"{(s - w0) / 1e6:9.3f} {(e - s) / 1e6:8.3f} {'*' if d else ' '} {k}\n")
