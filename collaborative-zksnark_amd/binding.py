@@ -471,14 +471,16 @@ class Context:
         z = np.ascontiguousarray(np.stack([np.asarray(x, np.uint64).reshape(4) for x in zs]) if k else np.zeros((0, 4), np.uint64))
         self._ck(self._L.czk_poly_evaluate_many(self._h, C.c_size_t(k), src, n, ln, _ptr(z if k else None), dst))
 
-    def fr_lincomb(self, ptrs, lens, term_lanes, coeffs, lanes: int, lift_mask: int, out_ptr, out_len: int):
-        """czk_fr_lincomb on DEVICE pointers: out[l][i] = sum_k coeffs[k] * term_k[l][i]; a term with one lane is public (added on the lanes of lift_mask)."""
+    def fr_lincomb(self, ptrs, lens, term_lanes, coeffs, lanes: int, lift_mask: int, out_ptr, out_len: int, constant=None):
+        """czk_fr_lincomb on DEVICE pointers: out[l][i] = constant + sum_k coeffs[k] * term_k[l][i]; a term with one lane -- and the constant -- is public
+        (added on the lanes of lift_mask)."""
         k = len(ptrs)
         src = (C.c_void_p * k)(*[int(p) for p in ptrs])
         n = (C.c_size_t * k)(*[int(x) for x in lens])
         tl = (C.c_size_t * k)(*[int(x) for x in term_lanes])
         c = np.ascontiguousarray(np.stack([np.asarray(x, np.uint64).reshape(4) for x in coeffs]) if k else np.zeros((0, 4), np.uint64))
-        self._ck(self._L.czk_fr_lincomb(self._h, C.c_size_t(k), src, n, tl, _ptr(c if k else None), C.c_size_t(lanes), C.c_uint64(lift_mask), _ptr(out_ptr), C.c_size_t(out_len)))
+        cst = None if constant is None else np.ascontiguousarray(constant, np.uint64).reshape(4)
+        self._ck(self._L.czk_fr_lincomb(self._h, C.c_size_t(k), src, n, tl, _ptr(c if k else None), _ptr(cst), C.c_size_t(lanes), C.c_uint64(lift_mask), _ptr(out_ptr), C.c_size_t(out_len)))
 
     def fr_prefix_product(self, x, out=None, n=None, mem=CZK_MEM_HOST):
         """Running products of a public Fr vector (partial_products' local loop)."""

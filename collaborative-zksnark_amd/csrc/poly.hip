@@ -206,14 +206,15 @@ struct LinTerm {
 };
 struct LinBatch {
     LinTerm t[LINCOMB_MAX];
-    unsigned count;
+    unsigned count, has_const;
     unsigned long long lift_mask;
+    Fr constant;               // a PUBLIC constant on every element (lifting lanes only, like a public term)
 };
 __global__ __launch_bounds__(256) void k_lincomb(LinBatch b, u64* out, size_t out_len) {
     const unsigned lane = blockIdx.y;
     const bool lifts = (b.lift_mask >> (lane & 63)) & 1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < out_len; i += (size_t)gridDim.x * blockDim.x) {
-        Fr acc = Fr::zero();
+        Fr acc = (b.has_const && lifts) ? b.constant : Fr::zero();
         for (unsigned k = 0; k < b.count; k++) {
             const LinTerm& t = b.t[k];
             if (i >= t.len || (t.lane_stride == 0 && !lifts)) continue;
@@ -535,7 +536,7 @@ extern "C" int czk_poly_evaluate_many(czk_ctx* ctx, size_t count, const uint64_t
 }
 
 extern "C" int czk_fr_lincomb(czk_ctx* ctx, size_t count, const uint64_t* const* terms, const size_t* term_len, const size_t* term_lanes, const uint64_t* coeffs,
-                              size_t lanes, uint64_t lift_mask, uint64_t* out, size_t out_len) {
+                              const uint64_t* constant, size_t lanes, uint64_t lift_mask, uint64_t* out, size_t out_len) {
     if (!ctx || (count && (!terms || !term_len || !term_lanes || !coeffs)) || (lanes && out_len && !out)) return ctx ? set_err(ctx, CZK_ERR_ARG, "null fr_lincomb argument") : CZK_ERR_ARG;
     if (count > LINCOMB_MAX) return set_err(ctx, CZK_ERR_SIZE, "czk_fr_lincomb: at most 12 terms per call (chain calls: the result of one is a unit term of the next)");
     if (lanes > 64) return set_err(ctx, CZK_ERR_SIZE, "czk_fr_lincomb: at most 64 lanes (the lift mask)");
@@ -544,6 +545,8 @@ extern "C" int czk_fr_lincomb(czk_ctx* ctx, size_t count, const uint64_t* const*
     LinBatch b;
     b.count = (unsigned)count;
     b.lift_mask = lanes == 1 ? ~0ull : lift_mask;   // a public result takes every public term
+    b.has_const = constant ? 1 : 0;
+    b.constant = constant ? host_fr(constant) : Fr::zero();
     static const Fr ONE = Fr::one();
     for (size_t k = 0; k < count; k++) {
         if (term_lanes[k] != lanes && term_lanes[k] != 1) return set_err(ctx, CZK_ERR_ARG, "czk_fr_lincomb: a term has `lanes` lanes or one (public)");

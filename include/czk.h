@@ -380,14 +380,15 @@ int czk_poly_evaluate(czk_ctx* ctx, const uint64_t* coeffs, size_t n, size_t lan
  * and the upper levels of one evaluation are a few dozen elements -- launch-bound when issued one polynomial at a time. */
 int czk_poly_evaluate_many(czk_ctx* ctx, size_t count, const uint64_t* const* coeffs, const size_t* n, const size_t* lanes, const uint64_t* z,
                            uint64_t* const* values);
-/* out[l][i] = sum_k coeffs[k] * terms[k][l][i], i < out_len, over `count` <= 12 DEVICE arrays of different lengths (term_len[k] elements per lane; shorter
- * terms end early, longer ones are cut at out_len), coeffs: count x 4 u64, HOST, Montgomery.  A term has `lanes` lanes (term_lanes[k] == lanes) or is
- * PUBLIC (term_lanes[k] == 1): a public term is added on the lanes whose bit is set in `lift_mask` only -- the rule by which the reference adds a public
+/* out[l][i] = constant + sum_k coeffs[k] * terms[k][l][i], i < out_len, over `count` <= 12 DEVICE arrays of different lengths (term_len[k] elements per lane; shorter
+ * terms end early, longer ones are cut at out_len), coeffs: count x 4 u64, HOST, Montgomery; constant: one Fr, HOST, Montgomery, or NULL (zero).  A term has
+ * `lanes` lanes (term_lanes[k] == lanes) or is PUBLIC (term_lanes[k] == 1): a public term -- and the constant, which is public -- is added on the lanes whose
+ * bit is set in `lift_mask` only -- the rule by which the reference adds a public
  * value to a shared one (AdditiveFieldShare::shift, mpc-algebra/src/share/add.rs:141-146: the king; GszFieldShare: every party).  One pass: the linear
  * combinations of polynomials a prover forms -- `poly += (*coeff, cur_poly.polynomial())` per term (poly-commit/src/marlin/mod.rs:275; the batch opening's
  * fold, marlin_pc/mod.rs:259-316; marlin/src/ahp/prover.rs:468-476) -- where a scale / resize / add chain makes a pass over memory per call. */
 int czk_fr_lincomb(czk_ctx* ctx, size_t count, const uint64_t* const* terms, const size_t* term_len, const size_t* term_lanes, const uint64_t* coeffs,
-                   size_t lanes, uint64_t lift_mask, uint64_t* out, size_t out_len);
+                   const uint64_t* constant, size_t lanes, uint64_t lift_mask, uint64_t* out, size_t out_len);
 int czk_poly_div_vanishing(czk_ctx* ctx, const uint64_t* coeffs, size_t m, size_t lanes, size_t n, uint64_t* quotient, uint64_t* remainder, int mem);
 
 /* out[i] = x[0] * x[1] * ... * x[i] over a PUBLIC vector: the sequential loop of partial_products between its

@@ -122,7 +122,7 @@ extern "C" {
     pub fn czk_poly_div_linear(ctx: *mut czk_ctx, coeffs: *const u64, n: usize, lanes: usize, z: *const u64, quotient: *mut u64, remainder: *mut u64, mem: c_int) -> c_int;
     pub fn czk_poly_evaluate(ctx: *mut czk_ctx, coeffs: *const u64, n: usize, lanes: usize, z: *const u64, values: *mut u64, mem: c_int) -> c_int;
     pub fn czk_poly_evaluate_many(ctx: *mut czk_ctx, count: usize, coeffs: *const *const u64, n: *const usize, lanes: *const usize, z: *const u64, values: *const *mut u64) -> c_int;
-    pub fn czk_fr_lincomb(ctx: *mut czk_ctx, count: usize, terms: *const *const u64, term_len: *const usize, term_lanes: *const usize, coeffs: *const u64, lanes: usize, lift_mask: u64, out: *mut u64, out_len: usize) -> c_int;
+    pub fn czk_fr_lincomb(ctx: *mut czk_ctx, count: usize, terms: *const *const u64, term_len: *const usize, term_lanes: *const usize, coeffs: *const u64, constant: *const u64, lanes: usize, lift_mask: u64, out: *mut u64, out_len: usize) -> c_int;
     pub fn czk_poly_div_vanishing(ctx: *mut czk_ctx, coeffs: *const u64, m: usize, lanes: usize, n: usize, quotient: *mut u64, remainder: *mut u64, mem: c_int) -> c_int;
     pub fn czk_fr_prefix_product(ctx: *mut czk_ctx, x: *const u64, n: usize, out: *mut u64, mem: c_int) -> c_int;
     pub fn czk_fr_batch_inverse(ctx: *mut czk_ctx, v: *const u64, n: usize, coeff: *const u64, out: *mut u64, mem: c_int) -> c_int;

@@ -714,11 +714,12 @@ def test_fr_lincomb_matches_checker(ctx, czk, orc):
     dev = [torch.from_numpy(t.view(np.int64).copy()).cuda() for t in terms]
     out = torch.full((lanes, out_len, 4), -1, dtype=torch.int64, device="cuda")
     torch.cuda.synchronize()
-    ctx.fr_lincomb([d.data_ptr() for d in dev], [n for _, n in spec], [ln for ln, _ in spec], coeffs, lanes, mask, out.data_ptr(), out_len)
+    cst = orc.fr_from_repr(rand_fr_canonical(899, 1))[0]
+    ctx.fr_lincomb([d.data_ptr() for d in dev], [n for _, n in spec], [ln for ln, _ in spec], coeffs, lanes, mask, out.data_ptr(), out_len, constant=cst)
     ctx.sync()
     got = out.cpu().numpy().view(np.uint64)
     for l in range(lanes):
-        want = np.zeros((out_len, 4), dtype=np.uint64)
+        want = np.tile(cst, (out_len, 1)) if (mask >> l) & 1 else np.zeros((out_len, 4), dtype=np.uint64)   # the constant is public: lifting lanes only
         for (ln, n), t, c in zip(spec, terms, coeffs):
             if ln == 1 and not (mask >> l) & 1:
                 continue

@@ -345,13 +345,14 @@ static int polyiop(const char* workload, int argc, char** argv) {
     double arena_gb = 0;
     const char* dump = nullptr;
     int rank = -1, world = 0, transport = CZK_NET_SHM, device = 0;
-    bool commit_opens = true;
+    bool commit_opens = true, breakdown = false;
     std::vector<std::pair<std::string, long>> ctx_options;
     std::vector<uint8_t> id;
     for (int i = 2; i < argc; i++) {
         auto val = [&]() -> const char* { return i + 1 < argc ? argv[++i] : "0"; };
         if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
         else if (!strcmp(argv[i], "--no-commit-opens")) commit_opens = false;
+        else if (!strcmp(argv[i], "--breakdown")) breakdown = true;
         else if (!strcmp(argv[i], "--ctx-option")) {   // NAME=VALUE: czk_ctx_set_option on every context before its first MSM (repeatable)
             const std::string kv = val();
             const size_t eq = kv.find('=');
@@ -472,6 +473,63 @@ static int polyiop(const char* workload, int argc, char** argv) {
     t0 = clk::now();
     prove(provers[0]);                                             // one proof alone
     const double alone_ms = secs(t0, clk::now()) * 1e3;
+    // --breakdown: ONE more proof alone, with the accumulate kernels' HIP-event intervals (czk_profile_intervals) laid over the host times at which the
+    // transcript points' waits returned: per round (from one challenge to the next) the time an accumulate kernel was running, the head (challenge ->
+    // first accumulate kernel: witness polynomials, digit sort), the stalls between accumulate kernels (the next commitment's polynomial was not ready)
+    // and the tail (last accumulate kernel -> results on the host: bucket reduction, copy, conversion to affine)
+    std::string breakdown_json;
+    if (breakdown) {
+        Context& c = *provers[0].ctx;
+        std::vector<clk::time_point> log;
+        provers[0].B->settle_log = &log;
+        c.sync();
+        c.check(czk_profile_reset(c.raw()));
+        c.check(czk_profile_enable(c.raw(), 1));
+        const auto base = clk::now();
+        prove(provers[0]);
+        c.sync();
+        const auto fin = clk::now();
+        c.check(czk_profile_enable(c.raw(), 0));
+        provers[0].B->settle_log = nullptr;
+        size_t n_iv = 0;
+        std::vector<double> s0(4096), s1(4096);
+        c.check(czk_profile_intervals(c.raw(), "msm_accumulate_g1", s0.data(), s1.data(), s0.size(), &n_iv));
+        std::vector<std::pair<double, double>> iv;
+        for (size_t i = 0; i < n_iv && i < s0.size(); i++) iv.emplace_back(s0[i], s1[i]);
+        std::sort(iv.begin(), iv.end());
+        static const char* PLONK_TP[] = {"p, pub_q committed", "2 openings at x_pub, gates_q committed", "5 openings at x_gates", "l1, t, q committed (l2_q enqueued)",
+                                         "5 openings at r, l2_q committed", "4 openings at x_wiring"};
+        static const char* MARLIN_TP[] = {"round 1: w, z_a, z_b, mask_poly", "round 2: t, g_1, h_1", "round 3: g_2, h_2 (+ g_1's degree-bound opening)",
+                                          "evaluations at beta, gamma", "batched openings"};
+        double prev = 0, tot_busy = 0, tot_head = 0, tot_stall = 0, tot_tail = 0;
+        breakdown_json = "[";
+        for (size_t r = 0; r < log.size(); r++) {
+            const double end = secs(base, log[r]) * 1e3;
+            double busy = 0, first = -1, last = prev, cur = prev;
+            size_t launches = 0;
+            for (auto& v : iv) {
+                const double a = std::max(v.first, prev), b = std::min(v.second, end);
+                if (b <= a) continue;
+                if (first < 0) first = a;
+                if (a > cur) cur = a;
+                if (b > cur) busy += b - cur, cur = b;
+                last = std::max(last, b);
+                launches++;
+            }
+            const double wall = end - prev, head = first < 0 ? wall : first - prev, tail = first < 0 ? 0 : end - last, stall = wall - busy - head - tail;
+            const char* label = plonk ? (r < 6 ? PLONK_TP[r] : "?") : (r < 5 ? MARLIN_TP[r] : "?");
+            char buf[512];
+            snprintf(buf, sizeof buf, "%s{\"round\": \"%s\", \"wall_ms\": %.2f, \"accumulate_busy_ms\": %.2f, \"head_ms\": %.2f, \"stall_ms\": %.2f, \"tail_ms\": %.2f, \"accumulate_launches\": %zu}",
+                     r ? ", " : "", label, wall, busy, head, stall, tail, launches);
+            breakdown_json += buf;
+            tot_busy += busy, tot_head += head, tot_stall += stall, tot_tail += tail;
+            prev = end;
+        }
+        char buf[384];
+        snprintf(buf, sizeof buf, "%s{\"round\": \"total\", \"wall_ms\": %.2f, \"accumulate_busy_ms\": %.2f, \"head_ms\": %.2f, \"stall_ms\": %.2f, \"tail_ms\": %.2f, \"proof_ms\": %.2f}]",
+                 log.empty() ? "" : ", ", prev, tot_busy, tot_head, tot_stall, tot_tail, secs(base, fin) * 1e3);
+        breakdown_json += buf;
+    }
     for (auto& p : provers) p.B->msm_count = p.B->ntt_count = p.B->msm_points = 0;
     std::vector<size_t> share(inflight);
     for (size_t k = 0; k < inflight; k++) share[k] = steps / inflight + (k < steps % inflight ? 1 : 0);
@@ -505,11 +563,11 @@ static int polyiop(const char* workload, int argc, char** argv) {
     printf("{\"harness\": \"tools/host_demo.cpp %s (C++ over include/czk.h: tools/polyvm_host.hpp; no torch, no Python)\", \"workload\": \"%s\", \"constraints\": %zu, "
            "\"parties\": %zu, \"layout\": \"%s\", \"transport\": \"%s\", \"share_lanes\": %zu, \"steps\": %zu, \"warmup\": %zu, \"proofs_in_flight\": %zu, \"ms_per_proof\": %.4f, \"proofs_per_s\": %.5f, "
            "\"latency_ms_single_proof\": %.3f, \"first_proof_ms\": %.3f, \"setup_s\": %.3f, \"msms_per_proof\": %.1f, \"ntt_lanes_per_proof\": %.1f, "
-           "\"arena_peak_gb\": %.2f, \"commit_opens\": %s, \"in_flight_provers_equal\": true, \"output_sha256\": \"%s\"}\n",
+           "\"arena_peak_gb\": %.2f, \"commit_opens\": %s, \"in_flight_provers_equal\": true, \"output_sha256\": \"%s\"%s%s}\n",
            workload, workload, n, parties, party ? "party (one process per party, evaluations opened through czk_net)" : "one process",
            party ? transport_name(transport) : "none", lanes, steps, warmup,
            inflight, dt / steps * 1e3, steps / dt, alone_ms, first_ms, setup_s, (double)msms / steps,
-           (double)ntts / steps, provers[0].B->arena_peak_bytes() / 1e9, (party && !plonk) ? (commit_opens ? "true" : "false") : "null", hex(digest, 32).c_str());
+           (double)ntts / steps, provers[0].B->arena_peak_bytes() / 1e9, (party && !plonk) ? (commit_opens ? "true" : "false") : "null", hex(digest, 32).c_str(), breakdown ? ", \"single_proof_breakdown\": " : "", breakdown_json.c_str());
     if (net) {
         provers[0].B->net = nullptr;
         net.reset();   // the communicator goes before its context

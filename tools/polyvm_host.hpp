@@ -17,6 +17,7 @@
 // (CZK_MEM_SCALAR_HOST).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <deque>
 #include <map>
@@ -201,6 +202,7 @@ class Machine {
     unsigned gsz_degree = 0;
     Fr mac_share{};
     std::vector<std::vector<Fr>> opened;       // what the opens returned, in order (reset by the caller per proof)
+    std::vector<std::chrono::steady_clock::time_point>* settle_log = nullptr;   // when each transcript point's wait returned (tools/host_demo.cpp --breakdown)
 
     Machine(const czk::Context& c, size_t lanes_, size_t max_degree, std::vector<int> lift_, size_t arena_elems, std::shared_ptr<Srs> share = nullptr,
             uint64_t base_seed = 0xBA5E5 + 77)
@@ -416,6 +418,23 @@ class Machine {
         const size_t n = a.n + b.n - 1, size = next_pow2(n);
         return resized(ntt(mul(ntt(a, size, FFT), ntt(b, size, FFT)), size, IFFT), n);
     }
+    // a b c over ONE domain: the reference forms `&a * &(&b * &c)` as two products, interpolating b c and transforming it again -- on the SAME domain whenever
+    // next_pow2(len b + len c - 1) == next_pow2(len a + len b + len c - 2); the inverse transform followed by the forward one is then the identity on
+    // exact field elements, so multiplying the three evaluation vectors gives the same coefficients with two transforms fewer per lane
+    Arr poly_mul3(const Arr& a, const Arr& b, const Arr& c) {
+        const size_t n = a.n + b.n + c.n - 2, size = next_pow2(n);
+        if (next_pow2(b.n + c.n - 1) != size) return poly_mul(a, poly_mul(b, c));
+        return resized(ntt(mul(ntt(a, size, FFT), mul(ntt(b, size, FFT), ntt(c, size, FFT))), size, IFFT), n);
+    }
+    // out[i] = a[(i + k) mod n] per lane: the evaluations of f(w^k X) over a domain (or a coset of it) generated by w are those of f, k places on
+    Arr rotated(const Arr& a, size_t k) {
+        k %= a.n;
+        if (k == 0) return a;
+        Arr o = alloc(a.lanes, a.n);
+        copy(o, 0, {0, a.n, 1}, &a, k, {0, a.n, 1}, {1, a.lanes, a.n - k});
+        copy(o, a.n - k, {0, a.n, 1}, &a, 0, {0, a.n, 1}, {1, a.lanes, k});
+        return o;
+    }
     Arr padded_add(const Arr& a, const Arr& b) {
         const size_t n = std::max(a.n, b.n);
         return plus(resized(a, n), resized(b, n));
@@ -460,7 +479,7 @@ class Machine {
     }
     // sum_k c_k a_k over arrays of different lengths, public terms on the lifting lanes only (`plus`): `poly += (coeff, &other)` per term, one pass
     // (czk_fr_lincomb) instead of a scale, two resizes and an addition per term
-    Arr lincomb(const std::vector<std::pair<Fr, Arr>>& terms) {
+    Arr lincomb(const std::vector<std::pair<Fr, Arr>>& terms, const Fr* constant = nullptr) {
         size_t ln = 1, len = 0;
         for (auto& t : terms) ln = std::max(ln, t.second.lanes), len = std::max(len, t.second.n);
         uint64_t mask = 0;
@@ -477,7 +496,7 @@ class Machine {
                 src.push_back(a.p()), n.push_back(a.n), tl.push_back(a.lanes), c.push_back(terms[at].first);
             }
             Arr o = alloc(ln, len);
-            ctx.check(czk_fr_lincomb(ctx.raw(), src.size(), src.data(), n.data(), tl.data(), c[0].l, ln, mask, o.p(), len));
+            ctx.check(czk_fr_lincomb(ctx.raw(), src.size(), src.data(), n.data(), tl.data(), c[0].l, (constant && !acc) ? constant->l : nullptr, ln, mask, o.p(), len));
             acc = o;
         }
         return acc;
@@ -574,6 +593,7 @@ class Machine {
   private:
     void settle_one(Mark& m) {
         ctx.wait_mark(m.id);
+        if (settle_log) settle_log->push_back(std::chrono::steady_clock::now());
         // into_affine of every commitment settled here in ONE call (the library shares one field inversion over the array: czk_jac_to_affine); a hiding
         // commitment first adds its blinding commitment: into_affine of both, add_assign_mixed (GroupProjective::add_assign_mixed, kzg10/mod.rs:188), as
         // polyvm.group_add does -- the sums then go through the same call
@@ -709,14 +729,15 @@ inline Output plonk_prove(Machine& B, const PlonkInputs& inp) {
     // progress while an accumulate kernel holds the register files, so the openings -- which feed the MSM queue -- must not queue behind all of them
     Arr pw = B.shift(p, w), pww = B.shift(p, ww);
     Arr one_minus_s = B.poly_add_const(B.scale(s_pub, fr_neg(fr_one())), fr_one());   // public: `&(&circ.s * &-F::one()) + &F::one()` (:307-308)
-    Arr s_ppw = B.poly_mul(s_pub, B.add(p, pw)), p_pw = B.poly_mul(p, pw);
+    Arr s_ppw = B.poly_mul(s_pub, B.add(p, pw));
     B.settle(tp);
     Fr x = challenge("plonk.public.x");
     open_("pub_q_open", q_pub, x, "pub_q");
     open_("pub_p_open", p, x, "p");
-    Arr d = B.sub(B.padded_add(s_ppw, B.poly_mul(one_minus_s, p_pw)), B.resized(pww, G + 2 * W - 2));
+    // (1 - s) (p pw): `&(&(&circ.s * &-F::one()) + &F::one()) * &(p.polynomial() * &pw)` (:307) on one domain (Machine::poly_mul3: same coefficients, two transforms per lane fewer)
+    Arr d = B.sub(B.padded_add(s_ppw, B.poly_mul3(one_minus_s, p, pw)), B.resized(pww, G + 2 * W - 2));
     Arr q_gates = B.div_vanishing(d, G).first;
-    pw = pww = one_minus_s = d = s_ppw = p_pw = Arr();
+    pw = pww = one_minus_s = d = s_ppw = Arr();
     commit("gates_q", q_gates);
     tp = B.mark();                                                     // transcript: + the two openings, gates_q
     // prove_wiring's evaluations of p and w over the wire domain (:207-211) depend on no challenge either
@@ -737,16 +758,21 @@ inline Output plonk_prove(Machine& B, const PlonkInputs& inp) {
     Arr l1_evals = B.mul(num_evals, B.inverse(den_evals));
     Arr l1 = B.ntt(l1_evals, W, IFFT);
     commit("l1", l1);
-    // prove_unit_product(l1) (:115-198)
-    Arr t = B.ntt(B.prefix_product(B.ntt(l1, W, FFT)), W, IFFT);
+    // prove_unit_product(l1) (:115-198).  Three transforms of the reference's sequence are identities on exact field elements and are not repeated here:
+    //   f.evaluate_over_domain_by_ref (:119) of f = l1 = l1_evals.interpolate() (:217) is l1_evals itself;
+    //   the coset evaluations of f(w X) and t(w X) (distribute_powers by w, then coset_fft: :141-143, :151-153) are those of f and t, one place on
+    //   (w = domain.element(1) generates the wire domain: f(w g w^i) = f(g w^(i+1)));
+    //   and l1's coset evaluations serve the product argument and l2_q (:224) alike.
+    Arr t = B.ntt(B.prefix_product(l1_evals), W, IFFT);
     commit("t", t);
-    Arr f_c = B.ntt(B.shift(l1, w), W, COSET_FFT), t_c = B.ntt(t, W, COSET_FFT), tw_c = B.ntt(B.shift(t, w), W, COSET_FFT);
+    Arr l1_v = B.ntt(l1, W, COSET_FFT), t_c = B.ntt(t, W, COSET_FFT);
+    Arr f_c = B.rotated(l1_v, 1), tw_c = B.rotated(t_c, 1);
     Arr q_up = B.ntt(B.scale(B.sub(tw_c, B.mul(f_c, t_c)), zinv_w), W, COSET_IFFT);
     commit("q", q_up);
     tp = B.mark();                                                     // transcript: l1, t, q
     // l2_q (:228-243) depends on y and z only: enqueued ahead of the product argument's challenge r
     Arr num_c = B.ntt(num_evals, W, IFFT), den_c = B.ntt(den_evals, W, IFFT);   // interpolate() of both before the coset transforms (:225-226)
-    Arr l1_v = B.ntt(l1, W, COSET_FFT), num_v = B.ntt(num_c, W, COSET_FFT), den_v = B.ntt(den_c, W, COSET_FFT);
+    Arr num_v = B.ntt(num_c, W, COSET_FFT), den_v = B.ntt(den_c, W, COSET_FFT);
     Arr l2_q = B.ntt(B.scale(B.sub(B.mul(l1_v, den_v), num_v), zinv_w), W, COSET_IFFT);
     CommitmentP l2_cmt = B.commit(l2_q);
     B.settle(tp);
@@ -858,15 +884,20 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
     publish("mask_poly", mask_cmt);
     MarkP tp = B.mark();                                                 // transcript: the first round's four commitments
     // ---- second round (:439-556); what depends on no challenge comes first -------------------------------------------------------------
-    Arr z_c = B.poly_mul(z_a, z_b);                                     // shared x shared (:466)
     Arr hpow = B.powers(B.root_of_unity(H), H);
     x_poly = B.ntt(inp.x, X, IFFT);                                      // interpolated again in the second round (:503-507)
     Arr z_poly = B.padded_add(mul_by_vanishing(B, w_poly, X), x_poly);  // w v_X + x (:512-517)
-    const size_t summed_n = std::max(z_c.n, std::max(z_a.n, z_b.n));
+    const size_t z_c_n = z_a.n + z_b.n - 1;                              // z_c = z_a z_b, shared x shared (:466)
+    const size_t summed_n = std::max(z_c_n, std::max(z_a.n, z_b.n));
     const size_t n_rhs = std::max(H + summed_n, H + z_poly.n) - 1;      // r_alpha_poly and t_poly have |H| coefficients
     const size_t mul_size = next_pow2(std::max(mask_poly.n, n_rhs + 1));   // GeneralEvaluationDomain::new(max(..)) (:522-531)
     auto ev = [&](const Arr& a) { return B.ntt(a, mul_size, FFT); };
     Arr z_poly_ev = ev(z_poly);
+    // The reference forms z_c = z_a z_b, then summed = eta_c z_c + eta_a z_a + eta_b z_b (:468-476), and evaluates `summed` over the product domain (:526).
+    // The transform is linear and multiplicative on exact field elements (deg z_c < |domain|), so those evaluations are
+    // eta_c ev(z_a) ev(z_b) + eta_a ev(z_a) + eta_b ev(z_b): the two transforms need no challenge and run ahead of it; z_c's coefficients are used nowhere else
+    Arr za_ev = ev(z_a), zb_ev = ev(z_b);
+    Arr zc_ev = B.mul(za_ev, zb_ev);
     B.settle(tp);
     const Fr alpha = challenge("marlin.alpha"), eta_a = challenge("marlin.eta_a"), eta_b = challenge("marlin.eta_b"), eta_c = challenge("marlin.eta_c");
     // r(alpha, X) on H, unnormalised bivariate Lagrange: (alpha^|H| - 1) / (alpha - h^i)  (:480-482), public
@@ -874,13 +905,13 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
     Arr t_poly = B.ntt(B.mul(inp.t_rows, r_alpha_evals), H, IFFT);      // calculate_t (:400-416)
     commit("t", t_poly, false);                                          // hiding bounds None, Some(1), None (:558-560)
     Arr r_alpha_poly = B.ntt(r_alpha_evals, H, IFFT);
-    Arr summed = B.lincomb({{eta_c, z_c}, {eta_a, z_a}, {eta_b, z_b}});   // (:468-476)
-    if (summed.n != summed_n || std::max(r_alpha_poly.n + summed.n, t_poly.n + z_poly.n) - 1 != n_rhs) throw czk::Panic(CZK_ERR_ARG, "pvm: marlin second-round sizes");
-    Arr rhs = B.resized(B.ntt(B.sub(B.mul(ev(r_alpha_poly), ev(summed)), B.mul(z_poly_ev, ev(t_poly))), mul_size, IFFT), n_rhs);
+    Arr summed_ev = B.lincomb({{eta_c, zc_ev}, {eta_a, za_ev}, {eta_b, zb_ev}});
+    if (std::max(r_alpha_poly.n + summed_n, t_poly.n + z_poly.n) - 1 != n_rhs) throw czk::Panic(CZK_ERR_ARG, "pvm: marlin second-round sizes");
+    Arr rhs = B.resized(B.ntt(B.sub(B.mul(ev(r_alpha_poly), summed_ev), B.mul(z_poly_ev, ev(t_poly))), mul_size, IFFT), n_rhs);
     Arr q_1 = B.padded_add(mask_poly, rhs);
     auto hx = B.div_vanishing(q_1, H);
     Arr h_1 = hx.first, g_1 = B.drop_first(hx.second, 1);
-    z_c = hpow = z_poly_ev = summed = rhs = q_1 = r_alpha_evals = Arr();
+    hpow = z_poly_ev = summed_ev = za_ev = zb_ev = zc_ev = rhs = q_1 = r_alpha_evals = Arr();
     commit("g_1", g_1, true);
     commit("g_1_shifted", g_1, true);                                    // the degree bound's second commitment over the shifted powers, own blinding (marlin_pc/mod.rs:218-232)
     commit("h_1", h_1, false);
@@ -897,28 +928,27 @@ inline Output marlin_prove(Machine& B, const MarlinInputs& inp) {
     const Fr vh = fr_mul(vanishing(H, alpha), vanishing(H, beta));
     const Fr etas[3] = {eta_a, eta_b, eta_c};
     const Fr minus_one = fr_neg(fr_one());
-    Arr f_evals, den_b[3], val_b[3];
+    // (each affine combination below is one pass -- Machine::lincomb with a constant -- where the reference's statement is a chain of vector operations;
+    // the scalars eta_M and v_H(alpha) v_H(beta) multiply into one coefficient: the field is exact and associative)
+    Arr den_b[3], val_b[3], val_inv[3];
+    const Fr alpha_beta = fr_mul(beta, alpha);
     for (int i = 0; i < 3; i++) {
         const Arr &row = inp.star[i].on_K[0], &col = inp.star[i].on_K[1], &val = inp.star[i].on_K[2];
-        Arr inv = B.inverse(B.mul(B.add_const(B.scale(row, minus_one), beta), B.add_const(B.scale(col, minus_one), alpha)));   // (:612-620)
-        Arr term = B.scale(B.mul(val, inv), etas[i]);
-        f_evals = f_evals ? B.add(f_evals, term) : term;
+        Arr inv = B.inverse(B.mul(B.lincomb({{minus_one, row}}, &beta), B.lincomb({{minus_one, col}}, &alpha)));   // 1 / ((beta - row)(alpha - col))  (:612-620)
+        val_inv[i] = B.mul(val, inv);
         const Arr &rb = inp.star[i].on_B[0], &cb = inp.star[i].on_B[1], &rcb = inp.star[i].on_B[2], &vb = inp.star[i].on_B[3];
         // beta alpha - r alpha - beta c + r_c  (:641-658)
-        den_b[i] = B.add_const(B.add(B.sub(rcb, B.scale(rb, alpha)), B.scale(cb, fr_neg(beta))), fr_mul(beta, alpha));
+        den_b[i] = B.lincomb({{fr_one(), rcb}, {fr_neg(alpha), rb}, {fr_neg(beta), cb}}, &alpha_beta);
         val_b[i] = vb;
     }
-    Arr f = B.ntt(B.scale(f_evals, vh), K, IFFT);
+    Arr f = B.ntt(B.lincomb({{fr_mul(etas[0], vh), val_inv[0]}, {fr_mul(etas[1], vh), val_inv[1]}, {fr_mul(etas[2], vh), val_inv[2]}}), K, IFFT);
     Arr g_2 = B.drop_first(f, 1);
     commit("g_2", g_2, false);
     commit("g_2_shifted", g_2, false);                                   // degree bound |K| - 2
-    Arr a_on_b;
     const int others[3][2] = {{1, 2}, {0, 2}, {0, 1}};
-    for (int m = 0; m < 3; m++) {
-        Arr term = B.scale(B.mul(val_b[m], B.mul(den_b[others[m][0]], den_b[others[m][1]])), etas[m]);   // (:664-673)
-        a_on_b = a_on_b ? B.add(a_on_b, term) : term;
-    }
-    Arr a_poly = B.resized(B.ntt(B.scale(a_on_b, vh), b_size, IFFT), 3 * K - 2);   // degree 3 |K| - 3 in a real index: 3 |K| - 2 coefficients
+    std::vector<std::pair<Fr, Arr>> a_terms;
+    for (int m = 0; m < 3; m++) a_terms.emplace_back(fr_mul(etas[m], vh), B.mul(val_b[m], B.mul(den_b[others[m][0]], den_b[others[m][1]])));   // (:664-673)
+    Arr a_poly = B.resized(B.ntt(B.lincomb(a_terms), b_size, IFFT), 3 * K - 2);   // degree 3 |K| - 3 in a real index: 3 |K| - 2 coefficients
     Arr b_poly = B.resized(B.ntt(B.mul(den_b[0], B.mul(den_b[1], den_b[2])), b_size, IFFT), 3 * K - 2);
     Arr bf = B.poly_mul(b_poly, f);
     Arr h_2 = B.div_vanishing(B.sub(B.resized(a_poly, bf.n), bf), K).first;   // (a - b f) / v_K (:693-696)
