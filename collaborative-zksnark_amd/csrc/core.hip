@@ -364,7 +364,7 @@ extern "C" int czk_ctx_create(czk_ctx** out, int device, void* hip_stream) {
             {"CZK_REDUCE_SAT_G2", "msm_reduce_sat_g2"}, {"CZK_G2_MODE", "msm_g2_mode"}, {"CZK_MSM_AFFINE", "msm_affine_rounds"}, {"CZK_MSM_SLOTS", "msm_slots"},
             {"CZK_STREAM_PRIO", "msm_stream_priority"}, {"CZK_MSM_SAT", "msm_sat"}, {"CZK_MSM_SAT_G2", "msm_sat_g2"}, {"CZK_MSM_NO_TE", "msm_no_te"},
             {"CZK_MSM_FIXED_C", "msm_fixed_c"}, {"CZK_MSM_C_G1", "msm_window_g1"}, {"CZK_MSM_C_G2", "msm_window_g2"}, {"CZK_CHAOS", "chaos"},
-            {"CZK_CHAOS_DROP_WAIT", "chaos_drop_wait"}, {"CZK_NTT_SKIP_COSET_FIRST", "ntt_skip_coset_first"}, {"CZK_G1_LANE_PAIRS", "msm_g1_lane_pairs"}};
+            {"CZK_CHAOS_DROP_WAIT", "chaos_drop_wait"}, {"CZK_NTT_SKIP_COSET_FIRST", "ntt_skip_coset_first"}, {"CZK_LANE_INTERLEAVE", "msm_lane_interleave"}};
         for (auto& e : ENV)
             if (const char* v = getenv(e[0])) (void)czk_ctx_set_option(c, e[1], atol(v) ? atol(v) : (v[0] == '0' ? 0 : 1));
     }
@@ -424,6 +424,7 @@ struct OptDesc {
 const OptDesc OPTIONS[] = {
     {"msm_slots", 1, czk_ctx::MSM_SLOTS, true, [](czk_ctx* c, long v) { c->msm_slots_in_use = (int)v; }},
     {"msm_stream_priority", 0, 2, true, [](czk_ctx* c, long v) { c->msm_stream_prio = (int)v; }},
+    {"msm_lane_interleave", 0, 64, false, [](czk_ctx* c, long v) { c->msm_lane_interleave = (int)v; }},
     {"msm_sort_onepass", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sort_onepass = v != 0; }},
     {"msm_fixed_c", 0, 1, false, [](czk_ctx* c, long v) { c->msm_fixed_c = v != 0; }},
     {"msm_window_g1", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g1 = (unsigned)v; }},
@@ -443,7 +444,7 @@ const OptDesc OPTIONS[] = {
     {"chaos", 0, 0x7fffffff, false, [](czk_ctx* c, long v) { c->chaos = v ? ((unsigned long long)v * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)getpid() << 32) ^ (unsigned long long)(uintptr_t)c : 0; }},
     {"chaos_drop_wait", 0, 2, false, [](czk_ctx* c, long v) { c->chaos_drop_wait = (int)v; }},
     {"ntt_skip_coset_first", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_skip_coset_first = v != 0; }},
-    {"msm_g1_lane_pairs", 0, 1, false, [](czk_ctx* c, long v) { c->msm_g1_lane_pairs = v != 0; }},
+
 #endif
 };
 }  // namespace

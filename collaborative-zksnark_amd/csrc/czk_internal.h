@@ -86,6 +86,9 @@ struct CtxMark {
 };
 }  // namespace czk
 
+#ifndef CZK_ACC_INTERLEAVE_DEFAULT
+#define CZK_ACC_INTERLEAVE_DEFAULT 4u
+#endif
 struct czk_ctx {
     std::vector<czk::DeviceBuf> stage_pool;   // idle staging buffers of host-memory callers (core.hip)
     // pinned double buffer of czk_lanes_upload / czk_lanes_download (lanes.hip)
@@ -111,6 +114,8 @@ struct czk_ctx {
     bool msm_sort_onepass = false;   // "msm_sort_onepass": the single-pass digit sort for every call (it is the > 2048-partition fallback anyway)
     bool msm_fixed_c = false;        // "msm_fixed_c": keys registered from now on keep their own window width for short calls (no secondary table sets)
     unsigned msm_c_g1 = 0, msm_c_g2 = 0;   // "msm_window_g1" / "msm_window_g2": primary window width of keys registered from now on (0 = cost model)
+    bool msm_launch_split = false;   // (set by msm_enqueue for the launch it is making: a table-free call, lanes = windows)
+    int msm_lane_interleave = 0;     // "msm_lane_interleave": lanes per interleave group of the accumulate kernels (msm_acc.h acc_work_item); 0 = the default rule
     int msm_stream_prio = 0;         // "msm_stream_priority": 1 = sort / reduce streams above the accumulate stream, 2 = the reverse (before the first MSM)
     unsigned msm_affine_rounds = 0;  // lab "msm_affine_rounds": R rounds of batched-affine pair additions in front of the G1 bucket accumulation
     bool msm_reduce_sat = false;     // lab "msm_reduce_sat": buckets and their reduction in the saturated form
@@ -126,7 +131,6 @@ struct czk_ctx {
     // order, never timing.  "chaos_drop_wait" removes ONE such wait on purpose (1: the accumulate stream's wait for the digit sort; 2: the reduce stream's wait
     // for the accumulate kernel), so that the test can show it catches the class of bug it exists for.
     bool ntt_skip_coset_first = false;   // lab "ntt_skip_coset_first": timing experiment (wrong results), see ntt.hip
-    bool msm_g1_lane_pairs = false;      // lab "msm_g1_lane_pairs": k_accumulate_te_pairs -- neighbouring threads take the same bucket rank of two lanes
     unsigned long long chaos = 0;
     int chaos_drop_wait = 0;
     bool ntt_gen1 = false;           // "ntt_gen1": first-generation NTT passes (ntt.hip, the small-domain kernels) for every size
@@ -305,6 +309,16 @@ CZK_HD unsigned msm_win_width(unsigned c, unsigned W_hi, unsigned w) { return w 
 // sum_w 2^(bit(w)) R[lane][w] on the host (Horner: width(w) doublings per window); src: lanes x W Jacobian triples, out: lanes triples
 void host_combine_windows(int group, const char* src, unsigned W, unsigned c, size_t lanes, uint64_t* out);
 int msm_pipeline_sync(czk_ctx* ctx);
+// lanes per interleave group of the bucket accumulation kernels (msm_acc.h acc_work_item): the option, or the default rule
+// Default rule (EXPERIMENTS.md section 14): groups of up to 4 lanes for keys with window tables -- every lane's buckets have the same size
+// distribution, so equal ranks are equal work (measured: 4, 6 and 8 lanes per group are equal within noise; the Groth16 step gains 5 %) -- and no
+// interleaving on the table-free path, whose lanes are the WINDOWS of a share lane: the narrow top window's buckets are larger, equal ranks are not
+// equal work, and interleaving costs 6 - 20 % there (measured).  msm_enqueue notes which kind of call is being launched.
+inline unsigned acc_interleave(const czk_ctx* ctx, unsigned lanes) {
+    unsigned g = ctx->msm_lane_interleave > 0 ? (unsigned)ctx->msm_lane_interleave : (ctx->msm_launch_split ? 1u : CZK_ACC_INTERLEAVE_DEFAULT);
+    if (g > lanes) g = lanes;
+    return g ? g : 1;
+}
 int msm_pinned_take(czk_ctx* ctx, size_t bytes, char** out);   // staging for one host result (a ring over the pinned area; drains when full)
 int ctx_mark(czk_ctx* ctx, uint64_t* out);       // czk_ctx_mark / czk_ctx_wait_mark
 int ctx_wait_mark(czk_ctx* ctx, uint64_t id);

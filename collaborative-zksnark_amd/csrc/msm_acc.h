@@ -18,6 +18,19 @@ static inline unsigned fix_grid(size_t B) {
     return (unsigned)(g < FIX_GRID ? g : FIX_GRID);
 }
 
+// Which bucket a thread takes.  The buckets of a lane are walked in the order of `perm` (by size, so that the threads of a wave finish together); with
+// G > 1 the lanes of an MSM are INTERLEAVED in groups of G: neighbouring threads take the same rank of neighbouring lanes (blockIdx.y selects the
+// group, the last group may be smaller), so the G lanes' entry lists and table gathers of one rank are issued by the same wave.  Measured on the
+// Groth16 step (4 lanes): the G1 kernel 10.4 -> 8.7 ms per launch, the G2 kernel 32.4 -> 29.5 ms, at the same FETCH_SIZE and wave count; the rule that
+// picks G is czk_internal.h acc_interleave (EXPERIMENTS.md section 14).
+__device__ __forceinline__ bool acc_work_item(size_t B, unsigned G, unsigned lanes, size_t& t, unsigned& lane) {
+    const unsigned base = blockIdx.y * G, g = lanes - base < G ? lanes - base : G;
+    const size_t lin = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    t = g == 1 ? lin : lin / g;
+    lane = base + (g == 1 ? 0u : (unsigned)(lin % g));
+    return t < B;
+}
+
 // sorted[off .. off+cnt) lists this bucket's points as (w * n_bases + i) | sign<<31; pts holds the window
 // multiples 2^(c*w) * P_i in affine Montgomery form.  acc += (+/-) P in XYZZ coordinates (curve.h; same edge cases as
 // short_weierstrass_jacobian.rs:570-597).
@@ -538,10 +551,10 @@ __global__ __launch_bounds__(128) void k_sw_to_te_niels(const u64* aff, const ui
 // entry is taken over with one multiplication (teu_from_niels)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_te(const u64* pts, const u32* sorted, const u32* offsets,
                                                                                                    const u32* counts, const u32* perm, size_t B, size_t sorted_stride,
-                                                                                                   u64* buckets) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B) return;
-    const unsigned lane = blockIdx.y;
+                                                                                                   u64* buckets, unsigned G, unsigned lanes) {
+    size_t t;
+    unsigned lane;
+    if (!acc_work_item(B, G, lanes, t, lane)) return;
     const size_t b = perm[(size_t)lane * B + t];
     const u32* srt = sorted + (size_t)lane * sorted_stride;
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
@@ -564,30 +577,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
 }
-#ifdef CZK_LAB
-// lab variant (option "msm_g1_lane_pairs", EXPERIMENTS.md section 14): the same work with neighbouring threads on the same bucket RANK of two lanes -- threads
-// 2k / 2k + 1 of a workgroup walk bucket perm[lane][rank] of lanes 2y / 2y + 1 -- so that the two lanes' gathers of one rank are issued by the same wave
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_te_pairs(const u64* pts, const u32* sorted, const u32* offsets,
-                                                                                                         const u32* counts, const u32* perm, size_t B, size_t sorted_stride,
-                                                                                                         u64* buckets, unsigned lanes) {
-    const size_t t = (size_t)blockIdx.x * (blockDim.x / 2) + threadIdx.x / 2;
-    const unsigned lane = 2 * blockIdx.y + (threadIdx.x & 1);
-    if (t >= B || lane >= lanes) return;
-    const size_t b = perm[(size_t)lane * B + t];
-    const u32* srt = sorted + (size_t)lane * sorted_stride;
-    u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];
-    if (cnt > HEAVY_CHUNK) cnt = HEAVY_CHUNK;
-    TEU acc = teu_identity();
-    for (u32 e = 0; e < cnt; e++) {
-        const u32 code = srt[off + e];
-        FqU ym, yp, k2;
-        te_load_niels(pts + (size_t)TE_POINT_U64 * (code & 0x7fffffffu), (code & 0x80000000u) != 0, ym, yp, k2);
-        if (e == 0) acc = teu_from_niels(ym, yp, k2);
-        else teu_madd(acc, ym, yp, k2);
-    }
-    teu_store(buckets + (size_t)24 * ((size_t)lane * B + b), acc);
-}
-#endif
 // over-full buckets (see k_accumulate_heavy / k_heavy_combine above): the same work items, folded and combined with the unified law
 // (<= 128 VGPRs like k_accumulate_heavy: the normally empty launches must not wait for a drained SIMD beside the accumulate kernels)
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_accumulate_heavy_te(const u64* pts, const u32* sorted, const u32* offsets,
@@ -661,10 +650,10 @@ __device__ __forceinline__ Fq2 fq2_from_table_u(const u64* p) {   // table coord
 #endif
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(CZK_G2ACC_WAVES, CZK_G2ACC_WAVES))) void k_accumulate_u2(
     const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, const u32* perm, size_t B, size_t sorted_stride, u64* buckets,
-    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap, int ubuckets) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B) return;
-    const unsigned lane = blockIdx.y;
+    uint8_t* dirty, u32* exc_count, u32* exc_list, u32 exc_cap, int ubuckets, unsigned G, unsigned lanes) {
+    size_t t;
+    unsigned lane;
+    if (!acc_work_item(B, G, lanes, t, lane)) return;
     const size_t b = perm[(size_t)lane * B + t];
     const u32* srt = sorted + (size_t)lane * sorted_stride;
     u32 off = offsets[(size_t)lane * B + b], cnt = counts[(size_t)lane * B + b];

@@ -149,15 +149,9 @@ void launch_accumulate_g1_te(czk_ctx* ctx, hipStream_t st, const u64* pts, const
                              size_t sorted_stride, u64* buckets, unsigned lanes) {
     ProfScope ps(ctx, "msm_accumulate_g1", st);   // brackets the dominant kernel only
     // (a build for 3 waves per SIMD -- the kernel needs 155 VGPRs -- was measured: same isolated time, 88.6 against 84.0 ms per proof)
-#ifdef CZK_LAB
-    if (ctx->msm_g1_lane_pairs && lanes >= 2) {
-        hipLaunchKernelGGL(k_accumulate_te_pairs, dim3((unsigned)((B + 63) / 64), (lanes + 1) / 2), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B, sorted_stride,
-                           buckets, lanes);
-        return;
-    }
-#endif
-    hipLaunchKernelGGL(k_accumulate_te, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B, sorted_stride,
-                       buckets);
+    const unsigned G = acc_interleave(ctx, lanes);
+    hipLaunchKernelGGL(k_accumulate_te, dim3((unsigned)((B * G + 127) / 128), (lanes + G - 1) / G), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B, sorted_stride,
+                       buckets, G, lanes);
 }
 void launch_heavy_g1_te(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride, u64* buckets,
                         unsigned lanes, u32* hdr, u32* items, u32* heavy, u64* partials, u32 cap) {

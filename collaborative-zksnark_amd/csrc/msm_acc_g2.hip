@@ -39,8 +39,11 @@ void launch_accumulate_g2_u(czk_ctx* ctx, hipStream_t st, const u64* pts, const 
                            sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP);
     else
 #endif
-        hipLaunchKernelGGL(k_accumulate_u2, dim3((unsigned)((B + 127) / 128), lanes), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
-                           sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP, ubuckets);
+    {
+        const unsigned G = acc_interleave(ctx, lanes);
+        hipLaunchKernelGGL(k_accumulate_u2, dim3((unsigned)((B * G + 127) / 128), (lanes + G - 1) / G), dim3(128), 0, st, pts, sorted, offsets, counts, perm, B,
+                           sorted_stride, buckets, dirty, exc, exc + 4, G2_EXC_CAP, ubuckets, G, lanes);
+    }
 }
 void launch_accumulate_g2_u_fixup(hipStream_t st, const u64* pts, const u32* sorted, const u32* offsets, const u32* counts, size_t B, size_t sorted_stride,
                                   u64* buckets, unsigned lanes, uint8_t* dirty, int ubuckets) {

@@ -115,6 +115,9 @@ const char* czk_version(void);
 /* Tuning options of one context.  The library reads NO environment variables: everything a caller may select is named here.
  *   "msm_slots" 1..4            depth of the MSM pipeline's workspace ring (default 4)                          [before the first MSM]
  *   "msm_stream_priority" 0..2  0 = equal priorities (default), 1 = sort / reduce streams above accumulate, 2 = the reverse [before the first MSM]
+ *   "msm_lane_interleave" 0..64 lanes per interleave group of the bucket accumulation kernels: neighbouring threads take the same bucket rank of G
+ *                               neighbouring share lanes (1 = one lane per workgroup row, the layout of rounds 1 - 5; 0 = the library's default: 4 for keys
+ *                               with window tables, 1 on the table-free path)
  *   "msm_sort_onepass" 0/1      single-pass digit sort for every call (default: only beyond 2048 partitions)
  *   "msm_fixed_c" 0/1           keys registered AFTERWARDS keep their own window width for short calls (no secondary table sets)
  *   "msm_window_g1" / "msm_window_g2" 0, 8..22   primary window width of keys registered AFTERWARDS (0 = the cost model, default)

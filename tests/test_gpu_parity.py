@@ -1082,6 +1082,27 @@ def test_many_share_lanes(ctx, czk, orc):
             b.release()
 
 
+@pytest.mark.parametrize("interleave", [0, 1, 2, 3, 4, 8])
+def test_msm_lane_interleave_matches_checker(czk, orc, interleave):
+    """czk_ctx_set_option "msm_lane_interleave": the accumulate kernels' threads take the same bucket rank of G neighbouring lanes.  Every group size
+    (0 = the library's rule) against the checker's Pippenger for lane counts that leave a short last group (1, 3, 5, 7 lanes), G1 and G2, with
+    over-full buckets (a third of the scalars equal to one) and on the table-free path, whose lanes are windows."""
+    c = czk.Context(0, options={"msm_lane_interleave": interleave})
+    for g, n in ((1, 3000), (2, 400)):
+        _, bases = _bases(c, g, n, 9900 + n)
+        for lanes in (1, 3, 5, 7):
+            sc = rand_fr_canonical(9901 + n + lanes, lanes * n).reshape(lanes, n, 4)
+            sc[:, ::3] = np.array([1, 0, 0, 0], dtype=np.uint64)
+            want = [orc.msm(g, bases, np.zeros(n, dtype=np.uint8), sc[ln]) for ln in range(lanes)]
+            for no_tables in (0, czk.CZK_MEM_NO_TABLES):
+                b = c.register_bases(g, bases, None, mem=czk.CZK_MEM_HOST | no_tables)
+                got = c.msm(b, sc, lanes=lanes)
+                for ln in range(lanes):
+                    assert _same_point(c, orc, g, got[ln], want[ln]), (interleave, g, lanes, ln, no_tables)
+                b.release()
+    c.close()
+
+
 def _msm_random_case(ctx, czk, orc, rng, g, n, seed, tag):
     """One randomised MSM comparison: odd lane counts, random infinity patterns, repeated bases, scalar mixes with many zeros, ones, small
     values and r - small values; table form and CZK_MEM_NO_TABLES against the checker's Pippenger."""

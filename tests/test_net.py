@@ -451,7 +451,7 @@ def test_cpp_party_layout_with_eight_parties(transport):
     party = _json_tail(__import__("util").run_ranks([exe, "party-launch", "--world", "8", "--transport", transport] + size,
                                                     capture_output=True, text=True, timeout=600, env=env))
     assert party["parties"] == 8 and party["share_lanes_per_process"] == 2 and party["transport"] == transport
-    assert party["king_net_stats"]["broadcasts"] == 2 * 2 * 2
+    assert party["commit_opens"] is True and party["king_net_stats"]["broadcasts"] == 2 * 2 * 3   # 2 proofs x 2 opens x (sh lanes + dx_t through atomic_broadcast's two rounds)
     one = _json_tail(subprocess.run([exe, "bench", "--parties", "8"] + size, capture_output=True, text=True, timeout=600, env=env))
     assert one["share_lanes"] == 16 and one["mac_check_failures"] == 0
     assert party["results_sha256"] == one["results_sha256"]
