@@ -21,8 +21,10 @@ static inline unsigned fix_grid(size_t B) {
 // Which bucket a thread takes.  The buckets of a lane are walked in the order of `perm` (by size, so that the threads of a wave finish together); with
 // G > 1 the lanes of an MSM are INTERLEAVED in groups of G: neighbouring threads take the same rank of neighbouring lanes (blockIdx.y selects the
 // group, the last group may be smaller), so the G lanes' entry lists and table gathers of one rank are issued by the same wave.  Measured on the
-// Groth16 step (4 lanes): the G1 kernel 10.4 -> 8.7 ms per launch, the G2 kernel 32.4 -> 29.5 ms, at the same FETCH_SIZE and wave count; the rule that
-// picks G is czk_internal.h acc_interleave (EXPERIMENTS.md section 14).
+// Groth16 step (4 lanes): the G1 kernel 10.4 -> 8.7 ms per launch, the G2 kernel 32.4 -> 29.5 ms, with every instruction and memory counter unchanged and the
+// wave slots 93 % instead of 74 % occupied: what matters is that the launch walks ONE descending sequence of bucket sizes instead of one per lane
+// (interleaving at workgroup granularity gains the same; the lane-after-lane order on a one-dimensional grid, an ascending or a scattered order do not:
+// EXPERIMENTS.md section 14).  The rule that picks G is czk_internal.h acc_interleave.
 __device__ __forceinline__ bool acc_work_item(size_t B, unsigned G, unsigned lanes, size_t& t, unsigned& lane) {
     const unsigned base = blockIdx.y * G, g = lanes - base < G ? lanes - base : G;
     const size_t lin = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

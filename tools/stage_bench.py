@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Isolated (non-overlapped) stage times of one blocking MSM: sort / accumulate / reduce spans from the library's
-HIP-event profiling hooks.  python tools/stage_bench.py [log_n] [lanes]"""
+HIP-event profiling hooks.  python tools/stage_bench.py [log_n] [lanes] [NAME=VALUE context options ...]"""
 import os
 import sys
 
@@ -16,7 +16,8 @@ log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 lanes = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 ts = torch.cuda.Stream()
 torch.cuda.set_stream(ts)
-ctx = czk.Context(0, ts.cuda_stream)
+opts = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[3:]}
+ctx = czk.Context(0, ts.cuda_stream, options=opts)
 n = 1 << log_n
 for g in (czk.CZK_G1, czk.CZK_G2):
     aw = 12 if g == czk.CZK_G1 else 24
@@ -36,5 +37,5 @@ for g in (czk.CZK_G1, czk.CZK_G2):
         ms, launches = ctx.profile_read(name)
         out[name] = round(ms / max(launches, 1), 3)
     ctx.profile_enable(False)
-    print(f"G{g} n=2^{log_n} lanes={lanes}: {out}")
+    print(f"G{g} n=2^{log_n} lanes={lanes} {opts}: {out}")
     b.release()
