@@ -657,7 +657,7 @@ def cpu_baseline(log_n_sample: int, log_n_full: int, parties: int, all_cores_log
     scale = _ref_work(1 << log_n_full) / _ref_work(1 << log_n_sample)
     cal, cal_src, full_s = 1.0, None, None   # measured (one full single-thread run at 2^20 on the GPU box's host) / (model prediction from the 2^14 sample)
     if log_n_sample == 14 and log_n_full == 20:
-        for name in ("r05_cpu_baseline_validation.json", "r02_cpu_baseline_validation.json"):     # the newest validation run wins
+        for name in ("r06_cpu_baseline_validation.json", "r05_cpu_baseline_validation.json", "r02_cpu_baseline_validation.json"):     # the newest validation run wins
             try:
                 v = json.load(open(os.path.join(ROOT, "profiles", name)))
                 cal, cal_src, full_s = float(v["calibration_2^14_to_2^20"]), "profiles/" + name, v.get("single_thread_2^20_seconds", 513.9)
@@ -1293,7 +1293,7 @@ def main():
     # HBM traffic and the effective clock of the dominant kernels: PMC counters cannot be read from inside this process; the figures
     # are per-launch averages of the same command under `rocprofv3 --pmc` (separate passes), stored with the commit they were taken at
     traffic, traffic_src, pmc, traffic_raw, traffic_cal = None, None, {}, None, None
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tf = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tf):
             try:
