@@ -1107,6 +1107,7 @@ def main():
                                                                                "and the timing reduction")
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE", help="czk_ctx_set_option on every context before any key is registered "
                                                                                              "(e.g. msm_window_g1=18); repeatable")
+    ap.add_argument("--msm-order", default=None, help="groth16, A/B: enqueue order of the four witness-only MSMs, e.g. l,a,b_g1,b_g2 (default l,b_g2,a,b_g1)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--no-multi-gpu-report", action="store_true", help="--gpus N > 1, replica layout: skip the party / split layout children rank 0 runs after the replica line")
     ap.add_argument("--report-budget-s", type=float, default=240.0, help="wall-clock budget of the multi-GPU report; children that would start beyond it are skipped")
@@ -1177,6 +1178,10 @@ def main():
     else:
         prover = Groth16Local(czk, ctx, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme,
                               base_split=(rank, world) if split_layout else None, key_scalars=rk and rk[1])
+
+    if args.msm_order:
+        prover.msm_order = tuple(args.msm_order.split(","))
+        assert sorted(prover.msm_order) == ["a", "b_g1", "b_g2", "l"]
 
     def barrier():
         parallel.barrier(torch.cuda.synchronize)

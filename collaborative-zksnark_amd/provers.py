@@ -113,6 +113,9 @@ class Groth16Local:
         self.P = parties
         self.local = list(range(parties)) if local_parties is None else list(local_parties)
         self.exchange = exchange
+        # enqueue order of the four MSMs that need no witness map.  The witness map only makes progress beside the G2 accumulate kernel (EXPERIMENTS.md
+        # section 14); with that kernel second it is done closer to the moment `h` is needed: 14.51 / 14.54 against 14.42 / 14.29 proofs/s with b_g2 first
+        self.msm_order = ("l", "b_g2", "a", "b_g1")
         self.commit_opens = True                      # dx_t goes through atomic_broadcast (commit-then-open, spdz.rs:179, channel.rs:50-75); False = explicit opt-out
         # mac_share() = 1 on the king, 0 elsewhere (share/spdz.rs:30-37: the reference's stand-in MAC key is 1)
         self.mac_share = to_mont_limbs([1 if (self.local and self.local[0] == 0) else 0])[0]
@@ -363,10 +366,12 @@ class Groth16Local:
         # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
         # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
         na, nw = self.asg_q.shape[1], self.wit_q.shape[1]          # N + 1 and N, or this rank's base range of them (base_split)
-        ctx.msm_async(self.b_g2_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g2"], stable=True)
-        ctx.msm_async(self.l_query, self.wit_q.data_ptr(), nw, L, MONT, r["l"], stable=True)
-        ctx.msm_async(self.a_query, self.asg_q.data_ptr(), na, L, MONT, r["a"], stable=True)
-        ctx.msm_async(self.b_g1_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g1"], stable=True)
+        early = {"b_g2": lambda: ctx.msm_async(self.b_g2_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g2"], stable=True),
+                 "l": lambda: ctx.msm_async(self.l_query, self.wit_q.data_ptr(), nw, L, MONT, r["l"], stable=True),
+                 "a": lambda: ctx.msm_async(self.a_query, self.asg_q.data_ptr(), na, L, MONT, r["a"], stable=True),
+                 "b_g1": lambda: ctx.msm_async(self.b_g1_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g1"], stable=True)}
+        for k in self.msm_order:      # the accumulate kernels run in this order, `h` after them (EXPERIMENTS.md section 14)
+            early[k]()
         # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
         # constraint evaluation <A_i, z>, <B_i, z>, <C_i, z> over the share lanes of the full assignment (r1cs_to_qap.rs:
         # 67-83, 95-100); A carries the two instance-copy rows (:79-83).  Rows beyond each matrix are zero padding that the
