@@ -430,6 +430,7 @@ const OptDesc OPTIONS[] = {
     {"msm_window_g1", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g1 = (unsigned)v; }},
     {"msm_window_g2", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g2 = (unsigned)v; }},
     {"ntt_gen1", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_gen1 = v != 0; }},
+    {"ntt_fuse_pairs", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_fuse_pairs = v != 0; }},
     {"net_create_timeout_ms", 0, 3600000, false, [](czk_ctx* c, long v) { c->net_create_timeout_ms = v; }},
 #ifdef CZK_LAB
     {"msm_affine_rounds", 0, 3, false, [](czk_ctx* c, long v) { c->msm_affine_rounds = (unsigned)v; }},

@@ -133,6 +133,8 @@ struct czk_ctx {
     bool ntt_skip_coset_first = false;   // lab "ntt_skip_coset_first": timing experiment (wrong results), see ntt.hip
     unsigned long long chaos = 0;
     int chaos_drop_wait = 0;
+    bool ntt_fuse_pairs = false;     // "ntt_fuse_pairs": the witness map's ifft -> coset_fft pairs share a pass where their tiles line up (ntt.hip ifft_coset_fft_device);
+                                     // measured + 0.5 % per Groth16 proof (EXPERIMENTS.md section 14), below the 1 % adoption bar: off by default
     bool ntt_gen1 = false;           // "ntt_gen1": first-generation NTT passes (ntt.hip, the small-domain kernels) for every size
     bool profiling = false;
     std::map<std::string, czk::ProfEntry> prof;

@@ -630,7 +630,8 @@ int czk::ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes) {
     CZK_TRY(get_domain(ctx, log_d, &d));
     CZK_TRY(ensure_tables(ctx, d, true, true));
     const size_t D = (size_t)1 << log_d;
-    if (log_d > 7 && lanes) CZK_TRY(ensure_buf(ctx, ctx->ntt_scratch, lanes * D * (log_d >= NTT2_MIN_LOG ? NTT2_SCRATCH_ELEM_BYTES : 32)));
+    // (twice the lanes: the fused pass of an ifft -> coset_fft pair writes a second set of scratch lanes, ifft_coset_fft_device)
+    if (log_d > 7 && lanes) CZK_TRY(ensure_buf(ctx, ctx->ntt_scratch, 2 * lanes * D * (log_d >= NTT2_MIN_LOG ? NTT2_SCRATCH_ELEM_BYTES : 32)));
     CZK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CZK_OK;
 }
@@ -720,16 +721,77 @@ static int repr_common(czk_ctx* ctx, int to_mont, const uint64_t* a, uint64_t* o
 extern "C" int czk_fr_into_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem) { return repr_common(ctx, 0, a, out, n, mem); }
 extern "C" int czk_fr_from_repr(czk_ctx* ctx, const uint64_t* a, uint64_t* out, size_t n, int mem) { return repr_common(ctx, 1, a, out, n, mem); }
 
+// data <- coset_fft(ifft(data)) per lane: the pair R1CStoQAP::witness_map applies to a, b and c (mpc-snarks/src/groth/r1cs_to_qap.rs:85-89, 102-103).  Where the
+// two transforms' pass structures line up (the stage bits split into equal groups: 2^21 = 7 + 7 + 7, also 2^12, 2^14, 2^15, 2^18) the last pass of the
+// inverse and the first pass of the forward transform run as ONE kernel (ntt_pass.hip k_ntt2_final_first): five trips through HBM instead of six, same values.
+static int ifft_coset_fft_device(czk_ctx* ctx, u64* data, unsigned log_d, size_t lanes, size_t in_len) {
+    const unsigned n = log_d;
+    const unsigned m = n == 0 ? 1 : (n + 6) / 7;
+    const bool fuse = ctx->ntt_fuse_pairs && !ctx->ntt_gen1 && n >= NTT2_MIN_LOG && m >= 2 && n % m == 0;   // equal groups: the two passes own the same tiles
+    if (!fuse) {
+        CZK_TRY(ntt_device(ctx, data, log_d, lanes, CZK_IFFT, in_len));
+        return ntt_device(ctx, data, log_d, lanes, CZK_COSET_FFT, (size_t)1 << log_d);
+    }
+    DomainTables* d = nullptr;
+    CZK_TRY(get_domain(ctx, log_d, &d));
+    const size_t D = (size_t)1 << log_d;
+    if (in_len > D) return set_err(ctx, CZK_ERR_SIZE, "coeffs.len() > domain size (radix2/mod.rs:100)");
+    if (lanes == 0) return CZK_OK;
+    CZK_TRY(ensure_tables(ctx, d, true, false));
+    const unsigned K = n / m;
+    // two sets of scratch lanes: the fused pass reads one and writes the other (a block's inputs and outputs are different element sets)
+    CZK_TRY(ensure_buf(ctx, ctx->ntt_scratch, 2 * lanes * D * NTT2_SCRATCH_ELEM_BYTES));
+    u64* sa = (u64*)ctx->ntt_scratch.p;
+    u64* sb = (u64*)((char*)ctx->ntt_scratch.p + lanes * D * NTT2_SCRATCH_ELEM_BYTES);
+    Pass2Args inv{}, fwd{};
+    inv.tw = d->twu_inv, fwd.tw = d->twu_fwd;
+    inv.n = fwd.n = n;
+    inv.in_len = in_len, fwd.in_len = D;
+    inv.lane_stride = fwd.lane_stride = inv.in_lane_stride = fwd.in_lane_stride = D;
+    inv.postconst = fwd.postconst = host_fr_to_u(d->size_inv);
+    inv.prescale = inv.posttab = fwd.posttab = nullptr;
+    fwd.prescale = nullptr;
+    fwd.post_mode = 0;
+    // the inverse transform's passes but the last: data -> scratch A
+    unsigned s_hi_plus1 = n;
+    for (unsigned p = 0; p + 1 < m; p++) {
+        inv.s_lo = s_hi_plus1 - K;
+        s_hi_plus1 = inv.s_lo;
+        inv.first = p == 0 ? 1 : 0;
+        inv.post_mode = 0;
+        inv.in = p == 0 ? data : sa;
+        inv.out = sa;
+        ProfScope ps(ctx, "ntt_pass");
+        CZK_TRY(launch_ntt2_pass(ctx, inv, K, false, lanes));
+    }
+    {   // its last pass (bits [0, K), 1 / D) with the forward transform's first (g^i, bits [n - K, n)): scratch A -> scratch B
+        inv.s_lo = 0, inv.first = 0, inv.post_mode = 1, inv.in = sa, inv.out = nullptr;
+        fwd.s_lo = n - K, fwd.first = 0, fwd.prescale = d->cosetu_fwd, fwd.in = nullptr, fwd.out = sb;
+        ProfScope ps(ctx, "ntt_pass");
+        CZK_TRY(launch_ntt2_final_first(ctx, inv, fwd, K, lanes));
+    }
+    s_hi_plus1 = n - K;
+    for (unsigned p = 1; p < m; p++) {
+        const bool last = p == m - 1;
+        fwd.s_lo = s_hi_plus1 - K;
+        s_hi_plus1 = fwd.s_lo;
+        fwd.first = 0, fwd.prescale = nullptr;
+        fwd.in = sb;
+        fwd.out = last ? data : sb;
+        ProfScope ps(ctx, "ntt_pass");
+        CZK_TRY(launch_ntt2_pass(ctx, fwd, K, last, lanes));
+    }
+    return CZK_OK;
+}
+
 extern "C" int czk_witness_map_pre(czk_ctx* ctx, uint64_t* a, size_t a_len, uint64_t* b, size_t b_len, unsigned log_d, size_t lanes) {
     if (!ctx || !a || !b) return ctx ? set_err(ctx, CZK_ERR_ARG, "null witness_map argument") : CZK_ERR_ARG;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
     const size_t D = (size_t)1 << log_d;
     if (a_len > D || b_len > D) return set_err(ctx, CZK_ERR_SIZE, "witness_map: more evaluations than the domain holds");
     // elements [len, D) are the `vec![zero; domain_size]` padding (r1cs_to_qap.rs:66-67): the first pass zero-extends
-    CZK_TRY(ntt_device(ctx, a, log_d, lanes, CZK_IFFT, a_len));
-    CZK_TRY(ntt_device(ctx, b, log_d, lanes, CZK_IFFT, b_len));
-    CZK_TRY(ntt_device(ctx, a, log_d, lanes, CZK_COSET_FFT, D));
-    CZK_TRY(ntt_device(ctx, b, log_d, lanes, CZK_COSET_FFT, D));
+    CZK_TRY(ifft_coset_fft_device(ctx, a, log_d, lanes, a_len));
+    CZK_TRY(ifft_coset_fft_device(ctx, b, log_d, lanes, b_len));
     return CZK_OK;
 }
 
@@ -740,8 +802,7 @@ extern "C" int czk_witness_map_post(czk_ctx* ctx, uint64_t* ab, uint64_t* c, siz
     if (c_len > D) return set_err(ctx, CZK_ERR_SIZE, "witness_map: more evaluations than the domain holds");
     DomainTables* d = nullptr;
     CZK_TRY(get_domain(ctx, log_d, &d));
-    CZK_TRY(ntt_device(ctx, c, log_d, lanes, CZK_IFFT, c_len));
-    CZK_TRY(ntt_device(ctx, c, log_d, lanes, CZK_COSET_FFT, D));
+    CZK_TRY(ifft_coset_fft_device(ctx, c, log_d, lanes, c_len));
     size_t n = lanes * D;
     hipLaunchKernelGGL(k_sub_scale, dim3(grid_for(ctx, n)), dim3(256), 0, ctx->stream, (const u64*)ab, (const u64*)c, d->vanishing_inv, (u64*)ab, n);
     CZK_HIP(ctx, hipGetLastError());

@@ -35,6 +35,7 @@ struct Pass2Args {
 };
 
 int launch_ntt2_pass(czk_ctx* ctx, const Pass2Args& a, unsigned K, bool last, size_t lanes);
+int launch_ntt2_final_first(czk_ctx* ctx, const Pass2Args& ai, const Pass2Args& af, unsigned C, size_t lanes);
 void launch_table_to_u(hipStream_t st, const u64* sat, size_t count, u32* dst);
 FrU host_fr_to_u(const Fr& sat);
 

@@ -361,6 +361,106 @@ __global__ __launch_bounds__((1 << C) * 2) void k_ntt2_final(Pass2Args a) {   //
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fused pass of an `ifft -> coset_fft` pair (R1CStoQAP::witness_map, mpc-snarks/src/groth/r1cs_to_qap.rs:85-89, 102-103): the LAST pass of the inverse
+// transform (stage bits [0, C), bit-reversing store) and the FIRST pass of the forward transform (stage bits [n - C, n)) own the same tile -- block
+// `blk` of the last pass writes natural indices (brev_C(l) << (n - C)) | (16 blk + t), which is tile Lb = blk of the strided pass with row r = brev_C(l)
+// -- so the tile makes one trip through HBM instead of two.  Every value takes the steps it takes in the two kernels (canonical after the inverse
+// transform's 1 / D, times g^i, then the forward butterflies), so the results are the unfused ones bit for bit.
+// ------------------------------------------------------------------------------------------------------------
+// the last step of the inverse transform with its outputs kept in registers: y[g * R + k] = the forward transform's input element
+template <int C, int RB, int KB>
+__device__ __forceinline__ void final_step_keep(const Pass2Args& ai, const Pass2Args& af, const u32* smem, unsigned blk, FrU* y) {
+    constexpr int LEN = 1 << C, RS = LEN + 1, NEL = RS * NTT2_T, R = 1 << RB, GROUPS = 8 / R, NTHR = LEN * NTT2_T / 8;
+    const unsigned hb = ai.n - C;
+    const unsigned u = threadIdx.x;
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++) {
+        const unsigned gid = u + g * NTHR;
+        const unsigned t = gid & (NTT2_T - 1), lo = gid >> NTT2_LOGT;
+        const unsigned l0 = lo << RB;   // B0 == 0: the step's bits are the lowest
+        const size_t chunk = (size_t)blk * NTT2_T + t;
+        FrU x[R];
+#pragma unroll
+        for (int k = 0; k < R; k++) x[k] = lds_get9<NEL>(smem, t * RS + (l0 | (unsigned)k));
+        const u32* tw_s1 = ai.tw + 9 * 1;
+        if constexpr (RB == 3) {
+            FrU tw2[4];
+#pragma unroll
+            for (int k = 1; k < 4; k++) tw2[k] = tab_load(ai.tw + 9 * 3, k);
+            radix8_last<KB>(x, tw2, tab_load(tw_s1, 1));
+        } else {
+            radix4_last<KB>(x, tab_load(tw_s1, 1));
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const unsigned l = l0 | (unsigned)k;
+            const size_t ko = ((size_t)(__brev(l) >> (32 - C)) << hb) | chunk;
+            const Fr s = fru_canon_mulout(fru_mul(x[k], ai.postconst));          // what the inverse transform stores: x / D, canonical (fft.rs:26-29)
+            y[g * R + k] = fru_mul(fru_unpack(s), tab_load(af.prescale, ko));    // what the forward transform loads: times g^i (domain/mod.rs:93-106)
+        }
+    }
+}
+// ... and their hand-over into the strided pass's LDS layout (row r = brev_C(l), column t)
+template <int C, int RB>
+__device__ __forceinline__ void final_put_strided(u32* smem, const FrU* y) {
+    constexpr int LEN = 1 << C, NE = LEN * NTT2_T, R = 1 << RB, GROUPS = 8 / R, NTHR = LEN * NTT2_T / 8;
+    const unsigned u = threadIdx.x;
+#pragma unroll
+    for (int g = 0; g < GROUPS; g++) {
+        const unsigned gid = u + g * NTHR;
+        const unsigned t = gid & (NTT2_T - 1), l0 = (gid >> NTT2_LOGT) << RB;
+#pragma unroll
+        for (int k = 0; k < R; k++) lds_put9<NE>(smem, (__brev(l0 | (unsigned)k) >> (32 - C)) * NTT2_T + t, y[g * R + k]);
+    }
+}
+template <int C>
+__global__ __launch_bounds__((1 << C) * 2) void k_ntt2_final_first(Pass2Args ai, Pass2Args af) {
+    extern __shared__ __attribute__((aligned(16))) u32 smem2[];
+    constexpr int W = NTT2_SCRATCH_2R ? 2 : 1;   // the inverse transform's scratch lanes: inputs < 2 r
+    const u64* in = (const u64*)((const char*)ai.in + NTT2_SCRATCH_ELEM_BYTES * ai.lane_stride * blockIdx.y);
+    u64* out = (u64*)((char*)af.out + NTT2_SCRATCH_ELEM_BYTES * af.lane_stride * blockIdx.y);
+    const unsigned blk = blockIdx.x;
+    const size_t base = (size_t)blk << NTT2_LOGT;   // s_lo + C == n: one tile row of blocks
+    const unsigned low0 = blk << NTT2_LOGT;
+    FrU y[8];
+    if constexpr (C == 7) {
+        final_step<7, 4, 3, 2 * W, true, false>(ai, smem2, in, nullptr, blk);
+        __syncthreads();
+        final_step<7, 2, 2, 16 * W, false, false>(ai, smem2, in, nullptr, blk);
+        __syncthreads();
+        final_step_keep<7, 2, 64 * W>(ai, af, smem2, blk, y);
+        __syncthreads();
+        final_put_strided<7, 2>(smem2, y);
+        __syncthreads();
+        strided_step<7, 4, 3, 2, false, false, false>(af, smem2, nullptr, out, base, low0);
+        __syncthreads();
+        strided_step<7, 2, 2, 16, false, false, false>(af, smem2, nullptr, out, base, low0);
+        __syncthreads();
+        strided_step<7, 0, 2, 64, false, true, false>(af, smem2, nullptr, out, base, low0);
+    } else if constexpr (C == 6) {
+        final_step<6, 3, 3, 2 * W, true, false>(ai, smem2, in, nullptr, blk);
+        __syncthreads();
+        final_step_keep<6, 3, 16 * W>(ai, af, smem2, blk, y);
+        __syncthreads();
+        final_put_strided<6, 3>(smem2, y);
+        __syncthreads();
+        strided_step<6, 3, 3, 2, false, false, false>(af, smem2, nullptr, out, base, low0);
+        __syncthreads();
+        strided_step<6, 0, 3, 16, false, true, false>(af, smem2, nullptr, out, base, low0);
+    } else {
+        final_step<5, 2, 3, 2 * W, true, false>(ai, smem2, in, nullptr, blk);
+        __syncthreads();
+        final_step_keep<5, 2, 16 * W>(ai, af, smem2, blk, y);
+        __syncthreads();
+        final_put_strided<5, 2>(smem2, y);
+        __syncthreads();
+        strided_step<5, 2, 3, 2, false, false, false>(af, smem2, nullptr, out, base, low0);
+        __syncthreads();
+        strided_step<5, 0, 2, 16, false, true, false>(af, smem2, nullptr, out, base, low0);
+    }
+}
+
 // saturated table entry w R (8 x u32, canonical) -> unsaturated w 2^261 mod r (9 x 29-bit limbs)
 __global__ void k_table_to_u(const u64* sat, size_t count, u32* dst) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -394,6 +494,20 @@ FrU host_fr_to_u(const Fr& sat) {   // host-side conversion of one constant (siz
 
 // one pass of the second-generation NTT.  K in {5, 6, 7}; `first`: reads the caller's canonical lanes (otherwise the lazy
 // scratch lanes); `last`: stage bits [0, K) with the transposed store of canonical elements.
+// the fused pass above: `ai` = the inverse transform's last pass (in: its scratch lanes), `af` = the forward transform's first pass (out: the OTHER scratch
+// lanes -- a block reads and writes different element sets, so the pass cannot run in place); C = K = the stage bits both own
+int launch_ntt2_final_first(czk_ctx* ctx, const Pass2Args& ai, const Pass2Args& af, unsigned C, size_t lanes) {
+    const size_t D = (size_t)1 << ai.n;
+    const dim3 grid((unsigned)(D >> (C + NTT2_LOGT)), (unsigned)lanes), block((1u << C) * 2);
+    const size_t lds = (size_t)9 * (((size_t)1 << C) + 1) * NTT2_T * 4;   // the last pass's padded rows: the larger of the two layouts
+    if (lds > ctx->lds_per_block) return set_err(ctx, CZK_ERR_HIP, "fused NTT pass needs " + std::to_string(lds) + " bytes of LDS per workgroup");
+    if (C == 7) hipLaunchKernelGGL(k_ntt2_final_first<7>, grid, block, lds, ctx->stream, ai, af);
+    else if (C == 6) hipLaunchKernelGGL(k_ntt2_final_first<6>, grid, block, lds, ctx->stream, ai, af);
+    else hipLaunchKernelGGL(k_ntt2_final_first<5>, grid, block, lds, ctx->stream, ai, af);
+    CZK_HIP(ctx, hipGetLastError());
+    return CZK_OK;
+}
+
 int launch_ntt2_pass(czk_ctx* ctx, const Pass2Args& a, unsigned K, bool last, size_t lanes) {
     const size_t D = (size_t)1 << a.n;
     const unsigned blocks = (unsigned)(D >> (K + NTT2_LOGT));

@@ -122,6 +122,8 @@ const char* czk_version(void);
  *   "msm_fixed_c" 0/1           keys registered AFTERWARDS keep their own window width for short calls (no secondary table sets)
  *   "msm_window_g1" / "msm_window_g2" 0, 8..22   primary window width of keys registered AFTERWARDS (0 = the cost model, default)
  *   "ntt_gen1" 0/1              first-generation NTT passes (the small-domain kernels) for every size
+ *   "ntt_fuse_pairs" 0/1        czk_witness_map_pre/post: the last pass of an inverse transform and the first pass of the coset transform that follows it
+ *                               as one kernel where their tiles line up (2^21, 2^18, 2^15, 2^14, 2^12); same values; default 0 (+ 0.5 % per proof measured)
  *   "net_create_timeout_ms" 0..3600000   how long czk_net_create on this context waits for its peers at the rendezvous (0 = the default, 120 s;
  *                               afterwards the communicator's own "timeout_ms" option applies)
  * Any other name is CZK_ERR_ARG.  The call drains the context's enqueued work first, so an option never changes under a running proof.

@@ -1082,6 +1082,38 @@ def test_many_share_lanes(ctx, czk, orc):
             b.release()
 
 
+@pytest.mark.parametrize("log_d,lanes", [(12, 3), (14, 2), (15, 1), (18, 4), (21, 4), (13, 2), (16, 2)])
+def test_witness_map_fused_ifft_coset_fft_pass(czk, orc, log_d, lanes):
+    """czk_witness_map_pre / _post run `coset_fft(ifft(x))` with the inverse transform's last pass and the forward transform's first pass as ONE kernel where
+    their tiles line up (2^12, 2^14, 2^15, 2^18, 2^21: the stage bits split into equal groups).  Bit for bit the two-transform form: against the library
+    with the option off for every size (incl. 2^13 and 2^16, which do not fuse, and zero-extended inputs), and against the checker's ifft + coset_fft up to 2^15."""
+    import torch
+    d = 1 << log_d
+    a_len, b_len = d - 5, (3 * d) // 4
+    x = orc.fr_from_repr(rand_fr_canonical(5100 + log_d, 4096))
+    src = torch.from_numpy(x.view(np.int64).copy()).cuda().repeat((3 * lanes * d) // 4096 + 1, 1)[: 3 * lanes * d].contiguous().view(3, lanes, d, 4)
+    src[:, :, 17, 0] += torch.arange(3 * lanes, device="cuda", dtype=torch.int64).view(3, lanes) + 1      # lanes differ
+    outs = []
+    for fuse in (1, 0):
+        c = czk.Context(0, options={"ntt_fuse_pairs": fuse})
+        a, b, cc = (src[i].clone() for i in range(3))
+        ab = src[0].clone()
+        torch.cuda.synchronize()
+        c.witness_map_pre(a.data_ptr(), b.data_ptr(), log_d, lanes, a_len=a_len, b_len=b_len)
+        c.witness_map_post(ab.data_ptr(), cc.data_ptr(), log_d, lanes, c_len=a_len)
+        c.sync()
+        outs.append([t.cpu().numpy().view(np.uint64) for t in (a, b, cc, ab)])
+        c.close()
+    for got, want in zip(*outs):
+        assert np.array_equal(got, want)
+    if log_d <= 15:
+        h = src.cpu().numpy().view(np.uint64)
+        for ln in range(lanes):
+            for got, raw, n_in in ((outs[0][0], h[0], a_len), (outs[0][1], h[1], b_len), (outs[0][2], h[2], a_len)):
+                coeffs = orc.ntt_fr(raw[ln][:n_in], log_d, orc.IFFT, n_in)
+                assert np.array_equal(got[ln], orc.ntt_fr(coeffs, log_d, orc.COSET_FFT, d)), (log_d, ln)
+
+
 @pytest.mark.parametrize("interleave", [0, 1, 2, 3, 4, 8])
 def test_msm_lane_interleave_matches_checker(czk, orc, interleave):
     """czk_ctx_set_option "msm_lane_interleave": the accumulate kernels' threads take the same bucket rank of G neighbouring lanes.  Every group size
