@@ -107,7 +107,7 @@ def test_plonk_proof_of_a_satisfied_circuit_verifies(n_gates, parties):
     ctx.close()
 
 
-@pytest.mark.parametrize("H", [8, 64, 1024, 1 << 16])   # (|H| = 2^20, BASELINE configs[3]'s size: 27 s, run by hand and by bench.py -- profiles/r05_verification_runs.txt)
+@pytest.mark.parametrize("H", [8, 64, 1024, 1 << 16, 1 << 20])   # the last: BASELINE configs[3]'s size (about half a minute; also run by bench.py)
 def test_marlin_proof_of_a_satisfied_instance_verifies(H):
     """Marlin's AHP prover rounds, commitments and batched openings on the GPU path for a REAL index and a satisfied instance (the opt-in paths of
     polyvm.marlin_prove: calculate_t over the transposed matrices, the linear combinations' real coefficients), then the verifier: every KZG opening -- the
