@@ -346,6 +346,7 @@ static int polyiop(const char* workload, int argc, char** argv) {
     const char* dump = nullptr;
     int rank = -1, world = 0, transport = CZK_NET_SHM, device = 0;
     bool commit_opens = true, breakdown = false;
+    double stagger_ms = 0;   // several proofs in flight: prover k starts k * stagger_ms late, so that the provers are not all in the same round at the same time
     std::vector<std::pair<std::string, long>> ctx_options;
     std::vector<uint8_t> id;
     for (int i = 2; i < argc; i++) {
@@ -353,6 +354,7 @@ static int polyiop(const char* workload, int argc, char** argv) {
         if (!strcmp(argv[i], "--log-n")) n = (size_t)1 << atoi(val());
         else if (!strcmp(argv[i], "--no-commit-opens")) commit_opens = false;
         else if (!strcmp(argv[i], "--breakdown")) breakdown = true;
+        else if (!strcmp(argv[i], "--stagger-ms")) stagger_ms = atof(val());
         else if (!strcmp(argv[i], "--ctx-option")) {   // NAME=VALUE: czk_ctx_set_option on every context before its first MSM (repeatable)
             const std::string kv = val();
             const size_t eq = kv.find('=');
@@ -457,6 +459,7 @@ static int polyiop(const char* workload, int argc, char** argv) {
         for (size_t k = 0; k < share.size(); k++)
             th.emplace_back([&, k] {
                 try {
+                    if (stagger_ms > 0 && k) std::this_thread::sleep_for(std::chrono::duration<double, std::milli>(stagger_ms * k));
                     for (size_t i = 0; i < share[k]; i++) prove(provers[k]);
                 } catch (const Panic& e) {
                     errs[k] = e.what();
