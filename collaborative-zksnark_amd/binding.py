@@ -17,6 +17,7 @@ CZK_MEM_HOST, CZK_MEM_DEVICE = 0, 1
 CZK_MEM_NO_TABLES = 32   # czk_bases_register: OR-ed with the above, see include/czk.h
 CZK_MEM_ANY_POINTS = 64  # czk_bases_register: bases need not lie in the prime-order subgroup (keeps the XYZZ kernels for G1)
 CZK_MEM_SCALAR_HOST = 256    # czk_fr_vec_scale: device vectors, host scalar
+CZK_MEM_SAME_SCALARS = 512   # czk_msm_async: the scalars of the previous czk_msm_async call (its digit sort may be reused)
 CZK_MEM_CHECK_SUBGROUP = 128  # czk_bases_register: verify [r] P == infinity; a failing base keeps the handle on the XYZZ kernels
 CZK_SCALAR_CANONICAL, CZK_SCALAR_MONTGOMERY = 0, 1
 CZK_G1, CZK_G2 = 1, 2
@@ -311,11 +312,13 @@ class Context:
                                C.c_int(mem), _ptr(out)))
         return out
 
-    def msm_async(self, bases: "Bases", scalars_ptr, n_scalars: int, lanes: int, scalar_form: int, out: np.ndarray, stable: bool = False):
+    def msm_async(self, bases: "Bases", scalars_ptr, n_scalars: int, lanes: int, scalar_form: int, out: np.ndarray, stable: bool = False,
+                  same_scalars: bool = False):
         """czk_msm_async on device scalars; `out` (numpy, lanes x 18|36) is valid after sync().  stable=True promises
-        the scalars stay untouched until then (CZK_MEM_STABLE)."""
+        the scalars stay untouched until then (CZK_MEM_STABLE); same_scalars=True (with stable) says they are the previous
+        czk_msm_async call's scalars, whose digit sort the library may then take over (CZK_MEM_SAME_SCALARS)."""
         self._ck(self._L.czk_msm_async(self._h, bases._h, _ptr(scalars_ptr), C.c_size_t(n_scalars), C.c_size_t(lanes), C.c_int(scalar_form),
-                                     C.c_int(CZK_MEM_DEVICE | (16 if stable else 0)), _ptr(out)))
+                                     C.c_int(CZK_MEM_DEVICE | (16 if stable else 0) | (CZK_MEM_SAME_SCALARS if same_scalars else 0)), _ptr(out)))
         return out
 
     def msm_oneshot(self, group, bases, inf, scalars, lanes=1, scalar_form=CZK_SCALAR_CANONICAL):

@@ -425,6 +425,7 @@ const OptDesc OPTIONS[] = {
     {"msm_slots", 1, czk_ctx::MSM_SLOTS, true, [](czk_ctx* c, long v) { c->msm_slots_in_use = (int)v; }},
     {"msm_stream_priority", 0, 2, true, [](czk_ctx* c, long v) { c->msm_stream_prio = (int)v; }},
     {"msm_lane_interleave", 0, 64, false, [](czk_ctx* c, long v) { c->msm_lane_interleave = (int)v; }},
+    {"msm_sort_reuse", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sort_reuse = v != 0; }},
     {"msm_sort_onepass", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sort_onepass = v != 0; }},
     {"msm_fixed_c", 0, 1, false, [](czk_ctx* c, long v) { c->msm_fixed_c = v != 0; }},
     {"msm_window_g1", 0, 22, false, [](czk_ctx* c, long v) { c->msm_c_g1 = (unsigned)v; }},
@@ -445,6 +446,7 @@ const OptDesc OPTIONS[] = {
     {"chaos", 0, 0x7fffffff, false, [](czk_ctx* c, long v) { c->chaos = v ? ((unsigned long long)v * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)getpid() << 32) ^ (unsigned long long)(uintptr_t)c : 0; }},
     {"chaos_drop_wait", 0, 2, false, [](czk_ctx* c, long v) { c->chaos_drop_wait = (int)v; }},
     {"ntt_skip_coset_first", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_skip_coset_first = v != 0; }},
+    {"msm_sort_reuse_any_inf", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sort_reuse_any_inf = v != 0; }},
 
 #endif
 };

@@ -61,10 +61,22 @@ struct DeviceBuf {
     void* p = nullptr;
     size_t bytes = 0;
 };
+// What a slot's sort workspace holds when it was made from CZK_MEM_STABLE scalars: a CZK_MEM_SAME_SCALARS call that matches a slot's key in every field reads that
+// slot's sorted entries instead of sorting again.  Cleared by czk_ctx_sync / czk_ctx_wait_mark; overwritten by the slot's next sort.
+struct MsmSortKey {
+    bool valid = false;
+    uint64_t seq = 0;          // the call that made the sort (czk_ctx::msm_seq)
+    const void* scalars = nullptr;
+    size_t n_scalars = 0, lanes = 0, size = 0, nb = 0;
+    int form = 0;
+    unsigned c = 0, W = 0;
+    const czk_bases* bases = nullptr;
+};
 struct MsmSlot {
     DeviceBuf ws_sort, ws_red, ws_aff;
     hipEvent_t ev_sorted = nullptr, ev_acc = nullptr, ev_fix = nullptr, ev_red = nullptr;
     bool used = false;
+    MsmSortKey key;
 };
 struct MsmPending {   // a host result on its way: pinned staging -> the caller's buffer at czk_ctx_sync / czk_ctx_wait_mark (MSM results, deferred downloads)
     const char* src;
@@ -101,6 +113,9 @@ struct czk_ctx {
     static constexpr int MSM_SLOTS = 4;   // workspace ring: accumulate(k + MSM_SLOTS) waits for reduce(k)
     czk::MsmSlot msm_slots[MSM_SLOTS];
     int msm_next_slot = 0;
+    // CZK_MEM_SAME_SCALARS names the scalars of the most recent call made WITHOUT the flag (the leader of a group of calls over one vector): only sorts made by
+    // that call or after it qualify, so a later group -- the next proof over the same buffer -- never reads an earlier group's sort
+    uint64_t msm_seq = 0, msm_leader_seq = 0;
     int msm_slots_in_use = 4;
     char* msm_pinned = nullptr;
     size_t msm_pinned_bytes = 0, msm_pinned_used = 0;   // a ring: `used` is the tail, the oldest pending result's offset the head
@@ -111,6 +126,8 @@ struct czk_ctx {
     std::vector<hipEvent_t> mark_events;                // idle events of retired marks
     // ---- czk_ctx_set_option (core.hip).  The product library knows the first group only; the second group selects kernels that exist in the
     // lab build alone (libczk_hip_lab.so, -DCZK_LAB: the measured-and-rejected variants of EXPERIMENTS.md) and is fixed at its default otherwise.
+    bool msm_sort_reuse = false;     // "msm_sort_reuse": CZK_MEM_SAME_SCALARS calls read an earlier call's digit sort when the layouts match (default off: measured, EXPERIMENTS.md section 14)
+    bool msm_sort_reuse_any_inf = false;   // lab "msm_sort_reuse_any_inf": ... even when the keys' points at infinity differ (WRONG results: the upper bound of sharing one sort per scalar vector)
     bool msm_sort_onepass = false;   // "msm_sort_onepass": the single-pass digit sort for every call (it is the > 2048-partition fallback anyway)
     bool msm_fixed_c = false;        // "msm_fixed_c": keys registered from now on keep their own window width for short calls (no secondary table sets)
     unsigned msm_c_g1 = 0, msm_c_g2 = 0;   // "msm_window_g1" / "msm_window_g2": primary window width of keys registered from now on (0 = cost model)
@@ -188,6 +205,11 @@ struct czk_bases {
                                // extra lanes of the same kernels) and the per-window results are combined afterwards
     uint64_t* pts = nullptr;   // device, W x n x (12|24) u64: window w holds 2^(c*w) * P_i, affine Montgomery
     uint8_t* inf = nullptr;    // device, W x n infinity flags (never null)
+    // the indices (w n + i) of the primary table's entries at infinity when there are at most INF_LIST_MAX of them (host copy, made at registration): two keys
+    // of equal length and layout whose lists are equal drop the same digits, so MSMs over one scalar vector can share a digit sort (CZK_MEM_SAME_SCALARS)
+    static constexpr size_t INF_LIST_MAX = 4096;
+    bool inf_listed = false;
+    std::vector<uint32_t> inf_idx;
 };
 
 namespace czk {
@@ -294,7 +316,7 @@ int ntt_mixed_device(czk_ctx* ctx, u64* data, unsigned k, size_t lanes, int kind
 int msm_reserve(czk_ctx* ctx, const czk_bases* bases, size_t n_scalars, size_t lanes);   // czk_ctx_reserve (msm.hip)
 int ntt_reserve(czk_ctx* ctx, unsigned log_d, size_t lanes);                                   // czk_ctx_reserve (ntt.hip)
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes,
-               int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable);
+               int scalar_form, u64* out_jac_host, bool blocking, bool scalars_stable, bool same_scalars = false);
 int msm_pipeline_init(czk_ctx* ctx);
 // Window layout of the signed-digit split (254 bits: 253-bit scalars + the carry).  W(c) = ceil(254 / c) windows of c bits overshoot by
 // slack = W c - 254 bits, which the plain layout leaves in the TOP window: with a narrow top window (< 10 bits) every point's top digit lands on

@@ -897,6 +897,12 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
     return CZK_OK;
 }
 
+// two keys of one length and window layout drop the same digits: the same table entries (window w, point i) are infinity
+static bool same_infinities(const czk_bases* x, const czk_bases* y) {
+    if (x == y) return true;
+    return x->inf_listed && y->inf_listed && x->n == y->n && x->c == y->c && x->W == y->W && x->inf_idx == y->inf_idx;
+}
+
 // Enqueue one MSM on the context's three-stage pipeline:
 //   s_sort : digits -> partition -> per-partition sort -> population order; flag clearing  (memory bound)
 //   s_acc  : the bucket accumulation kernel, nothing else                            (integer-VALU bound, fills the chip)
@@ -906,7 +912,7 @@ static int pick_tables(czk_ctx* ctx, const czk_bases* cb, size_t size, TableView
 // buffer by msm_collect() after the streams are synchronised.
 template <class F>
 static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, size_t n_scalars, size_t lanes, int form, u64* out_host,
-                       bool scalars_stable, bool reserve_only = false) {
+                       bool scalars_stable, bool reserve_only = false, bool same_scalars = false) {
     constexpr int JW = GT<F>::JW, XW = GT<F>::XW;   // results leave as Jacobian; buckets are XYZZ internally
     const size_t size = b->n < n_scalars ? b->n : n_scalars;   // variable_base.rs:16
     // Bases without window tables (b->split): the W digit windows of every scalar lane become W "virtual lanes", each a
@@ -931,7 +937,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
 #ifdef CZK_LAB
     if (ctx->chaos && !reserve_only) ctx->msm_next_slot = (int)(chaos_rand(ctx) % (unsigned)ctx->msm_slots_in_use);   // any slot is valid: its events order the reuse
 #endif
-    MsmSlot& slot = ctx->msm_slots[ctx->msm_next_slot];
+    const int slot_idx = ctx->msm_next_slot;
+    MsmSlot& slot = ctx->msm_slots[slot_idx];
     if (!reserve_only) ctx->msm_next_slot = (ctx->msm_next_slot + 1) % ctx->msm_slots_in_use;
 
     // workspaces (grow-only; growing synchronises the pipeline first)
@@ -1004,7 +1011,43 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         aff.scratch = ba.take<char>(aff_scratch_bytes(ctx));
     }
 #endif
-    Bump bs{(char*)slot.ws_sort.p};
+    // CZK_MEM_SAME_SCALARS: an earlier call's digit sort stands for this one when nothing that enters it differs -- scalars, their form, the window layout, the
+    // table stride (entries are table indices) and the digits dropped for points at infinity.  The entries stay in THAT call's slot (`src`); this call takes its own
+    // slot for the buckets and the reduction as always.
+    const uint64_t seq = ++ctx->msm_seq;
+    if (!same_scalars) ctx->msm_leader_seq = seq;
+    int src_idx = -1;
+    if (same_scalars && scalars_stable && ctx->msm_sort_reuse && !b->split && tv.pts == b->pts) {   // (the primary table set)
+        for (int i = 0; i < ctx->msm_slots_in_use && src_idx < 0; i++) {
+            const MsmSortKey& k = ctx->msm_slots[i].key;
+            bool ok = k.valid && k.seq >= ctx->msm_leader_seq && k.scalars == (const void*)scalars && k.n_scalars == n_scalars && k.lanes == lanes && k.size == size && k.nb == nb && k.form == form &&
+                      k.c == c && k.W == W;
+#ifdef CZK_LAB
+            if (aff.rounds) ok = false;
+            if (ok && !ctx->msm_sort_reuse_any_inf) ok = same_infinities(k.bases, b);
+#else
+            if (ok) ok = same_infinities(k.bases, b);
+#endif
+            if (ok) src_idx = i;
+        }
+    }
+    const bool reuse = src_idx >= 0;
+    MsmSlot& src = reuse ? ctx->msm_slots[src_idx] : slot;
+    if (!reuse) {
+        MsmSortKey& k = slot.key;
+        k.valid = scalars_stable && !b->split && tv.pts == b->pts;
+        k.seq = seq;
+        k.scalars = scalars;
+        k.n_scalars = n_scalars;
+        k.lanes = lanes;
+        k.size = size;
+        k.nb = nb;
+        k.form = form;
+        k.c = c;
+        k.W = W;
+        k.bases = b;
+    }
+    Bump bs{(char*)src.ws_sort.p};
     u32* digits = bs.take<u32>(lanes * W * size);
     u32* sorted = bs.take<u32>(lanes * W * size);
     u32* ranks = bs.take<u32>(lanes * W * size);            // one-pass sort: ranks; partitioned sort: entries grouped by partition
@@ -1042,9 +1085,10 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_in, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_fix, 0));   // slot's sort buffers are read by its accumulate and fix-up kernels
     {
-        ProfScope ps(ctx, "msm_sort", ss);
+        ProfScope ps(ctx, reuse ? "msm_sort_reused" : "msm_sort", ss);
         const bool one_pass = one_pass_sort;
-        if (one_pass) {
+        if (reuse) {   // (`ss` is in order: the entries of `src` are complete before anything recorded on it from here)
+        } else if (one_pass) {
             CZK_HIP(ctx, hipMemsetAsync(counts, 0, lanes * B * 4, ss));
             if (size) {
                 hipLaunchKernelGGL(k_digits, dim3((unsigned)((size + 255) / 256), (unsigned)lanes), dim3(256), 0, ss, scalars, n_scalars, size,
@@ -1092,10 +1136,12 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
                                    sorted, offsets, counts, cap);
             }
         }
-        CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
-        hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
-        hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
-        hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
+        if (!reuse) {
+            CZK_HIP(ctx, hipMemsetAsync(chist, 0, lanes * CNT_BINS * 4, ss));
+            hipLaunchKernelGGL(k_count_hist, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist);
+            hipLaunchKernelGGL(k_count_starts, dim3((unsigned)lanes), dim3(1024), 0, ss, chist);
+            hipLaunchKernelGGL(k_count_scatter, dim3((unsigned)((B + 1023) / 1024), (unsigned)lanes), dim3(1024), 0, ss, counts, B, chist, perm);
+        }
 #ifdef CZK_LAB
         if (aff.rounds) {
             aff.sorted = sorted;
@@ -1164,6 +1210,8 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
         else launch_accumulate_g2_u_fixup(sr, tv.pts, sorted, offsets, counts, B, (size_t)W * size, buckets, (unsigned)lanes, dirty, ub);
     }
     CZK_HIP(ctx, hipEventRecord(slot.ev_fix, sr));   // the slot's sort buffers are free from here
+    if (reuse && &src != &slot) CZK_HIP(ctx, hipEventRecord(src.ev_fix, sr));   // ... and so are the ones this call borrowed: the next sort into `src` waits for the
+                                                                                 // LATEST record (`sr` is in order, so it covers src's own accumulate and fix-up too)
     {
         ProfScope ps(ctx, "msm_reduce", sr);
         const u64 *P = buckets, *E = nullptr;
@@ -1265,6 +1313,7 @@ int msm_pipeline_sync(czk_ctx* ctx) {
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_acc));
     CZK_HIP(ctx, hipStreamSynchronize(ctx->s_red));
     for (auto& p : ctx->msm_pending) deliver(p);
+    for (auto& sl : ctx->msm_slots) sl.key.valid = false;   // CZK_MEM_STABLE promises the scalars up to here
     ctx->msm_delivered += ctx->msm_pending.size();
     ctx->msm_pending.clear();
     ctx->msm_pinned_used = 0;
@@ -1327,6 +1376,7 @@ int ctx_mark(czk_ctx* ctx, uint64_t* out) {
 }
 int ctx_wait_mark(czk_ctx* ctx, uint64_t id) {
     if (id == 0 || id >= ctx->next_mark) return set_err(ctx, CZK_ERR_ARG, "czk_ctx_wait_mark: not a mark of this context");
+    for (auto& sl : ctx->msm_slots) sl.key.valid = false;   // a transcript point: what follows is another round's (or another proof's) work
     while (!ctx->marks.empty() && ctx->marks.front().id <= id) {   // older marks first: a mark covers the ones before it
         CtxMark m = ctx->marks.front();
         CZK_HIP(ctx, hipEventSynchronize(m.ev_stream));
@@ -1377,9 +1427,9 @@ int msm_reserve(czk_ctx* ctx, const czk_bases* bases, size_t n_scalars, size_t l
 }
 
 int msm_device(czk_ctx* ctx, const czk_bases* bases, const u64* scalars_dev, size_t n_scalars, size_t lanes, int scalar_form,
-               u64* out_jac_host, bool blocking, bool scalars_stable) {
-    int rc = bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable)
-                                    : msm_enqueue<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable);
+               u64* out_jac_host, bool blocking, bool scalars_stable, bool same_scalars) {
+    int rc = bases->group == CZK_G1 ? msm_enqueue<Fq>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable, false, same_scalars)
+                                    : msm_enqueue<Fq2>(ctx, bases, scalars_dev, n_scalars, lanes, scalar_form, out_jac_host, scalars_stable, false, same_scalars);
     if (rc != CZK_OK || !blocking) return rc;
     return msm_pipeline_sync(ctx);
 }
@@ -1459,6 +1509,21 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     (void)hipStreamSynchronize(ctx->stream);
     if (tmp_p) (void)hipFree(tmp_p);
     if (tmp_i) (void)hipFree(tmp_i);
+    const size_t n_flags = (no_tables ? 1 : (size_t)b->W) * n;   // (a multiple 2^(c w) P of a point outside the subgroup can be infinity where P is not: every window counts)
+    if (rc == CZK_OK && n && n_flags < ((size_t)1 << 32)) {   // which table entries are infinity (CZK_MEM_SAME_SCALARS compares two keys' lists)
+        std::vector<uint8_t> flags(n_flags);
+        if (hipMemcpy(flags.data(), b->inf, n_flags, hipMemcpyDeviceToHost) != hipSuccess) rc = set_err(ctx, CZK_ERR_HIP, "D2H infinity flags");
+        else {
+            b->inf_listed = true;
+            for (size_t i = 0; i < n_flags && b->inf_listed; i++)
+                if (flags[i]) {
+                    if (b->inf_idx.size() == czk_bases::INF_LIST_MAX) {
+                        b->inf_listed = false;
+                        b->inf_idx.clear();
+                    } else b->inf_idx.push_back((uint32_t)i);
+                }
+        }
+    } else if (rc == CZK_OK) b->inf_listed = n == 0;
     if (rc != CZK_OK) {
         czk_bases_release(b);
         return rc;
@@ -1546,10 +1611,10 @@ static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scal
     if (scalar_form != CZK_SCALAR_CANONICAL && scalar_form != CZK_SCALAR_MONTGOMERY) return set_err(ctx, CZK_ERR_ARG, "bad scalar_form");
     if (!lanes) return CZK_OK;
     CZK_HIP(ctx, hipSetDevice(ctx->device));
-    const bool stable = (mem & CZK_MEM_STABLE) != 0;
-    mem &= ~CZK_MEM_STABLE;
-    if (!valid_mem(mem) || (stable && (blocking || mem != CZK_MEM_DEVICE)))
-        return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (CZK_MEM_STABLE: czk_msm_async with device scalars only)");
+    const bool stable = (mem & CZK_MEM_STABLE) != 0, same = (mem & CZK_MEM_SAME_SCALARS) != 0;
+    mem &= ~(CZK_MEM_STABLE | CZK_MEM_SAME_SCALARS);
+    if (!valid_mem(mem) || (stable && (blocking || mem != CZK_MEM_DEVICE)) || (same && !stable))
+        return set_err(ctx, CZK_ERR_ARG, "mem must be CZK_MEM_HOST or CZK_MEM_DEVICE (CZK_MEM_STABLE: czk_msm_async with device scalars only; CZK_MEM_SAME_SCALARS: with CZK_MEM_STABLE only)");
     const u64* sdev = scalars;
     DeviceBuf tmp;
     if (mem == CZK_MEM_HOST && n_scalars) {
@@ -1562,7 +1627,7 @@ static int msm_common(czk_ctx* ctx, const czk_bases* bases, const uint64_t* scal
         sdev = (const u64*)tmp.p;
     }
     // host scalars: always blocking (the digits have been extracted from the staging buffer by the time this returns)
-    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp.p != nullptr, stable && !blocking);
+    int rc = msm_device(ctx, bases, sdev, n_scalars, lanes, scalar_form, out_jac, blocking || tmp.p != nullptr, stable && !blocking, same);
     if (tmp.p) stage_give(ctx, tmp);
     return rc;
 }

@@ -366,12 +366,16 @@ class Groth16Local:
         # --- create_proof MSMs that depend only on the witness (prover.rs:108, 132-156): enqueue-only; they pipeline on
         # the context's internal streams and overlap with the witness map below.  Results are valid after sync().
         na, nw = self.asg_q.shape[1], self.wit_q.shape[1]          # N + 1 and N, or this rank's base range of them (base_split)
-        early = {"b_g2": lambda: ctx.msm_async(self.b_g2_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g2"], stable=True),
-                 "l": lambda: ctx.msm_async(self.l_query, self.wit_q.data_ptr(), nw, L, MONT, r["l"], stable=True),
-                 "a": lambda: ctx.msm_async(self.a_query, self.asg_q.data_ptr(), na, L, MONT, r["a"], stable=True),
-                 "b_g1": lambda: ctx.msm_async(self.b_g1_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g1"], stable=True)}
+        early = {"b_g2": lambda s: ctx.msm_async(self.b_g2_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g2"], stable=True, same_scalars=s),
+                 "l": lambda s: ctx.msm_async(self.l_query, self.wit_q.data_ptr(), nw, L, MONT, r["l"], stable=True),
+                 "a": lambda s: ctx.msm_async(self.a_query, self.asg_q.data_ptr(), na, L, MONT, r["a"], stable=True, same_scalars=s),
+                 "b_g1": lambda s: ctx.msm_async(self.b_g1_query, self.asg_q.data_ptr(), na, L, MONT, r["b_g1"], stable=True, same_scalars=s)}
+        seen_asg = False
         for k in self.msm_order:      # the accumulate kernels run in this order, `h` after them (EXPERIMENTS.md section 14)
-            early[k]()
+            # a, b_g1 and b_g2 all take `assignment` (prover.rs:130-166): the second and third say so, and the library keeps one digit sort per proof where
+            # the keys allow it (CZK_MEM_SAME_SCALARS; the first of the three always sorts)
+            early[k](seen_asg and k != "l")
+            seen_asg = seen_asg or k != "l"
         # --- R1CStoQAP::witness_map ---------------------------------------------------------------------
         # constraint evaluation <A_i, z>, <B_i, z>, <C_i, z> over the share lanes of the full assignment (r1cs_to_qap.rs:
         # 67-83, 95-100); A carries the two instance-copy rows (:79-83).  Rows beyond each matrix are zero padding that the
@@ -409,8 +413,8 @@ class Groth16Local:
         M, ADD, MONT, P = czk.CZK_MEM_DEVICE, 0, czk.CZK_SCALAR_MONTGOMERY, self.lanes // 2
         ctx.msm_async(self.b_g2_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["b_g2"], stable=True)
         ctx.msm_async(self.l_query, self.wit_sh.data_ptr(), N, P, MONT, r["l"], stable=True)
-        ctx.msm_async(self.a_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["a"], stable=True)
-        ctx.msm_async(self.b_g1_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["b_g1"], stable=True)
+        ctx.msm_async(self.a_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["a"], stable=True, same_scalars=True)
+        ctx.msm_async(self.b_g1_query, self.asg_sh.data_ptr(), N + 1, P, MONT, r["b_g1"], stable=True, same_scalars=True)
         ctx.r1cs_matvec(self.mat_a, self.full.data_ptr(), lanes=L, out=self.a.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
         ctx.r1cs_matvec(self.mat_b, self.full.data_ptr(), lanes=L, out=self.b.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)
         ctx.r1cs_matvec(self.mat_c, self.full.data_ptr(), lanes=L, out=self.c.data_ptr(), z_stride=N + 2, out_stride=D, mem=M)

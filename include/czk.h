@@ -74,7 +74,15 @@ typedef enum {
     CZK_MEM_CHECK_SUBGROUP = 128,
     /* czk_fr_vec_scale only, OR-ed with CZK_MEM_DEVICE: the vectors are device memory, the scalar `k` is HOST memory, read when the call is
      * made and handed to the kernel with the launch -- no device copy of a 32-byte value, no lifetime to observe. */
-    CZK_MEM_SCALAR_HOST = 256
+    CZK_MEM_SCALAR_HOST = 256,
+    /* czk_msm_async only, OR-ed with CZK_MEM_DEVICE | CZK_MEM_STABLE: the scalars are those of the most recent czk_msm_async call on this context that
+     * did NOT carry this flag (the leader of a group of calls over one vector) -- same pointer, count, lanes and form, that call CZK_MEM_STABLE too,
+     * the buffer unchanged -- as when one assignment vector meets several queries (Groth16's a, b_g1, b_g2: groth16/src/prover.rs:130-166 passes
+     * `assignment` three times).  The library may then read a digit sort made by the leader (or by a later member of the group) instead of sorting
+     * again; it does while that sort is still in one of the pipeline's workspace slots and both keys run the same table layout (size, window width)
+     * and have the same points at infinity, otherwise the flag changes nothing (nor does it unless the option "msm_sort_reuse" is set).  Results are the same either way.  Nothing is carried from one
+     * group to the next or across czk_ctx_sync / czk_ctx_wait_mark: the next proof's first call over the same buffer sorts again. */
+    CZK_MEM_SAME_SCALARS = 512
 } czk_mem;
 
 /* EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place (algebra/poly/src/domain/mod.rs:79,90,139,155) */
@@ -118,6 +126,9 @@ const char* czk_version(void);
  *   "msm_lane_interleave" 0..64 lanes per interleave group of the bucket accumulation kernels: neighbouring threads take the same bucket rank of G
  *                               neighbouring share lanes (1 = one lane per workgroup row, the layout of rounds 1 - 5; 0 = the library's default: 4 for keys
  *                               with window tables, 1 on the table-free path)
+ *   "msm_sort_reuse" 0/1        honour CZK_MEM_SAME_SCALARS (default 0 = every call sorts: sharing b_g2's sort with b_g1 measured + 0.5 % per proof when the two
+ *                               calls are neighbours, - 0.6 % two calls apart -- the sorts run beside the accumulate kernels anyway, and entries sorted a moment
+ *                               ago are still in the last-level cache when their own accumulate kernel reads them)
  *   "msm_sort_onepass" 0/1      single-pass digit sort for every call (default: only beyond 2048 partitions)
  *   "msm_fixed_c" 0/1           keys registered AFTERWARDS keep their own window width for short calls (no secondary table sets)
  *   "msm_window_g1" / "msm_window_g2" 0, 8..22   primary window width of keys registered AFTERWARDS (0 = the cost model, default)

@@ -431,12 +431,14 @@ struct G2Affine {
 // The same call on share lanes that are already on the GPU (the `h` vector out of the witness map, prover.rs:104; the witness /
 // assignment lanes, :108-156): `lanes` scalar vectors of `n_scalars` Fr starting at scalars.data(lane0), one result per lane.
 // Enqueue-only (czk_msm_async): consecutive MSMs pipeline; `out` is valid after ctx.sync().  stable = the caller will not
-// overwrite the scalars before that sync (CZK_MEM_STABLE).
+// overwrite the scalars before that sync (CZK_MEM_STABLE); same_scalars (with stable) = they are the scalars of the previous call, whose digit
+// sort the library may take over (CZK_MEM_SAME_SCALARS: create_proof's a, b_g1 and b_g2 all take `assignment`, prover.rs:130-166).
 template <int GROUP, class Projective>
-inline void multi_scalar_mul_async(const Bases<GROUP>& bases, const DeviceLanes& scalars, size_t n_scalars, Projective* out, bool stable = false) {
+inline void multi_scalar_mul_async(const Bases<GROUP>& bases, const DeviceLanes& scalars, size_t n_scalars, Projective* out, bool stable = false,
+                                   bool same_scalars = false) {
     static_assert(sizeof(Projective) == (GROUP == CZK_G1 ? 18 : 36) * 8, "Projective does not match the group");
     bases.ctx().check(czk_msm_async(bases.ctx().raw(), bases.raw(), scalars.data(), n_scalars, scalars.lanes(), CZK_SCALAR_MONTGOMERY,
-                                    CZK_MEM_DEVICE | (stable ? CZK_MEM_STABLE : 0), reinterpret_cast<uint64_t*>(out)));
+                                    CZK_MEM_DEVICE | (stable ? CZK_MEM_STABLE : 0) | (same_scalars ? CZK_MEM_SAME_SCALARS : 0), reinterpret_cast<uint64_t*>(out)));
 }
 
 // mpc-algebra/src/share/spdz.rs:440-446 -- SPDZ multi_scale_pub_group.  The reference builds BOTH scalar vectors from `s.sh.val`

@@ -38,6 +38,7 @@ pub const CZK_MEM_NO_TABLES: c_int = 32; // czk_mem
 pub const CZK_MEM_ANY_POINTS: c_int = 64; // czk_mem
 pub const CZK_MEM_CHECK_SUBGROUP: c_int = 128; // czk_mem
 pub const CZK_MEM_SCALAR_HOST: c_int = 256; // czk_mem
+pub const CZK_MEM_SAME_SCALARS: c_int = 512; // czk_mem
 pub const CZK_FFT: c_int = 0; // czk_ntt_kind
 pub const CZK_IFFT: c_int = 1; // czk_ntt_kind
 pub const CZK_COSET_FFT: c_int = 2; // czk_ntt_kind

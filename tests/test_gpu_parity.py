@@ -1135,6 +1135,114 @@ def test_msm_lane_interleave_matches_checker(czk, orc, interleave):
     c.close()
 
 
+@pytest.mark.parametrize("n", [3000, 70000])
+def test_msm_same_scalars_shares_the_digit_sort(czk, orc, n):
+    """CZK_MEM_SAME_SCALARS: MSMs of one scalar vector against several keys (create_proof's a, b_g1, b_g2 all take `assignment`, groth16/src/prover.rs:
+    130-166) keep ONE digit sort where the keys' layouts and points at infinity agree.  Counted through the profiling brackets ("msm_sort" / "msm_sort_reused"),
+    results against the checker either way; a key with other points at infinity, a call after czk_ctx_sync, a call without the flag and the option
+    "msm_sort_reuse" = 0 all sort for themselves -- and so does the next group (the next proof's calls over the same buffer)."""
+    import torch
+    lanes = 3
+    c = czk.Context(0, options={"msm_sort_reuse": 1})       # (off by default: EXPERIMENTS.md section 14)
+    c.profile_enable(True)
+    inf_b = np.zeros(n, dtype=np.uint8)
+    inf_b[[0, n // 2]] = 1
+    inf_0 = np.zeros(n, dtype=np.uint8)
+    keys = {}
+    for name, g, inf, seed in (("b_g2", 2, inf_b, 1), ("a", 1, inf_0, 2), ("b_g1", 1, inf_b, 3), ("x", 1, inf_b, 4)):
+        _, pts = _bases(c, g, n, 7700 + seed)
+        keys[name] = (g, pts, inf, c.register_bases(g, pts, inf, mem=czk.CZK_MEM_HOST))
+    sc = rand_fr_canonical(7710 + n, lanes * n).reshape(lanes, n, 4)
+    sc[:, ::5] = np.array([1, 0, 0, 0], dtype=np.uint64)     # (over-full buckets: the heavy path reads the shared entries too)
+    sd = torch.from_numpy(np.ascontiguousarray(sc).view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    want = {k: [orc.msm(g, pts, inf, sc[ln]) for ln in range(lanes)] for k, (g, pts, inf, _) in keys.items()} if n <= 3000 else None
+
+    def run(order, flags):
+        outs = {}
+        for k, same in zip(order, flags):
+            g = keys[k][0]
+            outs[k] = np.zeros((lanes, 18 * g), dtype=np.uint64)
+            c.msm_async(keys[k][3], sd.data_ptr(), n, lanes, czk.CZK_SCALAR_CANONICAL, outs[k], stable=True, same_scalars=same)
+        c.sync()
+        return outs
+
+    def same(k, o):     # (Jacobian triples are not canonical and the order inside a bucket is not fixed: compare the points)
+        return all(_same_point(c, orc, keys[k][0], o[ln], ref[k][ln]) for ln in range(lanes))
+
+    def counts():
+        return c.profile_read("msm_sort")[1], c.profile_read("msm_sort_reused")[1]
+
+    ref = run(["b_g2", "a", "b_g1", "x"], [False] * 4)          # every call sorts
+    assert counts() == (4, 0)
+    if want:
+        for k in ref:
+            for ln in range(lanes):
+                assert _same_point(c, orc, keys[k][0], ref[k][ln], want[k][ln]), (k, ln)
+    c.profile_reset()
+    # b_g2 sorts; a has other points at infinity: sorts; b_g1 and x find b_g2's entries two slots back (a G2 sort read by the twisted Edwards kernels)
+    got = run(["b_g2", "a", "b_g1", "x"], [False, True, True, True])
+    assert counts() == (2, 2)
+    for k in got:
+        assert same(k, got[k]), k
+    c.profile_reset()
+    got = run(["b_g2", "b_g1", "x", "a"], [False, True, True, True])
+    assert counts() == (2, 2)
+    for k in got:
+        assert same(k, got[k]), k
+    c.profile_reset()
+    # nothing survives czk_ctx_sync; the flag on a first call has nothing to take
+    got = run(["b_g1"], [True])
+    got2 = run(["x"], [True])
+    assert counts() == (2, 0) and same("b_g1", got["b_g1"]) and same("x", got2["x"])
+    c.profile_reset()
+    # more calls in flight than workspace slots: the borrowed entries are protected until their last reader is done
+    order = ["b_g2"] + ["b_g1", "x"] * 5 + ["b_g2", "b_g1"]
+    got_l = []
+    outs = []
+    for i, k in enumerate(order):
+        o = np.zeros((lanes, 18 * keys[k][0]), dtype=np.uint64)
+        c.msm_async(keys[k][3], sd.data_ptr(), n, lanes, czk.CZK_SCALAR_CANONICAL, o, stable=True, same_scalars=i > 0)
+        outs.append((k, o))
+    c.sync()
+    assert counts() == (1, len(order) - 1)
+    for k, o in outs:
+        assert same(k, o), k
+    # a group ends where the next call without the flag begins: the second proof over the same buffer sorts again, with or without a czk_ctx_sync in between
+    c.profile_reset()
+    got = run(["b_g2", "b_g1", "b_g2", "b_g1", "x"], [False, True, False, True, True])
+    assert counts() == (2, 3)
+    for k in got:
+        assert same(k, got[k]), k
+    # ... and a call over OTHER scalars without the flag ends it too (the flag names the most recent unflagged call's scalars)
+    sd2 = sd.clone()
+    torch.cuda.synchronize()
+    c.profile_reset()
+    o = [np.zeros((lanes, 18 * g), dtype=np.uint64) for g in (2, 1, 1)]
+    c.msm_async(keys["b_g2"][3], sd.data_ptr(), n, lanes, czk.CZK_SCALAR_CANONICAL, o[0], stable=True)
+    c.msm_async(keys["a"][3], sd2.data_ptr(), n, lanes, czk.CZK_SCALAR_CANONICAL, o[1], stable=True)
+    c.msm_async(keys["b_g1"][3], sd.data_ptr(), n, lanes, czk.CZK_SCALAR_CANONICAL, o[2], stable=True, same_scalars=True)
+    c.sync()
+    assert counts() == (3, 0) and same("b_g2", o[0]) and same("a", o[1]) and same("b_g1", o[2])
+    c.set_option("msm_sort_reuse", 0)
+    c.profile_reset()
+    got = run(["b_g2", "b_g1", "x"], [False, True, True])
+    assert counts() == (3, 0)
+    for k in got:
+        assert same(k, got[k]), k
+    # a shorter call under the same keys (another table set or size): the key of the previous sort does not match
+    c.set_option("msm_sort_reuse", 1)
+    c.profile_reset()
+    o1, o2 = np.zeros((lanes, 36), dtype=np.uint64), np.zeros((lanes, 18), dtype=np.uint64)
+    c.msm_async(keys["b_g2"][3], sd.data_ptr(), n, lanes, czk.CZK_SCALAR_CANONICAL, o1, stable=True)
+    c.msm_async(keys["b_g1"][3], sd.data_ptr(), n - 1, lanes, czk.CZK_SCALAR_CANONICAL, o2, stable=True, same_scalars=True)
+    c.sync()
+    assert counts() == (2, 0) and same("b_g2", o1)
+    for _, _, _, b in keys.values():
+        b.release()
+    c.close()
+
+
 def _msm_random_case(ctx, czk, orc, rng, g, n, seed, tag):
     """One randomised MSM comparison: odd lane counts, random infinity patterns, repeated bases, scalar mixes with many zeros, ones, small
     values and r - small values; table form and CZK_MEM_NO_TABLES against the checker's Pippenger."""

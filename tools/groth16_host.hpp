@@ -279,8 +279,8 @@ class Groth16Host {
         // closer to the moment `h` is needed: 14.51 / 14.54 against 14.42 / 14.29 proofs/s with b_g2 first, same box; EXPERIMENTS.md section 14)
         czk::multi_scalar_mul_async(*l_query_, *wit_, N, r.l.data(), true);
         czk::multi_scalar_mul_async(*b_g2_query_, *asg_, N + 1, r.b_g2.data(), true);
-        czk::multi_scalar_mul_async(*a_query_, *asg_, N + 1, r.a.data(), true);
-        czk::multi_scalar_mul_async(*b_g1_query_, *asg_, N + 1, r.b_g1.data(), true);
+        czk::multi_scalar_mul_async(*a_query_, *asg_, N + 1, r.a.data(), true, true);         // (the same `assignment` as b_g2: one digit sort where the keys'
+        czk::multi_scalar_mul_async(*b_g1_query_, *asg_, N + 1, r.b_g1.data(), true, true);   //  layouts and points at infinity agree -- CZK_MEM_SAME_SCALARS)
         // evaluate_constraint over the share lanes of the full assignment (r1cs_to_qap.rs:67-83, 95-100)
         mat_a_->evaluate(*full_, *a_);
         mat_b_->evaluate(*full_, *b_);
