@@ -1510,7 +1510,8 @@ extern "C" int czk_bases_register(czk_ctx* ctx, int group, const uint64_t* bases
     if (tmp_p) (void)hipFree(tmp_p);
     if (tmp_i) (void)hipFree(tmp_i);
     const size_t n_flags = (no_tables ? 1 : (size_t)b->W) * n;   // (a multiple 2^(c w) P of a point outside the subgroup can be infinity where P is not: every window counts)
-    if (rc == CZK_OK && n && n_flags < ((size_t)1 << 32)) {   // which table entries are infinity (CZK_MEM_SAME_SCALARS compares two keys' lists)
+    if (rc == CZK_OK && !ctx->msm_sort_reuse) {   // (the lists are only read under the option: a key registered without it never shares a sort)
+    } else if (rc == CZK_OK && n && n_flags < ((size_t)1 << 32)) {   // which table entries are infinity (CZK_MEM_SAME_SCALARS compares two keys' lists)
         std::vector<uint8_t> flags(n_flags);
         if (hipMemcpy(flags.data(), b->inf, n_flags, hipMemcpyDeviceToHost) != hipSuccess) rc = set_err(ctx, CZK_ERR_HIP, "D2H infinity flags");
         else {

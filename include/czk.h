@@ -126,7 +126,7 @@ const char* czk_version(void);
  *   "msm_lane_interleave" 0..64 lanes per interleave group of the bucket accumulation kernels: neighbouring threads take the same bucket rank of G
  *                               neighbouring share lanes (1 = one lane per workgroup row, the layout of rounds 1 - 5; 0 = the library's default: 4 for keys
  *                               with window tables, 1 on the table-free path)
- *   "msm_sort_reuse" 0/1        honour CZK_MEM_SAME_SCALARS (default 0 = every call sorts: sharing b_g2's sort with b_g1 measured + 0.5 % per proof when the two
+ *   "msm_sort_reuse" 0/1        honour CZK_MEM_SAME_SCALARS between keys registered AFTERWARDS (default 0 = every call sorts: sharing b_g2's sort with b_g1 measured + 0.5 % per proof when the two
  *                               calls are neighbours, - 0.6 % two calls apart -- the sorts run beside the accumulate kernels anyway, and entries sorted a moment
  *                               ago are still in the last-level cache when their own accumulate kernel reads them)
  *   "msm_sort_onepass" 0/1      single-pass digit sort for every call (default: only beyond 2048 partitions)
