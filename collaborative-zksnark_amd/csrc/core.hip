@@ -444,7 +444,7 @@ const OptDesc OPTIONS[] = {
     // (the seed is mixed with the process id and the context's address: the parties of a party layout and the contexts of several proofs in flight must not
     // draw the same delays)
     {"chaos", 0, 0x7fffffff, false, [](czk_ctx* c, long v) { c->chaos = v ? ((unsigned long long)v * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)getpid() << 32) ^ (unsigned long long)(uintptr_t)c : 0; }},
-    {"chaos_drop_wait", 0, 2, false, [](czk_ctx* c, long v) { c->chaos_drop_wait = (int)v; }},
+    {"chaos_drop_wait", 0, 1, false, [](czk_ctx* c, long v) { c->chaos_drop_wait = (int)v; }},
     {"ntt_skip_coset_first", 0, 1, false, [](czk_ctx* c, long v) { c->ntt_skip_coset_first = v != 0; }},
     {"msm_sort_reuse_any_inf", 0, 1, false, [](czk_ctx* c, long v) { c->msm_sort_reuse_any_inf = v != 0; }},
 

@@ -145,8 +145,8 @@ struct czk_ctx {
     // lab "chaos": schedule perturbation (tests/test_chaos.py).  Non-zero = seed: every stage boundary (the profiling brackets around the sort / accumulate /
     // reduce / NTT / polynomial stages, the result copy) first enqueues a spin kernel of random length on the stage's stream and / or sleeps on the host, and the
     // MSM workspace ring hands out its slots in random order.  Results must not change: every ordering the library relies on has to be an event wait or stream
-    // order, never timing.  "chaos_drop_wait" removes ONE such wait on purpose (1: the accumulate stream's wait for the digit sort; 2: the reduce stream's wait
-    // for the accumulate kernel), so that the test can show it catches the class of bug it exists for.
+    // order, never timing.  "chaos_drop_wait" = 1 removes ONE such wait on purpose (the reduce stream's wait for the accumulate kernel:
+    // msm.hip), so that the test can show it catches the class of bug it exists for.
     bool ntt_skip_coset_first = false;   // lab "ntt_skip_coset_first": timing experiment (wrong results), see ntt.hip
     unsigned long long chaos = 0;
     int chaos_drop_wait = 0;

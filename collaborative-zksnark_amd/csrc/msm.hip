@@ -1023,7 +1023,7 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
             bool ok = k.valid && k.seq >= ctx->msm_leader_seq && k.scalars == (const void*)scalars && k.n_scalars == n_scalars && k.lanes == lanes && k.size == size && k.nb == nb && k.form == form &&
                       k.c == c && k.W == W;
 #ifdef CZK_LAB
-            if (aff.rounds) ok = false;
+            if (aff.rounds || ctx->chaos_drop_wait) ok = false;
             if (ok && !ctx->msm_sort_reuse_any_inf) ok = same_infinities(k.bases, b);
 #else
             if (ok) ok = same_infinities(k.bases, b);
@@ -1084,6 +1084,9 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipEventRecord(ctx->ev_in, ctx->stream));
     CZK_HIP(ctx, hipStreamWaitEvent(ss, ctx->ev_in, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_fix, 0));   // slot's sort buffers are read by its accumulate and fix-up kernels
+#ifdef CZK_LAB
+    if (ctx->chaos_drop_wait && slot.used) CZK_HIP(ctx, hipStreamWaitEvent(ss, slot.ev_acc, 0));   // (the broken schedule below breaks bucket CONTENTS only: ev_fix no longer implies ev_acc there)
+#endif
     {
         ProfScope ps(ctx, reuse ? "msm_sort_reused" : "msm_sort", ss);
         const bool one_pass = one_pass_sort;
@@ -1161,9 +1164,6 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipEventRecord(slot.ev_sorted, ss));
     // the caller's stream may overwrite the scalars once the digits are extracted
     if (!scalars_stable) CZK_HIP(ctx, hipStreamWaitEvent(ctx->stream, slot.ev_sorted, 0));
-#ifdef CZK_LAB
-    if (ctx->chaos_drop_wait != 1)   // (the deliberately broken schedule of tests/test_chaos.py)
-#endif
     CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_sorted, 0));
     if (slot.used) CZK_HIP(ctx, hipStreamWaitEvent(sa, slot.ev_red, 0));   // slot's buckets are read by its reduce
     ctx->msm_launch_split = b->split;
@@ -1189,7 +1189,12 @@ static int msm_enqueue(czk_ctx* ctx, const czk_bases* b, const u64* scalars, siz
     CZK_HIP(ctx, hipGetLastError());
     CZK_HIP(ctx, hipEventRecord(slot.ev_acc, sa));
 #ifdef CZK_LAB
-    if (ctx->chaos_drop_wait != 2)
+    // the deliberately broken schedule of tests/test_chaos.py: the reduce stream waits for the digit sort only, not for the accumulate kernel -- it then folds buckets
+    // that are stale or half written (wrong results, which the harness must notice), while everything else it reads (entry lists, counts, offsets) is complete and
+    // well formed, and the slot's sort buffers stay protected (the extra wait for ev_acc above).  (Dropping the accumulate stream's wait for the sort instead lets
+    // kernels read another call's buffer layout as counts and indices: memory faults and minute-long loops -- that was the first version of this switch.)
+    if (ctx->chaos_drop_wait) CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_sorted, 0));
+    else
 #endif
     CZK_HIP(ctx, hipStreamWaitEvent(sr, slot.ev_acc, 0));
     // work items beyond the first 1024 entries of over-full buckets (none with uniformly random scalars): reduce stream
