@@ -1032,6 +1032,69 @@ def host_demo_exe() -> str:
     return exe
 
 
+def contexts_in_flight_report(czk, torch, device, args, n_constraints, first, ref_aff, contexts: int, steps: int, value: float) -> dict:
+    """`contexts` independent Groth16 pipelines on this GPU at once -- each its own czk context, streams, share lanes and key, one host thread each, `steps`
+    pipelined proofs per context -- as a deployment that only wants throughput would run it (the polynomial provers' `--inflight`, for Groth16).  `value` is ONE
+    context's pipeline, whose accumulate kernels run one after the other; with several contexts the kernels of different proofs share the GPU (a G2 accumulate
+    kernel of one beside G1 kernels, transforms and sorts of the others).  Measured: 0.99 - 1.02 x `value` with 2 - 4 contexts (EXPERIMENTS.md section 14) -- one pipeline
+    already fills the GPU.  Never `value`: per-kernel launch times stretch when launches overlap, and the roofline block is defined on one launch at a time.  Every context's last proof must equal the headline's in affine."""
+    import threading
+    from czk_amd.provers import Groth16Local
+    ctx0, p0, ts0 = first
+    provers = [first]
+    t0 = time.perf_counter()
+    for _ in range(contexts - 1):
+        ts = torch.cuda.Stream()
+        with torch.cuda.stream(ts):
+            c = czk.Context(device, ts.cuda_stream, options=args.ctx_options)
+            p = Groth16Local(czk, c, n_constraints, args.parties, no_tables=args.no_tables, scheme=args.scheme)
+            p.msm_order = p0.msm_order
+            p.step()
+            p.step()
+        provers.append((c, p, ts))
+    setup_s = time.perf_counter() - t0
+    saved = list(p0.all_results)
+    for _, p, _ in provers:
+        p.all_results.clear()
+    errs = []
+
+    def work(i):
+        try:
+            c, p, ts = provers[i]
+            torch.cuda.set_device(device)           # torch's current device is per thread
+            with torch.cuda.stream(ts):
+                for _ in range(steps):
+                    p.step(sync=False)
+                c.sync()
+        except BaseException as e:      # noqa: BLE001 -- re-raised on the main thread
+            errs.append(e)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(contexts)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if errs:
+        raise errs[0]
+    equal = True
+    for c, p, _ in provers:
+        assert len(p.all_results) == steps
+        for k, v in p.all_results[-1].items():
+            aff = c.jac_to_affine(czk.CZK_G2 if k == "b_g2" else czk.CZK_G1, v)
+            equal = equal and bool(np.array_equal(aff[0], ref_aff[k][0]) and np.array_equal(aff[1], ref_aff[k][1]))
+    p0.all_results[:] = saved
+    for c, p, _ in provers[1:]:
+        p.all_results.clear()
+        c.close()
+    proofs = contexts * steps
+    return {"contexts": contexts, "proofs": proofs, "proofs_per_s": proofs / dt, "ms_per_proof": dt / proofs * 1e3, "vs_value": proofs / dt / value,
+            "last_proofs_equal_the_headline's": equal, "setup_s_of_the_extra_contexts": setup_s,
+            "note": "independent pipelines on one GPU, one czk context and one host thread each, every context with its own key; never `value` (see DESIGN.md section 5)"}
+
+
 def seam_device_handles(n_constraints: int, parties: int, steps: int, warmup: int, value: float) -> dict:
     """The same step from a torch-free, Python-free host: tools/host_demo.cpp `bench` (C++ over include/czk.hpp, the mirror of the
     Rust shim) builds the same circuit, key and shares from host vectors, uploads the share lanes ONCE into czk_lanes handles,
@@ -1108,6 +1171,8 @@ def main():
     ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE", help="czk_ctx_set_option on every context before any key is registered "
                                                                                              "(e.g. msm_window_g1=18); repeatable")
     ap.add_argument("--msm-order", default=None, help="groth16, A/B: enqueue order of the four witness-only MSMs, e.g. l,a,b_g1,b_g2 (default l,b_g2,a,b_g1)")
+    ap.add_argument("--contexts-report", type=int, default=0, help="groth16, one GPU: also time this many independent pipelines (contexts) on the GPU at once and "
+                    "report their aggregate as `contexts_in_flight` (default 0 = skip: measured at 0.99 - 1.02 x `value`, EXPERIMENTS.md section 14)")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the `other_workloads` report (configs[2], [3] and the configs[4] size as short child runs)")
     ap.add_argument("--no-multi-gpu-report", action="store_true", help="--gpus N > 1, replica layout: skip the party / split layout children rank 0 runs after the replica line")
     ap.add_argument("--report-budget-s", type=float, default=240.0, help="wall-clock budget of the multi-GPU report; children that would start beyond it are skipped")
@@ -1417,6 +1482,14 @@ def main():
         "stream_elapsed_ms_per_step": {**breakdown, "note": STREAM_ELAPSED_NOTE},
         "setup_key_s": prover.setup_key_s,
     }
+    if (rank == 0 and world == 1 and args.contexts_report > 1 and not party_layout and not split_layout and ref_aff is not None
+            and not os.environ.get("CZK_BENCH_CHILD")):
+        try:
+            out["contexts_in_flight"] = contexts_in_flight_report(czk, torch, device, args, n_constraints, (ctx, prover, tstream), ref_aff, args.contexts_report, args.steps,
+                                                                  proofs / dt)
+        except Exception as e:      # noqa: BLE001 -- the report must not take the headline down with it
+            out["contexts_in_flight"] = {"error": repr(e)[-400:]}
+            torch.cuda.empty_cache()
     if real_key_report is not None:
         out["proof_verifies"] = real_key_report
         out["data"] = "synthetic circuit, REAL proving key (known toxic waste)"
